@@ -1,0 +1,177 @@
+/*
+ * omgsr_hip.h — C ABI of libomgsr_hip.so, the gfx950 (MI355X) kernel library under the
+ * diffusers-shaped module surface that OMGSR's inference pipeline consumes.
+ *
+ * The reference (wuer5/OMGSR) has no FFI of its own: its hot path calls diffusers modules
+ * (infer/omgsr_s_infer_model.py:75-85,173; infer/omgsr_f_infer_model.py:15-18,191-211) which
+ * dispatch to torch's L0 ops (F.conv2d, F.group_norm, F.linear, F.layer_norm,
+ * F.scaled_dot_product_attention, F.interpolate ...).  Each entry point below replaces one such
+ * L0 op family; the comment on each names the torch op / reference call
+ * site it stands in for.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless stated otherwise; activations are bf16 NHWC
+ *    ([N,H,W,C]; a token matrix [B,L,C] is the same thing with H*W = L)
+ *  - no allocation inside the library: callers pass outputs and workspaces
+ *  - `stream` is a hipStream_t passed as void* (0 = null stream)
+ *  - return value: 0 on success, a hipError_t (>0) from the launch, or a negative OMGSR_E_* code
+ *    for an unsupported shape/argument; nothing is launched when a negative code is returned
+ */
+#ifndef OMGSR_HIP_H
+#define OMGSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMGSR_E_BADARG (-1)   /* null pointer / non-positive dimension            */
+#define OMGSR_E_SHAPE (-2)    /* dimension not supported by the kernel (alignment) */
+#define OMGSR_E_ARCH (-3)     /* device is not gfx950                               */
+
+#define OMGSR_ACT_NONE 0
+#define OMGSR_ACT_SILU 1
+#define OMGSR_ACT_GELU_TANH 2
+#define OMGSR_ACT_GEGLU 3     /* out[:, j] = a_j * gelu_erf(g_j); weight rows packed [32 a | 32 g] per 64 */
+
+#define OMGSR_OUT_BF16 0
+#define OMGSR_OUT_F32 1
+
+#define OMGSR_LAYOUT_NHWC 0   /* out[m][n]                                                        */
+#define OMGSR_LAYOUT_T 1      /* out[(m / t_rows) * Cout + n][m % t_rows] with row stride t_ld     */
+
+/* ABI version: bump on any struct change. */
+int omgsr_abi_version(void);
+/* 0 when the current device is gfx950, OMGSR_E_ARCH otherwise. */
+int omgsr_check_device(void);
+const char* omgsr_error_string(int code);
+
+/*
+ * K1/K2/K3/K5/K6 — implicit-GEMM convolution / linear / batched GEMM on MFMA
+ * (replaces F.conv2d, F.linear, F.interpolate(nearest,2x)+conv, torch.bmm/baddbmm).
+ *   out[m, n] = epilogue( alpha * sum_{r,s,c} in[img, vy(r), vx(s), c] * weight[n, (r*S+s)*Cin + c] )
+ * with m = (img, oy, ox); virtual input coords vy = oy*stride - pad_top + r (same for x); when
+ * `upsample` is 1 the virtual input is the nearest-2x upsampling of `in` (vy>>1), never materialised.
+ * epilogue(v): v += bias[n]; v = act(v); v *= gate[n]; v += residual[m, n].
+ * Requirements: Cin % 8 == 0; weight packed [Cout_pad][K_pad] bf16 with Cout_pad % 128 == 0
+ * (zero rows) and K_pad = roundup(R*S*Cin, 32) (zero columns).
+ */
+typedef struct omgsr_igemm_args {
+    const void* in;        /* bf16 [batch][N,H,W,Cin]                                 */
+    const void* weight;    /* bf16 [batch?][Cout_pad][K_pad]                           */
+    const float* bias;     /* f32 [Cout] (GEGLU: [2*Cout] packed like the rows) | NULL */
+    const float* gate;     /* f32 [Cout] | NULL                                        */
+    const void* residual;  /* bf16, same layout as out (NHWC only) | NULL              */
+    void* out;             /* bf16 or f32                                              */
+    int32_t N, H, W, Cin;  /* input geometry (per batch entry)                         */
+    int32_t Cout;          /* logical output channels (GEGLU: the halved count)        */
+    int32_t Cout_pad, K_pad;
+    int32_t R, S, stride, pad_top, pad_left, upsample;
+    int32_t Ho, Wo;
+    int32_t act, out_dtype, out_layout;
+    int32_t t_rows, t_ld;  /* OMGSR_LAYOUT_T only                                      */
+    int32_t batch;         /* grid.z; strides below are in elements                    */
+    int64_t in_bstride, w_bstride, out_bstride;
+    float alpha;
+} omgsr_igemm_args;
+int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
+
+/*
+ * K4 — GroupNorm statistics and apply (replaces F.group_norm; the externally supplied
+ * (mean, var) form is what infer/vaehook.py:384-413 custom_group_norm needs).
+ * stats: x bf16 [N, HW, C]; partial f32 [N][nchunk][G][2] workspace; mean/rstd f32 [N][G].
+ * nchunk = omgsr_groupnorm_nchunk(HW).  `var_out` (optional) receives the biased variance.
+ */
+int omgsr_groupnorm_nchunk(int64_t HW);
+int omgsr_groupnorm_stats(const void* x, float* partial, float* mean, float* rstd, float* var_out,
+                          int32_t N, int64_t HW, int32_t C, int32_t G, float eps, void* stream);
+/* y = act((x - mean[n,g]) * rstd[n,g] * gamma[c] + beta[c]);  act in {NONE, SILU}. x and y may alias. */
+int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int32_t N, int64_t HW, int32_t C,
+                          int32_t G, int32_t act, void* stream);
+
+/*
+ * K9/K10 — LayerNorm over the last dim (replaces F.layer_norm and the AdaLN-Zero modulate chain of
+ * FluxTransformerBlock): y = (x - mu) * rsqrt(var + eps) * a[c] + b[c], a/b f32 [C] or NULL (1 / 0).
+ */
+int omgsr_layernorm(const void* x, void* y, const float* a, const float* b, int64_t rows, int32_t C,
+                    float eps, void* stream);
+
+/*
+ * K7/K8 — fused softmax(Q K^T * scale) V on MFMA (replaces F.scaled_dot_product_attention).
+ * q  bf16 rows [B][Lq]  with row stride q_ld,  head h at column h*D
+ * k  bf16 rows [B][Lk]  with row stride k_ld
+ * vt bf16 V TRANSPOSED: [B][H*D][vt_ld], key index contiguous (written by omgsr_igemm LAYOUT_T)
+ * o  bf16 rows [B][Lq]  with row stride o_ld
+ * D in {64, 128}; Lk arbitrary (keys >= Lk are masked); kv_bstride 0 broadcasts one K/V to all B.
+ */
+typedef struct omgsr_attn_args {
+    const void* q; const void* k; const void* vt; void* o;
+    int32_t B, H, D, Lq, Lk;
+    int64_t q_ld, k_ld, vt_ld, o_ld;
+    int64_t q_bstride, k_bstride, vt_bstride, o_bstride;
+    float scale;
+} omgsr_attn_args;
+int omgsr_attention(const omgsr_attn_args* a, void* stream);
+
+/* Row softmax for the unfused d=512 VAE attention: p = softmax(s) ; s f32 [rows][L], p bf16 [rows][L]. */
+int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t L, void* stream);
+
+/*
+ * K11 — RMSNorm(q,k over head_dim) * w then interleaved-pair RoPE, in place
+ * (FluxAttnProcessor2_0: norm_q/norm_k + apply_rotary_emb).  x bf16 rows [B*L] with stride ld,
+ * head h at column col0 + h*D; w f32 [D]; cos/sin f32 [L][D] (repeat-interleaved pairs); rope may be NULL.
+ */
+int omgsr_rmsnorm_rope(void* x, const float* w, const float* cos_t, const float* sin_t, int32_t B,
+                       int32_t L, int32_t H, int32_t D, int64_t ld, int32_t col0, int32_t pos0,
+                       float eps, void* stream);
+
+/* K14 — layout and latent algebra. */
+/* NCHW (f32 or bf16 per src_dtype: 0 bf16, 1 f32) -> NHWC bf16 with channels zero-padded to Cpad. */
+int omgsr_nchw_to_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                       int32_t Cpad, int32_t src_dtype, void* stream);
+/* NHWC bf16 (row stride ld, first C channels) -> NCHW (dst_dtype 0 bf16, 1 f32); optional clamp to [lo,hi]. */
+int omgsr_nhwc_to_nchw(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                       int32_t ld, int32_t dst_dtype, int32_t do_clamp, float lo, float hi, void* stream);
+/* dst[..., off:off+C] = src (bf16 rows) — channel concat building block (torch.cat(dim=1) in NCHW). */
+int omgsr_copy_channels(const void* src, void* dst, int64_t rows, int32_t C, int32_t src_ld,
+                        int32_t dst_ld, int32_t dst_off, void* stream);
+/*
+ * DiagonalGaussianDistribution.sample() * scale (infer/omgsr_s_infer_model.py:173,
+ * infer/omgsr_f_infer_model.py:16-17): z = ((mu + exp(0.5*clamp(logvar,-30,20)) * eps) - shift) * scale.
+ * moments bf16 NHWC [rows][2*C]; eps f32 NHWC [rows][C]; z bf16 NHWC [rows][ld_out] (cols >= C zeroed).
+ */
+int omgsr_vae_sample(const void* moments, const float* eps, void* z, int64_t rows, int32_t C,
+                     int32_t ld_out, float shift, float scale, void* stream);
+/* out = (x * a + y * b + c) * d, bf16 tensors with bf16 rounding after every op when `bf16_steps`
+ * (mirrors the reference's eager bf16 arithmetic, infer/omgsr_s_infer_model.py:80-84). */
+int omgsr_axpby(const void* x, const void* y, void* out, int64_t n, float a, float b, float c, float d,
+                int32_t bf16_steps, void* stream);
+/* acc[n,y0+y,x0+x,c] += tile[n,y,x,c] * w[y,x] (f32 acc, bf16 tile NHWC ld=tile_ld), and the matching
+ * normaliser; infer/omgsr_s_infer_model.py:137-161. */
+int omgsr_tile_accumulate(const void* tile, const float* w, float* acc, int32_t N, int32_t C,
+                          int32_t th, int32_t tw, int32_t tile_ld, int32_t H, int32_t W, int32_t y0,
+                          int32_t x0, void* stream);
+/* out bf16[rows][ld] = acc f32[rows][C] / wsum[pixel]  (cols >= C zeroed) */
+int omgsr_tile_normalise(const float* acc, const float* wsum, void* out, int32_t N, int64_t HW,
+                         int32_t C, int32_t ld, void* stream);
+/* bf16 window copy: dst[n,y,x,:] = src[n,y0+y,x0+x,:] */
+int omgsr_crop_nhwc(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t y0,
+                    int32_t x0, int32_t th, int32_t tw, void* stream);
+/* Flux 2x2 pack / unpack between NHWC [N,H,W,C(ld)] and tokens [N,(H/2)(W/2),4C] with channel
+ * order c*4 + dy*2 + dx (infer/omgsr_f_infer_model.py:21-41). dir 0 = pack, 1 = unpack. */
+int omgsr_flux_pack(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ld,
+                    int32_t dir, void* stream);
+
+/* Optional per-launch timing (HIP events on the launch stream) for bench.py's roofline leg. */
+int omgsr_timing_enable(int on);
+int omgsr_timing_reset(void);
+/* Synchronises, then fills up to `cap` entries; returns the number of recorded launches. */
+typedef struct omgsr_timing_entry { int32_t kind; float ms; double flops; double bytes; } omgsr_timing_entry;
+int omgsr_timing_collect(omgsr_timing_entry* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMGSR_HIP_H */

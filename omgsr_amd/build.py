@@ -1,0 +1,68 @@
+"""Builds libomgsr_hip.so (the C-ABI kernel library, include/omgsr_hip.h) for gfx950 with hipcc.
+
+The .so is written in-tree (omgsr_amd/lib/) so that it travels to the GPU box with the repo
+snapshot; it is git-ignored. hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIBNAME = "libomgsr_hip.so"
+SOURCES = ["igemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+ARCH = "gfx950"
+
+
+def lib_path() -> str:
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def _source_digest() -> str:
+    h = hashlib.sha256()
+    names = sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "omgsr_hip.h")]
+    for n in names:
+        p = os.path.join(CSRC, n)
+        if os.path.isfile(p):
+            h.update(n.encode())
+            with open(p, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source into one shared library; returns its path."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = lib_path()
+    stamp = out + ".sha256"
+    digest = _source_digest()
+    if not force and os.path.isfile(out) and os.path.isfile(stamp) and open(stamp).read().strip() == digest:
+        return out
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libomgsr_hip.so")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+               "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,243 @@
+// Fused attention softmax(Q K^T * scale) V for gfx950, head_dim 64 / 128, bf16 in, fp32 softmax.
+// Replaces F.scaled_dot_product_attention under diffusers' AttnProcessor2_0 / FluxAttnProcessor2_0
+// (UNet self/cross attention, Flux joint attention).
+//
+// CDNA4 design notes
+//  * one workgroup = 4 waves (one per SIMD) = 128 queries; a wave owns 32 queries for the whole
+//    key sweep, K/V tiles of 64 keys are shared by the 4 waves through LDS (register-staged double
+//    buffering, one barrier per tile)
+//  * scores are computed TRANSPOSED, S^T = K Q^T, with v_mfma_f32_32x32x16_bf16: the C layout then
+//    puts one query per lane (col = lane & 31) and its keys in registers, so the online-softmax
+//    row statistics are register-local plus one exchange with lane ^ 32
+//  * O is accumulated transposed too (O^T = V^T P^T), so the per-query rescale factor is
+//    lane-local; the P^T operand is the score registers converted in place: the MFMA contraction
+//    index is a PERMUTATION of the key index (slot j of half h <-> key (j&3) + 8*(j>>2) + 4h),
+//    matched on the V side by reading two 8-byte pieces of the transposed V tile - no cross-lane
+//    shuffles, no LDS round trip for P
+//  * V arrives transposed from the projection GEMM's epilogue (OMGSR_LAYOUT_T), so the key index
+//    is contiguous and every operand fragment is a 16-byte (K) or 2 x 8-byte (V^T) LDS read
+//  * LDS pitches: K rows 2*D+16 B (odd number of 16-B slots -> conflict-free ds_read_b128),
+//    V^T rows 136 B (34 banks -> conflict-free ds_read_b64)
+#include "common.hip.h"
+#include "../../include/omgsr_hip.h"
+#include "timing.hip.h"
+
+namespace {
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_kernel(const omgsr_attn_args p, const int ntiles) {
+    constexpr int KP = 2 * D + 16;
+    constexpr int VP = 136;
+    constexpr int K_BYTES = 64 * KP, V_BYTES = D * VP;
+    constexpr int STAGE = K_BYTES + V_BYTES;
+    constexpr int CPR = D / 8;               // 16-byte chunks per K row
+    constexpr int NKC = 64 * CPR / 256;      // K chunks per thread
+    constexpr int NVC = D * 8 / 256;         // V^T chunks per thread
+    constexpr int NKS = D / 16, NDB = D / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const bf16_t* __restrict__ qp = (const bf16_t*)p.q + (int64_t)b * p.q_bstride + h * D;
+    const bf16_t* __restrict__ kp = (const bf16_t*)p.k + (int64_t)b * p.k_bstride + h * D;
+    const bf16_t* __restrict__ vp = (const bf16_t*)p.vt + (int64_t)b * p.vt_bstride + (int64_t)h * D * p.vt_ld;
+
+    // Q^T operand fragments live in registers for the whole sweep
+    bf16x8_t qf[NKS];
+    {
+        int qrow = q0 + l31; if (qrow > p.Lq - 1) qrow = p.Lq - 1;
+        const bf16_t* qr = qp + (int64_t)qrow * p.q_ld + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qr + 16 * ks);
+    }
+
+    u32x4_t kreg[NKC], vreg[NVC];
+    auto load_tile = [&](int kt) {
+        const int key_base = kt * 64;
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            const int c = t + 256 * i;
+            const int row = c / CPR, kc = c % CPR;
+            const int key = key_base + row;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (key < p.Lk) v = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)key * p.k_ld + kc * 8);
+            kreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = t + 256 * i;
+            const int drow = c >> 3, kc = c & 7;
+            const int key0 = key_base + kc * 8;
+            const int nvalid = p.Lk - key0;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (nvalid > 0) {
+                v = *reinterpret_cast<const u32x4_t*>(vp + (int64_t)drow * p.vt_ld + key0);
+                if (nvalid < 8) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        if (2 * w >= nvalid) v[w] = 0u;
+                        else if (2 * w + 1 >= nvalid) v[w] &= 0xffffu;
+                    }
+                }
+            }
+            vreg[i] = v;
+        }
+    };
+    auto write_tile = [&](int buf) {
+        unsigned char* Ks = lds + buf * STAGE;
+        unsigned char* Vs = Ks + K_BYTES;
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            const int c = t + 256 * i;
+            *reinterpret_cast<u32x4_t*>(Ks + (c / CPR) * KP + (c % CPR) * 16) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = t + 256 * i;
+            unsigned char* d = Vs + (c >> 3) * VP + (c & 7) * 16;     // 8-byte aligned only
+            *reinterpret_cast<u32x2_t*>(d) = (u32x2_t){vreg[i][0], vreg[i][1]};
+            *reinterpret_cast<u32x2_t*>(d + 8) = (u32x2_t){vreg[i][2], vreg[i][3]};
+        }
+    };
+
+    f32x16_t o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float sc = p.scale * 1.4426950408889634f;   // softmax in base 2
+
+    load_tile(0);
+    write_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) load_tile(kt + 1);
+        const unsigned char* Ks = lds + buf * STAGE;
+        const unsigned char* Vs = Ks + K_BYTES;
+
+        // S^T = K Q^T : two 32-key blocks
+        f32x16_t s[2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sb][r] = 0.0f;
+            const unsigned char* kr = Ks + (32 * sb + l31) * KP + half * 16;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
+                s[sb] = mfma32(kf, qf[ks], s[sb]);
+            }
+        }
+        // online softmax (one query per lane pair)
+        const bool tail = (kt == ntiles - 1) && (p.Lk & 63);
+        float mt = -INFINITY;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[sb][r] * sc;
+                if (tail && (kt * 64 + 32 * sb + cfrag_row(lane, r) >= p.Lk)) v = -INFINITY;
+                s[sb][r] = v;
+                mt = fmaxf(mt, v);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.0f;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(s[sb][r] - m_new);
+                s[sb][r] = e;
+                rs += e;
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+        // P^T operand: score registers converted in place (key permutation, see header)
+        bf16x8_t pf[2][2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[sb][u][j] = (bf16_t)s[sb][8 * u + j];
+
+        // O^T += V^T P^T
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const unsigned char* vr = Vs + (32 * db + l31) * VP + 8 * half;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned char* a = vr + (32 * sb + 16 * u) * 2;
+                    const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(a);
+                    const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(a + 16);
+                    const u32x4_t both = {lo[0], lo[1], hi[0], hi[1]};
+                    o[db] = mfma32(*reinterpret_cast<const bf16x8_t*>(&both), pf[sb][u], o[db]);
+                }
+        }
+        if (kt + 1 < ntiles) write_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + l31;
+    if (qrow < p.Lq) {
+        bf16_t* op = (bf16_t*)p.o + (int64_t)b * p.o_bstride + (int64_t)qrow * p.o_ld + h * D + 4 * half;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2_t w;
+                w[0] = pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+                w[1] = pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g) = w;
+            }
+    }
+}
+
+template <int D>
+int launch_attn(const omgsr_attn_args& a, hipStream_t st) {
+    constexpr int LDS = 2 * (64 * (2 * D + 16) + D * 136);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int ntiles = (a.Lk + 63) / 64;
+    dim3 grid((a.Lq + 127) / 128, a.H, a.B);
+    hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), LDS, st, a, ntiles);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int omgsr_attention(const omgsr_attn_args* ap, void* stream) {
+    if (!ap || !ap->q || !ap->k || !ap->vt || !ap->o) return OMGSR_E_BADARG;
+    const omgsr_attn_args a = *ap;
+    if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return OMGSR_E_BADARG;
+    if ((a.q_ld & 7) || (a.k_ld & 7) || (a.vt_ld & 7) || (a.o_ld & 3) || a.vt_ld < a.Lk) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const double flops = 4.0 * (double)a.B * a.H * (double)a.Lq * a.Lk * a.D;
+    const double bytes = 2.0 * (double)a.B * a.H * a.D * (2.0 * a.Lq + 2.0 * a.Lk);
+    omgsr::TimingScope ts(OMGSR_TK_ATTN, flops, bytes, st);
+    if (a.D == 64) return launch_attn<64>(a, st);
+    if (a.D == 128) return launch_attn<128>(a, st);
+    return OMGSR_E_SHAPE;
+}

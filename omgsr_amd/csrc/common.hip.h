@@ -1,0 +1,79 @@
+// Shared device helpers for the OMGSR gfx950 kernels.
+// Wave = 64 lanes; MFMA fragment layouts follow the CDNA4 ISA (v_mfma_f32_32x32x16_bf16):
+//   A frag (32 x 16): lane l holds row (l & 31), k = 8*(l >> 5) + j, j = 0..7
+//   B frag (16 x 32): lane l holds col (l & 31), k = 8*(l >> 5) + j
+//   C/D   (32 x 32): lane l holds col (l & 31), row = (r & 3) + 8*(r >> 2) + 4*(l >> 5), r = 0..15
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+#define OMGSR_DEVINL __device__ __forceinline__
+
+OMGSR_DEVINL f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// row index inside a 32x32 C fragment held by (lane, reg)
+OMGSR_DEVINL int cfrag_row(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+OMGSR_DEVINL float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
+
+OMGSR_DEVINL void unpack8(const u32x4_t v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+
+OMGSR_DEVINL unsigned int pack2(float lo, float hi) {
+    bf16x2_t r = __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t);
+    return *reinterpret_cast<unsigned int*>(&r);
+}
+
+OMGSR_DEVINL u32x4_t pack8(const float (&f)[8]) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+OMGSR_DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+OMGSR_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+OMGSR_DEVINL float gelu_tanh_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    // tanh(u) = 1 - 2/(1+exp(2u)); saturates cleanly for large |u|
+    float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
+    return 0.5f * x * (1.0f + t);
+}
+
+OMGSR_DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+OMGSR_DEVINL float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// XCD-aware bijective remap of a linear block id: blocks that land on one XCD (b % 8) get a
+// contiguous range of logical tile ids so neighbouring tiles share that XCD's L2.
+OMGSR_DEVINL int xcd_remap(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

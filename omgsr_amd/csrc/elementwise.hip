@@ -1,0 +1,294 @@
+// Layout changes and latent algebra plus the library's housekeeping entry
+// points. Everything here is HBM-bound plumbing around the MFMA kernels.
+#include "common.hip.h"
+#include "../../include/omgsr_hip.h"
+#include "timing.hip.h"
+#include <string.h>
+
+namespace omgsr {
+TimingState& timing_state() { static TimingState s; return s; }
+}
+
+namespace {
+
+OMGSR_DEVINL float bf16_round(float x) { return (float)(bf16_t)x; }
+
+// NCHW -> NHWC(Cpad) bf16. One thread per output pixel-channel-group of 8.
+template <typename SRC>
+__global__ void nchw_to_nhwc_kernel(const SRC* __restrict__ src, bf16_t* __restrict__ dst, int N, int C, int64_t HW, int Cpad) {
+    const int ng = Cpad >> 3;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * HW * ng;
+    if (i >= total) return;
+    const int g = (int)(i % ng);
+    const int64_t pix = i / ng;
+    const int n = (int)(pix / HW);
+    const int64_t hw = pix - (int64_t)n * HW;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        f[e] = (c < C) ? (float)src[((int64_t)n * C + c) * HW + hw] : 0.0f;
+    }
+    *reinterpret_cast<u32x4_t*>(dst + pix * Cpad + g * 8) = pack8(f);
+}
+
+// NHWC(ld) bf16 -> NCHW. Thread per (n, c, hw) element; hw fastest => coalesced writes.
+template <typename DST>
+__global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ src, DST* __restrict__ dst, int N, int C, int64_t HW, int ld,
+                                    int do_clamp, float lo, float hi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * C * HW;
+    if (i >= total) return;
+    const int64_t hw = i % HW;
+    const int64_t nc = i / HW;
+    const int c = (int)(nc % C);
+    const int n = (int)(nc / C);
+    float v = (float)src[((int64_t)n * HW + hw) * ld + c];
+    if (do_clamp) v = fminf(fmaxf(v, lo), hi);
+    dst[i] = (DST)v;
+}
+
+__global__ void copy_channels_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int C, int src_ld,
+                                     int dst_ld, int dst_off) {
+    const int ng = C >> 3;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ng) return;
+    const int g = (int)(i % ng);
+    const int64_t r = i / ng;
+    *reinterpret_cast<u32x4_t*>(dst + r * dst_ld + dst_off + g * 8) =
+        *reinterpret_cast<const u32x4_t*>(src + r * src_ld + g * 8);
+}
+
+// z = ((mu + exp(0.5*clamp(logvar,-30,20)) * eps) - shift) * scale, fp32 math, one rounding.
+__global__ void vae_sample_kernel(const bf16_t* __restrict__ mom, const float* __restrict__ eps, bf16_t* __restrict__ z, int64_t rows,
+                                  int C, int ld_out, float shift, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ld_out) return;
+    const int c = (int)(i % ld_out);
+    const int64_t r = i / ld_out;
+    float out = 0.0f;
+    if (c < C) {
+        const float mu = (float)mom[r * 2 * C + c];
+        float lv = (float)mom[r * 2 * C + C + c];
+        lv = fminf(fmaxf(lv, -30.0f), 20.0f);
+        out = ((mu + __expf(0.5f * lv) * eps[r * C + c]) - shift) * scale;
+    }
+    z[i] = (bf16_t)out;
+}
+
+__global__ void axpby_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, bf16_t* __restrict__ out, int64_t n, float a,
+                             float b, float c, float d, int steps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xv = (float)x[i];
+    const float yv = y ? (float)y[i] : 0.0f;
+    float v;
+    if (steps) {
+        const float t0 = (a == 1.0f) ? xv : bf16_round(xv * a);
+        const float t1 = y ? bf16_round(yv * b) : 0.0f;
+        v = y ? bf16_round(t0 + t1) : t0;
+        if (c != 0.0f) v = bf16_round(v + c);
+        if (d != 1.0f) v = bf16_round(v * d);
+    } else {
+        v = (xv * a + yv * b + c) * d;
+    }
+    out[i] = (bf16_t)v;
+}
+
+// acc[n, y0+y, x0+x, c] += tile[n,y,x,c] * w[y,x]; wsum[n?]: handled by a second call with tile==NULL
+__global__ void tile_accumulate_kernel(const bf16_t* __restrict__ tile, const float* __restrict__ w, float* __restrict__ acc, int N,
+                                       int C, int th, int tw, int tile_ld, int H, int W, int y0, int x0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * th * tw * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int x = (int)(r % tw); r /= tw;
+    const int y = (int)(r % th);
+    const int n = (int)(r / th);
+    const float wv = w[y * tw + x];
+    const float tv = tile ? (float)tile[(((int64_t)n * th + y) * tw + x) * tile_ld + c] : 1.0f;
+    acc[(((int64_t)n * H + y0 + y) * W + x0 + x) * C + c] += tv * wv;
+}
+
+__global__ void tile_normalise_kernel(const float* __restrict__ acc, const float* __restrict__ wsum, bf16_t* __restrict__ out, int N,
+                                      int64_t HW, int C, int ld) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * HW * ld) return;
+    const int c = (int)(i % ld);
+    const int64_t pix = i / ld;
+    float v = 0.0f;
+    if (c < C) v = acc[pix * C + c] / wsum[pix % HW];
+    out[i] = (bf16_t)v;
+}
+
+__global__ void crop_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int H, int W, int C, int y0, int x0, int th,
+                            int tw) {
+    const int ng = C >> 3;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * th * tw * ng) return;
+    const int g = (int)(i % ng);
+    int64_t r = i / ng;
+    const int x = (int)(r % tw); r /= tw;
+    const int y = (int)(r % th);
+    const int n = (int)(r / th);
+    *reinterpret_cast<u32x4_t*>(dst + i * 8) =
+        *reinterpret_cast<const u32x4_t*>(src + (((int64_t)n * H + y0 + y) * W + x0 + x) * C + g * 8);
+}
+
+// Flux 2x2 pack: tokens[n, (y/2)*(W/2) + x/2, c*4 + (y&1)*2 + (x&1)] <-> nhwc[n, y, x, c]
+__global__ void flux_pack_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int H, int W, int C, int ld, int dir) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * H * W * C) return;
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    const int64_t nhwc = (((int64_t)n * H + y) * W + x) * ld + c;
+    const int64_t tok = (((int64_t)n * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * (4 * C) + c * 4 + (y & 1) * 2 + (x & 1);
+    if (dir == 0) dst[tok] = src[nhwc]; else dst[nhwc] = src[tok];
+}
+
+inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)((total + block - 1) / block)); }
+
+}  // namespace
+
+extern "C" int omgsr_abi_version(void) { return 1; }
+
+extern "C" int omgsr_check_device(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return OMGSR_E_ARCH;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return OMGSR_E_ARCH;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 0 : OMGSR_E_ARCH;
+}
+
+extern "C" const char* omgsr_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case OMGSR_E_BADARG: return "omgsr: bad argument (null pointer or non-positive dimension)";
+        case OMGSR_E_SHAPE: return "omgsr: shape/alignment not supported by the gfx950 kernel";
+        case OMGSR_E_ARCH: return "omgsr: current device is not gfx950 (MI355X)";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "omgsr: unknown error";
+    }
+}
+
+extern "C" int omgsr_nchw_to_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad,
+                                  int32_t src_dtype, void* stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0) return OMGSR_E_BADARG;
+    if ((Cpad & 7) || Cpad < C) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t HW = (int64_t)H * W, total = (int64_t)N * HW * (Cpad >> 3);
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 2.0 * N * HW * (C + Cpad), st);
+    if (src_dtype == 1) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid1d(total), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, N, C, HW, Cpad);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, C, HW, Cpad);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_nhwc_to_nchw(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ld,
+                                  int32_t dst_dtype, int32_t do_clamp, float lo, float hi, void* stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return OMGSR_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t HW = (int64_t)H * W, total = (int64_t)N * C * HW;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 4.0 * total, st);
+    if (dst_dtype == 1) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, N, C, HW, ld, do_clamp, lo, hi);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, C, HW, ld, do_clamp, lo, hi);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_copy_channels(const void* src, void* dst, int64_t rows, int32_t C, int32_t src_ld, int32_t dst_ld,
+                                   int32_t dst_off, void* stream) {
+    if (!src || !dst || rows <= 0 || C <= 0) return OMGSR_E_BADARG;
+    if ((C & 7) || (src_ld & 7) || (dst_ld & 7) || (dst_off & 7) || dst_off + C > dst_ld || src_ld < C) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 4.0 * rows * C, st);
+    hipLaunchKernelGGL(copy_channels_kernel, grid1d(rows * (C >> 3)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, C, src_ld, dst_ld, dst_off);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_vae_sample(const void* moments, const float* eps, void* z, int64_t rows, int32_t C, int32_t ld_out,
+                                float shift, float scale, void* stream) {
+    if (!moments || !eps || !z || rows <= 0 || C <= 0 || ld_out < C) return OMGSR_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 10.0 * rows * C, st);
+    hipLaunchKernelGGL(vae_sample_kernel, grid1d(rows * ld_out), dim3(256), 0, st, (const bf16_t*)moments, eps, (bf16_t*)z, rows, C, ld_out, shift, scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_axpby(const void* x, const void* y, void* out, int64_t n, float a, float b, float c, float d,
+                           int32_t bf16_steps, void* stream) {
+    if (!x || !out || n <= 0) return OMGSR_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 6.0 * n, st);
+    hipLaunchKernelGGL(axpby_kernel, grid1d(n), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)out, n, a, b, c, d, bf16_steps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_tile_accumulate(const void* tile, const float* w, float* acc, int32_t N, int32_t C, int32_t th, int32_t tw,
+                                     int32_t tile_ld, int32_t H, int32_t W, int32_t y0, int32_t x0, void* stream) {
+    if (!w || !acc || N <= 0 || C <= 0 || th <= 0 || tw <= 0) return OMGSR_E_BADARG;
+    if (y0 < 0 || x0 < 0 || y0 + th > H || x0 + tw > W || (tile && tile_ld < C)) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)N * th * tw * C;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 10.0 * total, st);
+    hipLaunchKernelGGL(tile_accumulate_kernel, grid1d(total), dim3(256), 0, st, (const bf16_t*)tile, w, acc, N, C, th, tw, tile_ld, H, W, y0, x0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_tile_normalise(const float* acc, const float* wsum, void* out, int32_t N, int64_t HW, int32_t C, int32_t ld,
+                                    void* stream) {
+    if (!acc || !wsum || !out || N <= 0 || HW <= 0 || C <= 0 || ld < C) return OMGSR_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)N * HW * ld;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 6.0 * total, st);
+    hipLaunchKernelGGL(tile_normalise_kernel, grid1d(total), dim3(256), 0, st, acc, wsum, (bf16_t*)out, N, HW, C, ld);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_crop_nhwc(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t y0, int32_t x0,
+                               int32_t th, int32_t tw, void* stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || th <= 0 || tw <= 0) return OMGSR_E_BADARG;
+    if ((C & 7) || y0 < 0 || x0 < 0 || y0 + th > H || x0 + tw > W) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)N * th * tw * (C >> 3);
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 32.0 * total, st);
+    hipLaunchKernelGGL(crop_kernel, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, H, W, C, y0, x0, th, tw);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_flux_pack(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ld, int32_t dir,
+                               void* stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return OMGSR_E_BADARG;
+    if ((H & 1) || (W & 1)) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)N * H * W * C;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 4.0 * total, st);
+    hipLaunchKernelGGL(flux_pack_kernel, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, H, W, C, ld, dir);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_timing_enable(int on) { omgsr::timing_state().on = (on != 0); return 0; }
+
+extern "C" int omgsr_timing_reset(void) {
+    auto& s = omgsr::timing_state();
+    for (auto& r : s.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    s.recs.clear();
+    return 0;
+}
+
+extern "C" int omgsr_timing_collect(omgsr_timing_entry* out, int cap) {
+    auto& s = omgsr::timing_state();
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    int n = 0;
+    for (auto& r : s.recs) {
+        if (out && n < cap) {
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+            out[n].kind = r.kind; out[n].ms = ms; out[n].flops = r.flops; out[n].bytes = r.bytes;
+        }
+        ++n;
+    }
+    return n;
+}

@@ -1,0 +1,302 @@
+// Implicit-GEMM convolution / linear / batched GEMM for gfx950 (MI355X), bf16 in, fp32 accumulate.
+//
+// Replaces the cuDNN/cuBLAS calls under diffusers' ResnetBlock2D / Upsample2D / Downsample2D /
+// Attention / FeedForward on the OMGSR hot path.
+//
+// Structure (CDNA4-first, not a port of a CUDA tiling):
+//   * activations NHWC bf16, weights KRSC bf16  -> both MFMA operands are contiguous along the
+//     contraction index, so every fragment is one 16-byte ds_read_b128
+//   * v_mfma_f32_32x32x16_bf16; 4 waves (one per SIMD) per workgroup; block tile BM x BN, BK = 32
+//   * register-staged double buffering (issue global loads for K-step t+1, run the MFMAs of step t,
+//     then write the staged registers to the other LDS buffer): one barrier per K-step
+//   * LDS rows padded to 80 B = 5 x 16-B slots (odd) => the 16-lane service groups of ds_read_b128
+//     touch 16 distinct slots: conflict-free
+//   * im2col is never materialised: per K-step a thread recomputes (tap, channel) incrementally and
+//     gathers its 16-byte chunk, zero-filling the padding halo; nearest-2x upsampling is folded
+//     into the gather (vy >> 1)
+//   * epilogue goes through LDS in fp32 so global stores/residual loads are 16 B per lane
+//   * blockIdx -> tile mapping is XCD-aware (tiles sharing input rows stay on one XCD's L2)
+#include "common.hip.h"
+#include "../../include/omgsr_hip.h"
+#include "timing.hip.h"
+
+namespace {
+
+constexpr int BK = 32;        // K elements per pipeline step
+constexpr int ROWB = 80;      // LDS row pitch in bytes (64 B of data + 16 B pad)
+constexpr int NTHREADS = 256;
+
+struct Geo {
+    int M;          // N*Ho*Wo rows per batch entry
+    int HoWo;
+    int Hv, Wv;     // virtual (post-upsample) input extent
+    int nk;         // K_pad / BK
+    int ntm, ntn;   // tile counts
+};
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args p, const Geo g) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
+    constexpr int FM = WTM / 32, FN = WTN / 32;     // 32x32 fragments per wave
+    constexpr int A_CH = BM / 64, B_CH = BN / 64;   // 16-byte chunks staged per thread
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(FM >= 1 && FN >= 1 && A_CH >= 1, "tile");
+    constexpr int B_CHN = (B_CH >= 1) ? B_CH : 1;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int EPI_LD = WTN + 4;                 // floats
+    constexpr int EPI_BYTES = 4 * 32 * EPI_LD * 4;
+    constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int tile = xcd_remap(blockIdx.x, g.ntm * g.ntn);
+    const int tn = tile % g.ntn, tm = tile / g.ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int bz = blockIdx.z;
+
+    const bf16_t* __restrict__ in = (const bf16_t*)p.in + (int64_t)bz * p.in_bstride;
+    const bf16_t* __restrict__ wt = (const bf16_t*)p.weight + (int64_t)bz * p.w_bstride;
+
+    // ---- per-thread staging coordinates -------------------------------------------------
+    const int kc = t & 3;      // which 16-byte chunk of the 64-byte K-step row
+    const int r0 = t >> 2;     // 0..63
+    int a_img[A_CH], a_vy0[A_CH], a_vx0[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        if (m < g.M) {
+            const int img = m / g.HoWo;
+            const int rem = m - img * g.HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_img[i] = img;
+            a_vy0[i] = oy * p.stride - p.pad_top;
+            a_vx0[i] = ox * p.stride - p.pad_left;
+        } else {
+            a_img[i] = -1; a_vy0[i] = 0; a_vx0[i] = 0;
+        }
+    }
+    // chunk cursor: this thread's chunk at K-step kt covers k = kt*32 + kc*8 .. +8 = (tap, c0..c0+8)
+    int c0 = kc * 8, tap_r = 0, tap_s = 0;
+    while (c0 >= p.Cin) { c0 -= p.Cin; if (++tap_s == p.S) { tap_s = 0; ++tap_r; } }
+
+    u32x4_t a_reg[A_CH], b_reg[B_CHN];
+
+    auto load_stage = [&](int kt) {
+        const bool tap_ok = tap_r < p.R;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int vy = a_vy0[i] + tap_r, vx = a_vx0[i] + tap_s;
+            const bool ok = tap_ok && a_img[i] >= 0 && (unsigned)vy < (unsigned)g.Hv && (unsigned)vx < (unsigned)g.Wv;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const int iy = vy >> p.upsample, ix = vx >> p.upsample;
+                const int64_t pix = ((int64_t)a_img[i] * p.H + iy) * p.W + ix;
+                v = *reinterpret_cast<const u32x4_t*>(in + pix * p.Cin + c0);
+            }
+            a_reg[i] = v;
+        }
+        if constexpr (B_CH >= 1) {
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) {
+                const int n = n0 + r0 + 64 * i;
+                b_reg[i] = *reinterpret_cast<const u32x4_t*>(wt + (int64_t)n * p.K_pad + kt * BK + kc * 8);
+            }
+        } else {  // BN == 32: only threads with r0 < 32 carry a weight chunk
+            if (r0 < BN) b_reg[0] = *reinterpret_cast<const u32x4_t*>(wt + (int64_t)(n0 + r0) * p.K_pad + kt * BK + kc * 8);
+        }
+        // advance the (tap, channel) cursor by one K-step (32 channels)
+        c0 += BK;
+        while (c0 >= p.Cin) { c0 -= p.Cin; if (++tap_s == p.S) { tap_s = 0; ++tap_r; } }
+    };
+    auto write_stage = [&](int buf) {
+        unsigned char* As = lds + buf * STAGE_BYTES;
+        unsigned char* Bs = As + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i)
+            *reinterpret_cast<u32x4_t*>(As + (r0 + 64 * i) * ROWB + kc * 16) = a_reg[i];
+        if constexpr (B_CH >= 1) {
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i)
+                *reinterpret_cast<u32x4_t*>(Bs + (r0 + 64 * i) * ROWB + kc * 16) = b_reg[i];
+        } else {
+            if (r0 < BN) *reinterpret_cast<u32x4_t*>(Bs + r0 * ROWB + kc * 16) = b_reg[0];
+        }
+    };
+
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    load_stage(0);
+    write_stage(0);
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * ROWB + (lane >> 5) * 16;
+    for (int kt = 0; kt < g.nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < g.nk) load_stage(kt + 1);
+        const unsigned char* As = lds + buf * STAGE_BYTES + wm * WTM * ROWB + frag_off;
+        const unsigned char* Bs = lds + buf * STAGE_BYTES + BM * ROWB + wn * WTN * ROWB + frag_off;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[FM], bf[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + i * 32 * ROWB + ks * 32);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 32 * ROWB + ks * 32);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+        if (kt + 1 < g.nk) write_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: fragments -> LDS (fp32) -> 8 consecutive channels per lane -------------
+    float* epi = reinterpret_cast<float*>(lds) + wave * 32 * EPI_LD;
+    const bool geglu = (p.act == OMGSR_ACT_GEGLU);
+    // lanes per output row and rows per pass when reading back
+    constexpr int OUTW = WTN;                 // staged columns per wave
+    const int cols_per_row = geglu ? OUTW / 2 : OUTW;   // produced output columns
+    const int lanes_per_row = cols_per_row / 8;
+    const int rows_per_pass = 64 / lanes_per_row;
+    const int lrow = lane / lanes_per_row, lcol = (lane % lanes_per_row) * 8;
+    bf16_t* outb = (bf16_t*)p.out + (int64_t)bz * p.out_bstride;
+    float* outf = (float*)p.out + (int64_t)bz * p.out_bstride;
+    const bf16_t* resb = p.residual ? (const bf16_t*)p.residual + (int64_t)bz * p.out_bstride : nullptr;
+    const bool vec_ok = (p.Cout & 7) == 0;
+
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                epi[cfrag_row(lane, r) * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+        for (int rb = 0; rb < 32; rb += rows_per_pass) {
+            const int row = rb + lrow;
+            const int m = m0 + wm * WTM + i * 32 + row;
+            float v[8];
+            int n;  // first logical output column of this lane
+            if (geglu) {
+                // staged columns: per 64-wide group [32 a | 32 g]
+                const int grp = lcol >> 5, within = lcol & 31;
+                const float* pa = epi + row * EPI_LD + grp * 64 + within;
+                const int nb = n0 + wn * WTN + grp * 64 + within;   // packed bias index of a
+                n = ((n0 + wn * WTN) >> 1) + lcol;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a = pa[e] * p.alpha, gt = pa[32 + e] * p.alpha;
+                    if (p.bias) { a += p.bias[nb + e]; gt += p.bias[nb + 32 + e]; }
+                    v[e] = a * gelu_erf_f(gt);
+                }
+            } else {
+                const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(epi + row * EPI_LD + lcol);
+                const f32x4_t x1 = *reinterpret_cast<const f32x4_t*>(epi + row * EPI_LD + lcol + 4);
+                n = n0 + wn * WTN + lcol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = x0[e] * p.alpha; v[4 + e] = x1[e] * p.alpha; }
+                if (p.bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (n + e < p.Cout) v[e] += p.bias[n + e];
+                }
+                if (p.act == OMGSR_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                } else if (p.act == OMGSR_ACT_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                }
+            }
+            if (m >= g.M || n >= p.Cout) continue;
+            if (p.gate) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (n + e < p.Cout) v[e] *= p.gate[n + e];
+            }
+            if (p.out_layout == OMGSR_LAYOUT_NHWC) {
+                const int64_t o = (int64_t)m * p.Cout + n;
+                if (vec_ok) {
+                    if (resb) {
+                        float rf[8];
+                        unpack8(*reinterpret_cast<const u32x4_t*>(resb + o), rf);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+                    }
+                    if (p.out_dtype == OMGSR_OUT_BF16) {
+                        *reinterpret_cast<u32x4_t*>(outb + o) = pack8(v);
+                    } else {
+                        *reinterpret_cast<f32x4_t*>(outf + o) = (f32x4_t){v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4_t*>(outf + o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+                    }
+                } else {
+                    for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
+                        float x = v[e];
+                        if (resb) x += (float)resb[o + e];
+                        if (p.out_dtype == OMGSR_OUT_BF16) outb[o + e] = (bf16_t)x; else outf[o + e] = x;
+                    }
+                }
+            } else {  // OMGSR_LAYOUT_T: out[(m / t_rows) * Cout + n][m % t_rows]
+                const int blk = m / p.t_rows, mr = m - blk * p.t_rows;
+                for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
+                    const int64_t o = ((int64_t)blk * p.Cout + n + e) * p.t_ld + mr;
+                    if (p.out_dtype == OMGSR_OUT_BF16) outb[o] = (bf16_t)v[e]; else outf[o] = v[e];
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch(const omgsr_igemm_args& a, Geo g, hipStream_t st) {
+    g.ntm = (g.M + BM - 1) / BM;
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    g.ntn = (logical_cols + BN - 1) / BN;   // Cout_pad (multiple of 128) always covers ntn * BN rows
+    dim3 grid(g.ntm * g.ntn, 1, a.batch);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WGM, WGN>), grid, dim3(NTHREADS), 0, st, a, g);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
+    if (!ap || !ap->in || !ap->weight || !ap->out) return OMGSR_E_BADARG;
+    omgsr_igemm_args a = *ap;
+    if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.Cin <= 0 || a.Cout <= 0 || a.Ho <= 0 || a.Wo <= 0 ||
+        a.R <= 0 || a.S <= 0 || a.stride <= 0 || a.batch <= 0) return OMGSR_E_BADARG;
+    if ((a.Cin & 7) || (a.Cout_pad & 127) || (a.K_pad % BK) || a.K_pad < a.R * a.S * a.Cin) return OMGSR_E_SHAPE;
+    if (a.upsample != 0 && a.upsample != 1) return OMGSR_E_BADARG;
+    const int64_t M64 = (int64_t)a.N * a.Ho * a.Wo;
+    if (M64 >= (1ll << 31)) return OMGSR_E_SHAPE;
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    if (logical_cols > a.Cout_pad) return OMGSR_E_SHAPE;
+    if (a.act == OMGSR_ACT_GEGLU && ((a.Cout & 31) || a.out_layout != OMGSR_LAYOUT_NHWC)) return OMGSR_E_SHAPE;
+    if (a.out_layout == OMGSR_LAYOUT_T && (a.t_rows <= 0 || a.t_ld < a.t_rows || a.residual)) return OMGSR_E_BADARG;
+    Geo g;
+    g.M = (int)M64;
+    g.HoWo = a.Ho * a.Wo;
+    g.Hv = a.H << a.upsample;
+    g.Wv = a.W << a.upsample;
+    g.nk = a.K_pad / BK;
+    hipStream_t st = (hipStream_t)stream;
+    const double flops = 2.0 * (double)M64 * (double)a.R * a.S * a.Cin * (double)logical_cols * a.batch;
+    const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.Cout_pad * a.K_pad +
+                                (double)M64 * a.Cout * (a.residual ? 2 : 1)) * a.batch;
+    omgsr::TimingScope ts(OMGSR_TK_IGEMM, flops, bytes, st);
+    // Tile choice: the 128x128 tile is the MFMA-efficient default; narrow outputs use 128x32 so
+    // padded columns do not burn MFMA cycles; small problems drop to 64x64 to fill the 256 CUs.
+    const int64_t tiles128 = ((M64 + 127) / 128) * (a.Cout_pad / 128) * a.batch;
+    if (a.act == OMGSR_ACT_GEGLU) return launch<128, 128, 2, 2>(a, g, st);   // needs a 64-wide wave tile
+    if (logical_cols <= 32) return launch<128, 32, 4, 1>(a, g, st);
+    if (logical_cols <= 64 || tiles128 < 192) return launch<64, 64, 2, 2>(a, g, st);
+    return launch<128, 128, 2, 2>(a, g, st);
+}

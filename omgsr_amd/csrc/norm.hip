@@ -1,0 +1,326 @@
+// GroupNorm / LayerNorm / row-softmax / RMSNorm+RoPE for gfx950. All HBM-bound: 16-byte loads,
+// fp32 statistics, wave64 shuffles + LDS for reductions.
+#include "common.hip.h"
+#include "../../include/omgsr_hip.h"
+#include "timing.hip.h"
+
+namespace {
+
+constexpr int GN_PPC = 256;   // pixels per statistics chunk
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics, pass 1: per (image, pixel-chunk) partial (sum, sumsq) per group.
+// x [N][HW][C] bf16.  grid = (nchunk, N), 256 threads.  LDS: 2*C floats.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
+                                                          int64_t HW, int C, int G, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) float gn_lds[];
+    float* csum = gn_lds;
+    float* csq = gn_lds + C;
+    const int t = threadIdx.x;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    for (int c = t; c < 2 * C; c += 256) gn_lds[c] = 0.0f;
+    __syncthreads();
+    const int nch8 = C >> 3;
+    const int TP = nch8 < 256 ? nch8 : 256;      // threads per pixel
+    const int P = 256 / TP;                      // pixels in flight
+    const int64_t p0 = (int64_t)chunk * GN_PPC;
+    const int npx = (int)((HW - p0) < GN_PPC ? (HW - p0) : GN_PPC);
+    if (t < TP * P) {
+        const int pl = t / TP;
+        const bf16_t* base = x + ((int64_t)n * HW + p0) * C;
+        for (int c8 = t % TP; c8 < nch8; c8 += TP) {
+            float s[8], q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] = 0.0f; q[e] = 0.0f; }
+            for (int px = pl; px < npx; px += P) {
+                float f[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(base + (int64_t)px * C + c8 * 8), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                atomicAdd(&csum[c8 * 8 + e], s[e]);
+                atomicAdd(&csq[c8 * 8 + e], q[e]);
+            }
+        }
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    if (t < G) {
+        float s = 0.0f, q = 0.0f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { s += csum[c]; q += csq[c]; }
+        float* o = partial + (((int64_t)n * nchunk + chunk) * G + t) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+
+// pass 2: one thread per (n, g): fold the chunk partials in double.
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ var_out, int N, int G, int nchunk, double count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * G) return;
+    const int n = i / G, g = i - n * G;
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+        const float* p = partial + (((int64_t)n * nchunk + c) * G + g) * 2;
+        s += (double)p[0]; q += (double)p[1];
+    }
+    const double m = s / count;
+    double v = q / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(v + (double)eps));
+    if (var_out) var_out[i] = (float)v;
+}
+
+// GroupNorm apply (+ optional SiLU). grid = (nblk, N); each block builds the per-channel
+// (scale, shift) table of its image in LDS, then streams its pixel range.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int64_t HW, int C, int G, int act, int64_t px_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float gn_lds[];
+    float* sc = gn_lds;
+    float* sh = gn_lds + C;
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int cpg = C / G;
+    for (int c = t; c < C; c += 256) {
+        const int g = c / cpg;
+        const float r = rstd[n * G + g], m = mean[n * G + g];
+        const float a = r * (gamma ? gamma[c] : 1.0f);
+        sc[c] = a;
+        sh[c] = (beta ? beta[c] : 0.0f) - m * a;
+    }
+    __syncthreads();
+    const int nch8 = C >> 3;
+    const int64_t p0 = (int64_t)blockIdx.x * px_per_block;
+    int64_t p1 = p0 + px_per_block; if (p1 > HW) p1 = HW;
+    const int total = (int)((p1 - p0) * nch8);   // <= ~4k chunks per block by construction
+    const bf16_t* xb = x + ((int64_t)n * HW + p0) * C;
+    bf16_t* yb = y + ((int64_t)n * HW + p0) * C;
+    for (int i = t; i < total; i += 256) {
+        const int c8 = i % nch8;
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(xb + (int64_t)i * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = f[e] * sc[c8 * 8 + e] + sh[c8 * 8 + e];
+            f[e] = (act == OMGSR_ACT_SILU) ? silu_f(v) : v;
+        }
+        *reinterpret_cast<u32x4_t*>(yb + (int64_t)i * 8) = pack8(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, C <= 64*8*MAXCH. y = (x-mu)*rstd*a[c] + b[c].
+template <int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                         const float* __restrict__ a, const float* __restrict__ b,
+                                                         int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch8 = C >> 3;
+    const bf16_t* xr = x + row * C;
+    float f[MAXCH][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c8 = lane + 64 * i;
+        if (c8 < nch8) {
+            unpack8(*reinterpret_cast<const u32x4_t*>(xr + c8 * 8), f[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[i][e];
+        }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c8 = lane + 64 * i;
+        if (c8 < nch8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mu; q += d * d; }
+        }
+    }
+    const float r = rsqrtf(wave_sum(q) / (float)C + eps);
+    bf16_t* yr = y + row * C;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c8 = lane + 64 * i;
+        if (c8 < nch8) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = c8 * 8 + e;
+                float v = (f[i][e] - mu) * r;
+                if (a) v *= a[c];
+                if (b) v += b[c];
+                o[e] = v;
+            }
+            *reinterpret_cast<u32x4_t*>(yr + c8 * 8) = pack8(o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax fp32 -> bf16, one 256-thread block per row, L <= 256*4*MAXV.
+template <int MAXV>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, int L) {
+    __shared__ float red[8];
+    const int t = threadIdx.x;
+    const float* sr = s + (int64_t)blockIdx.x * L;
+    bf16_t* pr = p + (int64_t)blockIdx.x * L;
+    const int nv = L >> 2;
+    f32x4_t v[MAXV];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = t + 256 * i;
+        if (j < nv) {
+            v[i] = *reinterpret_cast<const f32x4_t*>(sr + 4 * j);
+            mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+        }
+    }
+    mx = wave_max(mx);
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = t + 256 * i;
+        if (j < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][e] = __expf(v[i][e] - mx); sum += v[i][e]; }
+        }
+    }
+    sum = wave_sum(sum);
+    if ((t & 63) == 0) red[4 + (t >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int j = t + 256 * i;
+        if (j < nv) {
+            u32x2_t o;
+            o[0] = pack2(v[i][0] * inv, v[i][1] * inv);
+            o[1] = pack2(v[i][2] * inv, v[i][3] * inv);
+            *reinterpret_cast<u32x2_t*>(pr + 4 * j) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm over head_dim (D = 128) * w, then interleaved-pair RoPE, in place.  16 lanes per head
+// (8 elements each), 4 heads per wave.
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                            int64_t rows, int L, int H, int D, int64_t ld, int col0,
+                                                            int pos0, float eps) {
+    const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);   // (row, head) index
+    if (gid >= rows * H) return;
+    const int sub = threadIdx.x & 15;
+    const int64_t row = gid / H;
+    const int h = (int)(gid - row * H);
+    bf16_t* px = x + row * ld + col0 + h * D + sub * 8;
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(px), f);
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q += f[e] * f[e];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float r = rsqrtf(q / (float)D + eps);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = f[e] * r * w[sub * 8 + e];
+    if (cos_t) {
+        const int pos = pos0 + (int)(row % L);
+        const float* cp = cos_t + (int64_t)pos * D + sub * 8;
+        const float* sp = sin_t + (int64_t)pos * D + sub * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float a = f[e], b = f[e + 1];
+            f[e] = a * cp[e] - b * sp[e];
+            f[e + 1] = b * cp[e + 1] + a * sp[e + 1];
+        }
+    }
+    *reinterpret_cast<u32x4_t*>(px) = pack8(f);
+}
+
+}  // namespace
+
+extern "C" int omgsr_groupnorm_nchunk(int64_t HW) { return (int)((HW + GN_PPC - 1) / GN_PPC); }
+
+extern "C" int omgsr_groupnorm_stats(const void* x, float* partial, float* mean, float* rstd, float* var_out,
+                                     int32_t N, int64_t HW, int32_t C, int32_t G, float eps, void* stream) {
+    if (!x || !partial || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
+    if ((C & 7) || (C % G) || G > 256 || C > 8192) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = omgsr_groupnorm_nchunk(HW);
+    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 2.0 * N * (double)HW * C, st);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, N), dim3(256), 2 * C * sizeof(float), st,
+                       (const bf16_t*)x, partial, HW, C, G, nchunk);
+    const int tot = N * G;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 127) / 128), dim3(128), 0, st, partial, mean, rstd, var_out,
+                       N, G, nchunk, (double)HW * (C / G), eps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
+                                     const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act,
+                                     void* stream) {
+    if (!x || !y || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
+    if ((C & 7) || (C % G) || C > 8192) return OMGSR_E_SHAPE;
+    if (act != OMGSR_ACT_NONE && act != OMGSR_ACT_SILU) return OMGSR_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    // ~64 KB of activations per block keeps >= 2k blocks in flight on the big VAE maps
+    int64_t ppb = (32768 + C - 1) / C;
+    if (ppb < 1) ppb = 1;
+    const int nblk = (int)((HW + ppb - 1) / ppb);
+    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 4.0 * N * (double)HW * C, st);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, N), dim3(256), 2 * C * sizeof(float), st, (const bf16_t*)x,
+                       (bf16_t*)y, mean, rstd, gamma, beta, HW, C, G, act, ppb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_layernorm(const void* x, void* y, const float* a, const float* b, int64_t rows, int32_t C,
+                               float eps, void* stream) {
+    if (!x || !y || rows <= 0 || C <= 0) return OMGSR_E_BADARG;
+    if ((C & 7) || C > 64 * 8 * 8) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    omgsr::TimingScope ts(OMGSR_TK_LN, 0.0, 4.0 * (double)rows * C, st);
+    const int nch = ((C >> 3) + 63) / 64;
+    if (nch <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, a, b, rows, C, eps);
+    else if (nch <= 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, a, b, rows, C, eps);
+    else if (nch <= 6) hipLaunchKernelGGL(layernorm_kernel<6>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, a, b, rows, C, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, a, b, rows, C, eps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t L, void* stream) {
+    if (!s || !p || rows <= 0 || L <= 0) return OMGSR_E_BADARG;
+    if ((L & 3) || L > 256 * 4 * 16 || rows >= (1ll << 31)) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    omgsr::TimingScope ts(OMGSR_TK_SOFTMAX, 0.0, 6.0 * (double)rows * L, st);
+    const int nv = (L / 4 + 255) / 256;
+    if (nv <= 1) hipLaunchKernelGGL(softmax_rows_kernel<1>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L);
+    else if (nv <= 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L);
+    else hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_rmsnorm_rope(void* x, const float* w, const float* cos_t, const float* sin_t, int32_t B, int32_t L,
+                                  int32_t H, int32_t D, int64_t ld, int32_t col0, int32_t pos0, float eps, void* stream) {
+    if (!x || !w || B <= 0 || L <= 0 || H <= 0) return OMGSR_E_BADARG;
+    if (D != 128 || (ld & 7) || (col0 & 7) || ((cos_t == nullptr) != (sin_t == nullptr))) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)B * L;
+    const int64_t groups = rows * H;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 4.0 * (double)groups * D, st);
+    hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, st, (bf16_t*)x, w, cos_t,
+                       sin_t, rows, L, H, D, ld, col0, pos0, eps);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,418 @@
+"""Tensor-level wrappers over the C ABI (include/omgsr_hip.h).
+
+torch is used for device memory and streams only: every function here validates shapes, allocates
+the output with torch.empty and launches a hand-written gfx950 kernel on torch's current stream.
+Activations are bf16, channels-last ([N, H, W, C]; token matrices are [B, L, C]).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AttnArgs, IgemmArgs, check
+
+ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_GEGLU = 0, 1, 2, 3
+OUT_BF16, OUT_F32 = 0, 1
+LAYOUT_NHWC, LAYOUT_T = 0, 1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise _lib.OmgsrError(f"{name}: tensor is on {t.device}; the OMGSR HIP path runs on an MI355X only")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------------------------
+# weight packing (load time)
+
+@dataclass
+class PackedWeight:
+    """KRSC bf16 weight [Cout_pad, K_pad] for omgsr_igemm (+ optional f32 bias)."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    cout: int          # logical output channels (GEGLU: halved)
+    cin: int           # padded input channels (multiple of 8)
+    R: int
+    S: int
+    geglu: bool = False
+
+    @property
+    def cout_pad(self) -> int:
+        return self.w.shape[0]
+
+    @property
+    def k_pad(self) -> int:
+        return self.w.shape[1]
+
+
+def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None) -> PackedWeight:
+    """[Cout, Cin, R, S] (torch conv layout) -> [Cout_pad, roundup(R*S*Cin8, 32)] bf16, k = (r*S+s)*Cin8 + c."""
+    cout, cin, R, S = weight.shape
+    dev = device or weight.device
+    cin8 = _round_up(cin, 8)
+    w = weight.detach().to(device=dev, dtype=torch.float32).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
+    if cin8 != cin:
+        w = torch.nn.functional.pad(w, (0, cin8 - cin))
+    w = w.reshape(cout, R * S * cin8)
+    k_pad = _round_up(w.shape[1], 32)
+    cout_pad = _round_up(cout, 128)
+    out = torch.zeros(cout_pad, k_pad, device=dev, dtype=torch.bfloat16)
+    out[:cout, : w.shape[1]] = w.to(torch.bfloat16)
+    b = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
+    return PackedWeight(out, b, cout, cin8, R, S)
+
+
+def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None) -> PackedWeight:
+    """[out, in] -> 1x1 'conv' weight."""
+    return pack_conv_weight(weight[:, :, None, None], bias, device)
+
+
+def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None) -> PackedWeight:
+    """GEGLU projection [2*inner, in] (rows [a | gate], diffusers `chunk(2, -1)`) -> rows interleaved in
+    blocks of 32: [a_0..31, g_0..31, a_32..63, g_32..63, ...] so one 64-wide wave tile holds both halves."""
+    two_inner, cin = weight.shape
+    inner = two_inner // 2
+    if inner % 32:
+        raise ValueError("GEGLU inner dim must be a multiple of 32")
+    a, g = weight[:inner], weight[inner:]
+    w = torch.stack([a.reshape(inner // 32, 32, cin), g.reshape(inner // 32, 32, cin)], dim=1).reshape(two_inner, cin)
+    pw = pack_linear_weight(w, None, device)
+    if bias is not None:
+        ba, bg = bias[:inner], bias[inner:]
+        b = torch.stack([ba.reshape(-1, 32), bg.reshape(-1, 32)], dim=1).reshape(two_inner)
+        pw.bias = b.detach().to(device=pw.w.device, dtype=torch.float32).contiguous()
+    pw.cout = inner
+    pw.geglu = True
+    return pw
+
+
+# --------------------------------------------------------------------------------------------
+# K1-K3, K5, K6: implicit-GEMM conv / linear / bmm
+
+def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, int, int] | int = 1,
+           upsample: bool = False, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
+           gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_BF16, alpha: float = 1.0,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [N,H,W,Cin] bf16 -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on the (virtual) input."""
+    _req(x, torch.bfloat16, "x")
+    N, H, W, Cin = x.shape
+    if Cin != pw.cin:
+        raise ValueError(f"conv2d: input has {Cin} channels, packed weight expects {pw.cin}")
+    if isinstance(pad, int):
+        pad = (pad, pad, pad, pad)
+    pt, pb, pl, pr = pad
+    Hv, Wv = (H * 2, W * 2) if upsample else (H, W)
+    Ho = (Hv + pt + pb - pw.R) // stride + 1
+    Wo = (Wv + pl + pr - pw.S) // stride + 1
+    if pw.geglu:
+        act = ACT_GEGLU
+    if out is None:
+        out = torch.empty((N, Ho, Wo, pw.cout), device=x.device,
+                          dtype=torch.bfloat16 if out_dtype == OUT_BF16 else torch.float32)
+    if residual is not None:
+        _req(residual, torch.bfloat16, "residual")
+        if residual.shape != out.shape:
+            raise ValueError(f"residual shape {tuple(residual.shape)} != output {tuple(out.shape)}")
+    a = IgemmArgs()
+    a.in_, a.weight, a.bias, a.gate = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
+    a.residual, a.out = _ptr(residual), out.data_ptr()
+    a.N, a.H, a.W, a.Cin = N, H, W, Cin
+    a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
+    a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = pw.R, pw.S, stride, pt, pl, int(upsample)
+    a.Ho, a.Wo = Ho, Wo
+    a.act, a.out_dtype, a.out_layout = act, out_dtype, LAYOUT_NHWC
+    a.t_rows, a.t_ld = 0, 0
+    a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
+    a.alpha = alpha
+    check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(conv2d)")
+    return out
+
+
+def linear(x: torch.Tensor, pw: PackedWeight, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
+           gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_BF16, alpha: float = 1.0) -> torch.Tensor:
+    """x [..., K] bf16 -> [..., Cout]."""
+    lead = x.shape[:-1]
+    M = 1
+    for d in lead:
+        M *= d
+    x2 = x.reshape(1, 1, M, x.shape[-1])
+    r2 = None if residual is None else residual.reshape(1, 1, M, pw.cout)
+    y = conv2d(x2, pw, stride=1, pad=0, act=act, residual=r2, gate=gate, out_dtype=out_dtype, alpha=alpha)
+    return y.reshape(*lead, pw.cout)
+
+
+def linear_t(x: torch.Tensor, pw: PackedWeight, rows_per_batch: int, ld: Optional[int] = None) -> torch.Tensor:
+    """Transposed-output projection: x [B, L, K] -> out [B, Cout, ld] with out[b, n, l] = (x W^T + bias)[b, l, n].
+    This is how V reaches omgsr_attention (key index contiguous). Columns l >= L are zero."""
+    _req(x, torch.bfloat16, "x")
+    B, L, K = x.shape
+    if L != rows_per_batch:
+        raise ValueError("rows_per_batch mismatch")
+    ld = ld or _round_up(L, 8)
+    out = torch.zeros((B, pw.cout, ld), device=x.device, dtype=torch.bfloat16) if ld != L else \
+        torch.empty((B, pw.cout, ld), device=x.device, dtype=torch.bfloat16)
+    a = IgemmArgs()
+    a.in_, a.weight, a.bias, a.gate, a.residual, a.out = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), None, None, out.data_ptr()
+    a.N, a.H, a.W, a.Cin = 1, 1, B * L, K
+    a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
+    a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
+    a.Ho, a.Wo = 1, B * L
+    a.act, a.out_dtype, a.out_layout = ACT_NONE, OUT_BF16, LAYOUT_T
+    a.t_rows, a.t_ld = L, ld
+    a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
+    a.alpha = 1.0
+    check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_t)")
+    return out
+
+
+def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_dtype: int = OUT_BF16) -> torch.Tensor:
+    """out[b] = alpha * a[b] @ b[b]^T ; a [B, M, K], b [B, Npad, K] bf16 with Npad % 128 == 0, K % 32 == 0.
+    Returns [B, M, Npad]. (d=512 VAE attention scores / PV product.)"""
+    _req(a_mat, torch.bfloat16, "a")
+    _req(b_mat, torch.bfloat16, "b")
+    B, M, K = a_mat.shape
+    Bb, Np, Kb = b_mat.shape
+    if Bb != B or Kb != K or Np % 128 or K % 32:
+        raise ValueError(f"bmm_nt: incompatible shapes {tuple(a_mat.shape)} x {tuple(b_mat.shape)}")
+    out = torch.empty((B, M, Np), device=a_mat.device, dtype=torch.bfloat16 if out_dtype == OUT_BF16 else torch.float32)
+    a = IgemmArgs()
+    a.in_, a.weight, a.bias, a.gate, a.residual, a.out = a_mat.data_ptr(), b_mat.data_ptr(), None, None, None, out.data_ptr()
+    a.N, a.H, a.W, a.Cin = 1, 1, M, K
+    a.Cout, a.Cout_pad, a.K_pad = Np, Np, K
+    a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
+    a.Ho, a.Wo = 1, M
+    a.act, a.out_dtype, a.out_layout = ACT_NONE, out_dtype, LAYOUT_NHWC
+    a.t_rows, a.t_ld = 0, 0
+    a.batch, a.in_bstride, a.w_bstride, a.out_bstride = B, M * K, Np * K, M * Np
+    a.alpha = alpha
+    check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(bmm_nt)")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# K4: GroupNorm
+
+def group_norm_stats(x: torch.Tensor, groups: int, eps: float):
+    """x [N, ..., C] bf16 -> (mean [N,G], rstd [N,G], var [N,G]) f32 (biased variance)."""
+    _req(x, torch.bfloat16, "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * Cc)
+    lib = _lib.load()
+    nchunk = lib.omgsr_groupnorm_nchunk(HW)
+    partial = torch.empty((N, nchunk, groups, 2), device=x.device, dtype=torch.float32)
+    mean = torch.empty((N, groups), device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    var = torch.empty_like(mean)
+    check(lib.omgsr_groupnorm_stats(x.data_ptr(), partial.data_ptr(), mean.data_ptr(), rstd.data_ptr(), var.data_ptr(),
+                                    N, HW, Cc, groups, eps, _stream()), "omgsr_groupnorm_stats")
+    return mean, rstd, var
+
+
+def group_norm_apply(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: Optional[torch.Tensor],
+                     beta: Optional[torch.Tensor], groups: int, act: int = ACT_NONE, inplace: bool = False) -> torch.Tensor:
+    _req(x, torch.bfloat16, "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * Cc)
+    y = x if inplace else torch.empty_like(x)
+    check(_lib.load().omgsr_groupnorm_apply(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
+                                            _ptr(beta), N, HW, Cc, groups, act, _stream()), "omgsr_groupnorm_apply")
+    return y
+
+
+def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, act: int = ACT_NONE) -> torch.Tensor:
+    mean, rstd, _ = group_norm_stats(x, groups, eps)
+    return group_norm_apply(x, mean, rstd, gamma, beta, groups, act)
+
+
+# --------------------------------------------------------------------------------------------
+# K9/K10: LayerNorm (affine or AdaLN-modulated)
+
+def layer_norm(x: torch.Tensor, a: Optional[torch.Tensor], b: Optional[torch.Tensor], eps: float) -> torch.Tensor:
+    _req(x, torch.bfloat16, "x")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    check(_lib.load().omgsr_layernorm(x.data_ptr(), y.data_ptr(), _ptr(a), _ptr(b), rows, Cc, eps, _stream()), "omgsr_layernorm")
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# K7/K8: attention
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, head_dim: int, scale: float,
+              *, q_col: int = 0, k_col: int = 0, Lk: Optional[int] = None, out: Optional[torch.Tensor] = None,
+              o_col: int = 0) -> torch.Tensor:
+    """q [B, Lq, *] (heads at columns q_col + h*D), k [Bk, Lk, *], vt [Bk, heads*D, ld] -> o [B, Lq, heads*D].
+    Bk == 1 broadcasts one K/V over the batch (constant cross-attention context)."""
+    _req(q, torch.bfloat16, "q"); _req(k, torch.bfloat16, "k"); _req(vt, torch.bfloat16, "vt")
+    B, Lq = q.shape[0], q.shape[1]
+    Bk = k.shape[0]
+    Lk = Lk if Lk is not None else k.shape[1]
+    inner = heads * head_dim
+    if out is None:
+        out = torch.empty((B, Lq, inner), device=q.device, dtype=torch.bfloat16)
+    a = AttnArgs()
+    esz = 2
+    a.q = q.data_ptr() + q_col * esz
+    a.k = k.data_ptr() + k_col * esz
+    a.vt = vt.data_ptr()
+    a.o = out.data_ptr() + o_col * esz
+    a.B, a.H, a.D, a.Lq, a.Lk = B, heads, head_dim, Lq, Lk
+    a.q_ld, a.k_ld, a.vt_ld, a.o_ld = q.shape[-1], k.shape[-1], vt.shape[-1], out.shape[-1]
+    a.q_bstride = Lq * q.shape[-1]
+    a.k_bstride = 0 if Bk == 1 and B > 1 else k.shape[1] * k.shape[-1]
+    a.vt_bstride = 0 if Bk == 1 and B > 1 else vt.shape[1] * vt.shape[-1]
+    a.o_bstride = Lq * out.shape[-1]
+    a.scale = scale
+    check(_lib.load().omgsr_attention(C.byref(a), _stream()), "omgsr_attention")
+    return out
+
+
+def softmax_rows(s: torch.Tensor) -> torch.Tensor:
+    _req(s, torch.float32, "s")
+    L = s.shape[-1]
+    rows = s.numel() // L
+    p = torch.empty(s.shape, device=s.device, dtype=torch.bfloat16)
+    check(_lib.load().omgsr_softmax_rows(s.data_ptr(), p.data_ptr(), rows, L, _stream()), "omgsr_softmax_rows")
+    return p
+
+
+def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor],
+                  heads: int, head_dim: int, col0: int = 0, pos0: int = 0, eps: float = 1e-6) -> torch.Tensor:
+    """In place on x [B, L, ld]: per head RMSNorm(head_dim)*w then RoPE with cos/sin [Lpos, D] (f32)."""
+    _req(x, torch.bfloat16, "x"); _req(w, torch.float32, "w")
+    B, L, ld = x.shape
+    check(_lib.load().omgsr_rmsnorm_rope(x.data_ptr(), w.data_ptr(), _ptr(cos), _ptr(sin), B, L, heads, head_dim, ld,
+                                         col0, pos0, eps, _stream()), "omgsr_rmsnorm_rope")
+    return x
+
+
+# --------------------------------------------------------------------------------------------
+# K14: layout + latent algebra
+
+def nchw_to_nhwc(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("nchw_to_nhwc: f32 or bf16 input")
+    _req(x, x.dtype, "x")
+    N, Cc, H, W = x.shape
+    cpad = cpad or _round_up(Cc, 8)
+    y = torch.empty((N, H, W, cpad), device=x.device, dtype=torch.bfloat16)
+    check(_lib.load().omgsr_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), N, Cc, H, W, cpad, int(x.dtype == torch.float32), _stream()),
+          "omgsr_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor, channels: Optional[int] = None, dtype=torch.bfloat16,
+                 clamp: Optional[tuple[float, float]] = None) -> torch.Tensor:
+    _req(x, torch.bfloat16, "x")
+    N, H, W, ld = x.shape
+    Cc = channels or ld
+    y = torch.empty((N, Cc, H, W), device=x.device, dtype=dtype)
+    lo, hi = clamp if clamp else (0.0, 0.0)
+    check(_lib.load().omgsr_nhwc_to_nchw(x.data_ptr(), y.data_ptr(), N, Cc, H, W, ld, int(dtype == torch.float32),
+                                         int(clamp is not None), lo, hi, _stream()), "omgsr_nhwc_to_nchw")
+    return y
+
+
+def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], dim=channel) for NHWC bf16."""
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b")
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    rows = a.numel() // Ca
+    out = torch.empty((*a.shape[:-1], Ca + Cb), device=a.device, dtype=torch.bfloat16)
+    lib = _lib.load()
+    check(lib.omgsr_copy_channels(a.data_ptr(), out.data_ptr(), rows, Ca, Ca, Ca + Cb, 0, _stream()), "omgsr_copy_channels")
+    check(lib.omgsr_copy_channels(b.data_ptr(), out.data_ptr(), rows, Cb, Cb, Ca + Cb, Ca, _stream()), "omgsr_copy_channels")
+    return out
+
+
+def vae_sample(moments: torch.Tensor, eps: torch.Tensor, latent_channels: int, shift: float, scale: float,
+               ld_out: Optional[int] = None) -> torch.Tensor:
+    """moments [N,h,w,2C] bf16, eps [N,h,w,C] f32 -> z [N,h,w,ld_out] bf16 (zero padded channels)."""
+    _req(moments, torch.bfloat16, "moments"); _req(eps, torch.float32, "eps")
+    N, h, w, _ = moments.shape
+    ld_out = ld_out or _round_up(latent_channels, 8)
+    z = torch.empty((N, h, w, ld_out), device=moments.device, dtype=torch.bfloat16)
+    check(_lib.load().omgsr_vae_sample(moments.data_ptr(), eps.data_ptr(), z.data_ptr(), N * h * w, latent_channels, ld_out,
+                                       shift, scale, _stream()), "omgsr_vae_sample")
+    return z
+
+
+def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float, c: float = 0.0, d: float = 1.0,
+          bf16_steps: bool = False) -> torch.Tensor:
+    _req(x, torch.bfloat16, "x")
+    out = torch.empty_like(x)
+    check(_lib.load().omgsr_axpby(x.data_ptr(), _ptr(y), out.data_ptr(), x.numel(), a, b, c, d, int(bf16_steps), _stream()),
+          "omgsr_axpby")
+    return out
+
+
+def tile_accumulate(tile: Optional[torch.Tensor], w: torch.Tensor, acc: torch.Tensor, y0: int, x0: int,
+                    channels: Optional[int] = None) -> None:
+    """acc [N,H,W,C] f32 += tile[..., :C] * w[th,tw]; tile None accumulates the weights alone (acc [1,H,W,1])."""
+    _req(w, torch.float32, "w"); _req(acc, torch.float32, "acc")
+    N, H, W, Cc = acc.shape
+    th, tw = w.shape
+    tile_ld = 0
+    if tile is not None:
+        _req(tile, torch.bfloat16, "tile")
+        tile_ld = tile.shape[-1]
+    check(_lib.load().omgsr_tile_accumulate(_ptr(tile), w.data_ptr(), acc.data_ptr(), N, Cc, th, tw, tile_ld, H, W, y0, x0,
+                                            _stream()), "omgsr_tile_accumulate")
+
+
+def tile_normalise(acc: torch.Tensor, wsum: torch.Tensor, ld: Optional[int] = None) -> torch.Tensor:
+    N, H, W, Cc = acc.shape
+    ld = ld or _round_up(Cc, 8)
+    out = torch.empty((N, H, W, ld), device=acc.device, dtype=torch.bfloat16)
+    check(_lib.load().omgsr_tile_normalise(acc.data_ptr(), wsum.data_ptr(), out.data_ptr(), N, H * W, Cc, ld, _stream()),
+          "omgsr_tile_normalise")
+    return out
+
+
+def crop_nhwc(x: torch.Tensor, y0: int, x0: int, th: int, tw: int) -> torch.Tensor:
+    _req(x, torch.bfloat16, "x")
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, th, tw, Cc), device=x.device, dtype=torch.bfloat16)
+    check(_lib.load().omgsr_crop_nhwc(x.data_ptr(), out.data_ptr(), N, H, W, Cc, y0, x0, th, tw, _stream()), "omgsr_crop_nhwc")
+    return out
+
+
+def flux_pack(x: torch.Tensor, channels: int) -> torch.Tensor:
+    """NHWC [N,H,W,ld] (first `channels`) -> tokens [N, (H/2)(W/2), 4*channels]."""
+    _req(x, torch.bfloat16, "x")
+    N, H, W, ld = x.shape
+    out = torch.empty((N, (H // 2) * (W // 2), 4 * channels), device=x.device, dtype=torch.bfloat16)
+    check(_lib.load().omgsr_flux_pack(x.data_ptr(), out.data_ptr(), N, H, W, channels, ld, 0, _stream()), "omgsr_flux_pack")
+    return out
+
+
+def flux_unpack(tok: torch.Tensor, H: int, W: int, ld: Optional[int] = None) -> torch.Tensor:
+    _req(tok, torch.bfloat16, "tok")
+    N, _, c4 = tok.shape
+    Cc = c4 // 4
+    ld = ld or _round_up(Cc, 8)
+    out = torch.zeros((N, H, W, ld), device=tok.device, dtype=torch.bfloat16) if ld != Cc else \
+        torch.empty((N, H, W, ld), device=tok.device, dtype=torch.bfloat16)
+    check(_lib.load().omgsr_flux_pack(tok.data_ptr(), out.data_ptr(), N, H, W, Cc, ld, 1, _stream()), "omgsr_flux_pack")
+    return out

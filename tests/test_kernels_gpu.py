@@ -1,0 +1,337 @@
+"""Kernel-level parity: every C-ABI entry point vs a plain PyTorch fp32 reference of the same op
+(computed on the CPU from the same bf16-rounded inputs). Tolerances: the kernels accumulate in fp32
+and round once to bf16, so the bound is bf16 output rounding (2^-9 relative) plus fp32
+accumulation-order noise."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from omgsr_amd import ops
+    return ops
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).float()
+
+
+def assert_close(got, ref, name, rel_l2=4e-3, max_ulps=3.0):
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    err = (got - ref).norm() / ref.norm().clamp_min(1e-12)
+    # per-element bound: a few bf16 ulps of max(|ref|, typical magnitude)
+    scale = ref.abs().clamp_min(ref.abs().mean())
+    worst = ((got - ref).abs() / scale).max().item()
+    assert err.item() < rel_l2, f"{name}: rel-L2 {err.item():.3e} (worst elt {worst:.3e})"
+    assert worst < max_ulps * 2 ** -8, f"{name}: worst element error {worst:.3e} (rel-L2 {err.item():.3e})"
+
+
+def nhwc(x):  # NCHW f32 -> NHWC bf16 on device
+    return bf(x.permute(0, 2, 3, 1).contiguous()).to(DEV)
+
+
+def to_nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+CONV_CASES = [
+    # N, Cin, Cout, H, W, stride, pad(t,b,l,r), upsample, bias, residual, act
+    (1, 32, 32, 8, 8, 1, (1, 1, 1, 1), False, True, False, 0),
+    (2, 128, 128, 32, 32, 1, (1, 1, 1, 1), False, True, True, 0),
+    (1, 320, 640, 16, 16, 1, (1, 1, 1, 1), False, True, False, 1),
+    (2, 8, 128, 24, 40, 1, (1, 1, 1, 1), False, True, False, 0),       # conv_in (3 -> padded 8)
+    (1, 128, 3, 32, 32, 1, (1, 1, 1, 1), False, True, False, 0),        # conv_out
+    (1, 64, 8, 16, 16, 1, (1, 1, 1, 1), False, True, False, 0),
+    (2, 128, 128, 32, 32, 2, (0, 1, 0, 1), False, True, False, 0),      # VAE downsample: pad(0,1,0,1), s2
+    (1, 320, 320, 16, 16, 2, (1, 1, 1, 1), False, True, False, 0),      # UNet downsample: p1, s2
+    (1, 256, 256, 12, 20, 1, (1, 1, 1, 1), True, True, False, 0),       # nearest-2x folded into the gather
+    (1, 40, 72, 9, 7, 1, (1, 1, 1, 1), False, False, False, 0),         # ragged everything
+    (3, 640, 1280, 8, 8, 1, (1, 1, 1, 1), False, True, True, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3(case):
+    ops = _ops()
+    N, Cin, Cout, H, W, stride, pad, ups, use_bias, use_res, act = case
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    b = rnd(Cout, seed=3) if use_bias else None
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    xin = F.pad(xin, (pad[2], pad[3], pad[0], pad[1]))
+    ref = F.conv2d(xin, w, b, stride=stride)
+    if act == 1:
+        ref = F.silu(ref)
+    res = None
+    if use_res:
+        res = rnd(*ref.shape, seed=4)
+        ref = ref + res
+    pw = ops.pack_conv_weight(w, b, device=DEV)
+    y = ops.conv2d(nhwc(x), pw, stride=stride, pad=pad, upsample=ups, act=act,
+                   residual=None if res is None else nhwc(res))
+    assert_close(to_nchw(y), ref, f"conv{case}")
+
+
+@pytest.mark.parametrize("M,K,Nout", [(64, 320, 320), (4096, 320, 960), (1000, 1280, 1280), (77, 1024, 640), (300, 64, 3072)])
+def test_linear(M, K, Nout):
+    ops = _ops()
+    x = rnd(2, M, K, seed=5)
+    w = rnd(Nout, K, seed=6, scale=1.0 / math.sqrt(K))
+    b = rnd(Nout, seed=7)
+    ref = F.linear(x, w, b)
+    pw = ops.pack_linear_weight(w, b, device=DEV)
+    y = ops.linear(bf(x).to(DEV), pw)
+    assert_close(y, ref, f"linear{(M, K, Nout)}")
+
+
+def test_linear_epilogues():
+    ops = _ops()
+    M, K, Nout = 333, 256, 384
+    x = rnd(1, M, K, seed=8)
+    w = rnd(Nout, K, seed=9, scale=1.0 / math.sqrt(K))
+    b = rnd(Nout, seed=10)
+    gate = rnd(Nout, seed=11)
+    res = rnd(1, M, Nout, seed=12)
+    pw = ops.pack_linear_weight(w, b, device=DEV)
+    y = ops.linear(bf(x).to(DEV), pw, act=ops.ACT_GELU_TANH, gate=gate.to(DEV), residual=bf(res).to(DEV))
+    ref = res + gate * F.gelu(F.linear(x, w, b), approximate="tanh")
+    assert_close(y, ref, "gelu_tanh+gate+residual")
+    y32 = ops.linear(bf(x).to(DEV), pw, out_dtype=ops.OUT_F32, alpha=0.125)
+    ref32 = 0.125 * F.linear(x, w) + b
+    assert y32.dtype == torch.float32
+    assert_close(y32, ref32, "f32 out + alpha", rel_l2=1e-5, max_ulps=0.05)
+
+
+def test_geglu():
+    ops = _ops()
+    M, K, inner = 200, 320, 1280
+    x = rnd(1, M, K, seed=13)
+    w = rnd(2 * inner, K, seed=14, scale=1.0 / math.sqrt(K))
+    b = rnd(2 * inner, seed=15, scale=0.1)
+    h = F.linear(x, w, b)
+    a, g = h.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    pw = ops.pack_geglu_weight(w, b, device=DEV)
+    y = ops.linear(bf(x).to(DEV), pw)
+    assert y.shape[-1] == inner
+    assert_close(y, ref, "geglu")
+
+
+def test_linear_transposed_out():
+    ops = _ops()
+    B, L, K, Nout = 2, 77, 1024, 320
+    x = rnd(B, L, K, seed=16)
+    w = rnd(Nout, K, seed=17, scale=1.0 / math.sqrt(K))
+    pw = ops.pack_linear_weight(w, None, device=DEV)
+    yt = ops.linear_t(bf(x).to(DEV), pw, L)
+    assert yt.shape == (B, Nout, 80)
+    ref = F.linear(x, w).transpose(1, 2)
+    assert_close(yt[:, :, :L], ref, "linear_t")
+    assert (yt[:, :, L:] == 0).all()
+
+
+def test_bmm_nt():
+    ops = _ops()
+    B, M, K, Nn = 2, 200, 512, 256
+    a = rnd(B, M, K, seed=18)
+    b = rnd(B, Nn, K, seed=19)
+    s = ops.bmm_nt(bf(a).to(DEV), bf(b).to(DEV), alpha=K ** -0.5, out_dtype=ops.OUT_F32)
+    ref = torch.einsum("bmk,bnk->bmn", a, b) * K ** -0.5
+    assert_close(s, ref, "bmm_nt", rel_l2=1e-5, max_ulps=0.05)
+
+
+@pytest.mark.parametrize("N,C,H,W,act", [(2, 128, 64, 64, 1), (1, 320, 16, 16, 0), (2, 1920, 8, 8, 1), (1, 512, 24, 40, 1), (1, 2560, 8, 8, 1)])
+def test_group_norm(N, C, H, W, act):
+    ops = _ops()
+    x = rnd(N, C, H, W, seed=20) * 2.0 + 0.5
+    gamma = rnd(C, seed=21) + 1.0
+    beta = rnd(C, seed=22)
+    ref = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    if act:
+        ref = F.silu(ref)
+    xd = nhwc(x)
+    mean, rstd, var = ops.group_norm_stats(xd, 32, 1e-6)
+    xr = x.reshape(N, 32, -1)
+    assert_close(mean, xr.mean(-1), "gn mean", rel_l2=1e-5, max_ulps=0.01)
+    assert_close(var, xr.var(-1, unbiased=False), "gn var", rel_l2=1e-4, max_ulps=0.05)
+    y = ops.group_norm_apply(xd, mean, rstd, gamma.to(DEV), beta.to(DEV), 32, act)
+    assert_close(to_nchw(y), ref, f"group_norm{(N, C, H, W)}")
+
+
+@pytest.mark.parametrize("rows,C", [(100, 320), (64, 640), (50, 1280), (33, 3072)])
+def test_layer_norm(rows, C):
+    ops = _ops()
+    x = rnd(rows, C, seed=23) * 3.0 + 1.0
+    a = rnd(C, seed=24) + 1.0
+    b = rnd(C, seed=25)
+    ref = F.layer_norm(x, (C,), a, b, eps=1e-5)
+    y = ops.layer_norm(bf(x).to(DEV), a.to(DEV), b.to(DEV), 1e-5)
+    assert_close(y, ref, f"layer_norm{(rows, C)}")
+    y0 = ops.layer_norm(bf(x).to(DEV), None, None, 1e-6)
+    assert_close(y0, F.layer_norm(x, (C,), eps=1e-6), "layer_norm no affine")
+
+
+def _sdpa_ref(q, k, v, heads, scale):
+    B, Lq, inner = q.shape
+    D = inner // heads
+    qh = q.reshape(B, Lq, heads, D).transpose(1, 2)
+    kh = k.reshape(k.shape[0], -1, heads, D).transpose(1, 2)
+    vh = v.reshape(v.shape[0], -1, heads, D).transpose(1, 2)
+    s = torch.einsum("bhqd,bhkd->bhqk", qh, kh.expand(B, -1, -1, -1)) * scale
+    o = torch.einsum("bhqk,bhkd->bhqd", s.softmax(-1), vh.expand(B, -1, -1, -1))
+    return o.transpose(1, 2).reshape(B, Lq, inner)
+
+
+@pytest.mark.parametrize("B,H,D,Lq,Lk,bcast", [
+    (2, 5, 64, 256, 256, False), (1, 10, 64, 1024, 1024, False), (2, 20, 64, 64, 64, False),
+    (2, 5, 64, 256, 77, True), (1, 5, 64, 100, 77, False), (1, 4, 128, 320, 320, False), (1, 2, 128, 200, 136, False)])
+def test_attention(B, H, D, Lq, Lk, bcast):
+    ops = _ops()
+    inner = H * D
+    q = rnd(B, Lq, inner, seed=26)
+    Bk = 1 if bcast else B
+    k = rnd(Bk, Lk, inner, seed=27)
+    v = rnd(Bk, Lk, inner, seed=28)
+    scale = D ** -0.5
+    ref = _sdpa_ref(q, k, v, H, scale)
+    ld = (Lk + 7) // 8 * 8
+    vt = torch.zeros(Bk, inner, ld)
+    vt[:, :, :Lk] = v.transpose(1, 2)
+    o = ops.attention(bf(q).to(DEV), bf(k).to(DEV), bf(vt).to(DEV), H, D, scale, Lk=Lk)
+    # P is rounded to bf16 before the PV product -> a little looser than a GEMM
+    assert_close(o, ref, f"attention{(B, H, D, Lq, Lk)}", rel_l2=6e-3, max_ulps=6.0)
+
+
+def test_attention_spiked_max():
+    """Force the online-softmax rescale: one key dominates late in the sweep."""
+    ops = _ops()
+    B, H, D, L = 1, 1, 64, 512
+    q = rnd(B, L, D, seed=29)
+    k = rnd(B, L, D, seed=30)
+    v = rnd(B, L, D, seed=31)
+    k[0, 300] = q[0, 5] * 4.0      # spikes q row 5 in the 5th key tile
+    k[0, 500] = q[0, 70] * 6.0
+    k = bf(k).float()
+    scale = D ** -0.5
+    ref = _sdpa_ref(q, k, v, H, scale)
+    o = ops.attention(bf(q).to(DEV), bf(k).to(DEV), bf(v.transpose(1, 2).contiguous()).to(DEV), H, D, scale)
+    assert_close(o, ref, "attention spiked", rel_l2=6e-3, max_ulps=6.0)
+
+
+def test_attention_strided_fused_qkv():
+    """q/k read straight out of a fused [q|k] projection buffer with column offsets."""
+    ops = _ops()
+    B, H, D, L = 2, 5, 64, 192
+    inner = H * D
+    qk = rnd(B, L, 2 * inner, seed=32)
+    v = rnd(B, L, inner, seed=33)
+    scale = D ** -0.5
+    ref = _sdpa_ref(qk[..., :inner], qk[..., inner:], v, H, scale)
+    qk_d = bf(qk).to(DEV)
+    o = ops.attention(qk_d, qk_d, bf(v.transpose(1, 2).contiguous()).to(DEV), H, D, scale, q_col=0, k_col=inner)
+    assert_close(o, ref, "attention fused qk", rel_l2=6e-3, max_ulps=6.0)
+
+
+def test_softmax_rows():
+    ops = _ops()
+    s = torch.randn(37, 4096, generator=torch.Generator().manual_seed(34)) * 4
+    p = ops.softmax_rows(s.to(DEV))
+    assert_close(p, s.softmax(-1), "softmax_rows")
+    s2 = torch.randn(3, 16384, generator=torch.Generator().manual_seed(35)) * 4
+    assert_close(ops.softmax_rows(s2.to(DEV)), s2.softmax(-1), "softmax_rows 16k")
+
+
+def test_rmsnorm_rope():
+    ops = _ops()
+    B, L, H, D = 2, 96, 3, 128
+    x = rnd(B, L, 2 * H * D, seed=36)
+    w = rnd(D, seed=37) + 1.0
+    pos = torch.arange(L + 8, dtype=torch.float64)
+    freqs = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float64) / D))
+    ang = torch.outer(pos, freqs)
+    cos = ang.cos().repeat_interleave(2, dim=1).float()
+    sin = ang.sin().repeat_interleave(2, dim=1).float()
+    col0, pos0 = H * D, 8
+    xs = x[..., col0:].reshape(B, L, H, D)
+    xn = xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    c = cos[pos0:pos0 + L][None, :, None, :]
+    s = sin[pos0:pos0 + L][None, :, None, :]
+    xr = torch.stack([-xn[..., 1::2], xn[..., 0::2]], dim=-1).flatten(-2)
+    ref = x.clone()
+    ref[..., col0:] = (xn * c + xr * s).reshape(B, L, H * D)
+    xd = bf(x).to(DEV)
+    ops.rmsnorm_rope_(xd, w.to(DEV), cos.to(DEV), sin.to(DEV), H, D, col0=col0, pos0=pos0)
+    assert_close(xd, ref, "rmsnorm_rope")
+
+
+def test_layout_and_latent_ops():
+    ops = _ops()
+    x = rnd(2, 3, 20, 12, seed=38)
+    xh = ops.nchw_to_nhwc(x.to(DEV))
+    assert xh.shape == (2, 20, 12, 8)
+    assert torch.equal(xh[..., :3].float().cpu(), x.permute(0, 2, 3, 1))
+    assert (xh[..., 3:] == 0).all()
+    back = ops.nhwc_to_nchw(xh, channels=3, dtype=torch.float32, clamp=(-1.0, 1.0))
+    assert torch.equal(back.cpu(), x.clamp(-1, 1))
+    a, b = rnd(2, 5, 7, 16, seed=39), rnd(2, 5, 7, 24, seed=40)
+    cat = ops.concat_channels(bf(a).to(DEV), bf(b).to(DEV))
+    assert torch.equal(cat.float().cpu(), torch.cat([a, b], -1))
+    # posterior sample
+    mom = rnd(2, 6, 5, 8, seed=41)
+    eps = torch.randn(2, 6, 5, 4, generator=torch.Generator().manual_seed(42))
+    z = ops.vae_sample(bf(mom).to(DEV), eps.to(DEV), 4, 0.1159, 0.3611)
+    mu, lv = mom[..., :4], mom[..., 4:].clamp(-30, 20)
+    ref = ((mu + torch.exp(0.5 * lv) * eps) - 0.1159) * 0.3611
+    assert_close(z[..., :4], ref, "vae_sample")
+    assert (z[..., 4:] == 0).all()
+    # axpby
+    u, v = rnd(1000, seed=43), rnd(1000, seed=44)
+    r = ops.axpby(bf(u).to(DEV), bf(v).to(DEV), 1.0 / 0.797, -0.6035 / 0.797, 0.0, 1.0 / 0.18215)
+    assert_close(r, (u / 0.797 - v * 0.6035 / 0.797) / 0.18215, "axpby")
+    # crop
+    t = rnd(2, 9, 11, 8, seed=45)
+    cr = ops.crop_nhwc(bf(t).to(DEV), 2, 3, 4, 5)
+    assert torch.equal(cr.float().cpu(), t[:, 2:6, 3:8])
+    # flux pack / unpack
+    lat = rnd(2, 8, 12, 16, seed=46)  # NHWC
+    tok = ops.flux_pack(bf(lat).to(DEV), 16)
+    nchw = lat.permute(0, 3, 1, 2)
+    ref_tok = nchw.reshape(2, 16, 4, 2, 6, 2).permute(0, 2, 4, 1, 3, 5).reshape(2, 24, 64)
+    assert torch.equal(tok.float().cpu(), ref_tok)
+    un = ops.flux_unpack(tok, 8, 12)
+    assert torch.equal(un.float().cpu(), lat)
+
+
+def test_tile_stitch_ops():
+    ops = _ops()
+    N, H, W, Cc, th, tw = 2, 12, 10, 4, 8, 8
+    acc = torch.zeros(N, H, W, Cc, device=DEV)
+    wsum = torch.zeros(1, H, W, 1, device=DEV)
+    wt = torch.rand(th, tw, generator=torch.Generator().manual_seed(47)) + 0.1
+    ref_acc = torch.zeros(N, H, W, Cc)
+    ref_w = torch.zeros(H, W)
+    for i, (y0, x0) in enumerate([(0, 0), (4, 2), (4, 0)]):
+        tile = rnd(N, th, tw, 8, seed=48 + i)
+        ops.tile_accumulate(bf(tile).to(DEV), wt.to(DEV), acc, y0, x0)
+        ops.tile_accumulate(None, wt.to(DEV), wsum, y0, x0)
+        ref_acc[:, y0:y0 + th, x0:x0 + tw] += tile[..., :Cc] * wt[None, :, :, None]
+        ref_w[y0:y0 + th, x0:x0 + tw] += wt
+    assert torch.allclose(acc.cpu(), ref_acc, atol=1e-6)
+    ref_w = ref_w.clamp_min(1e-3)
+    wsum.clamp_(min=1e-3)
+    out = ops.tile_normalise(acc, wsum)
+    assert_close(out[..., :Cc], ref_acc / ref_w[None, :, :, None], "tile_normalise")
