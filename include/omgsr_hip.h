@@ -115,8 +115,9 @@ typedef struct omgsr_attn_args {
 } omgsr_attn_args;
 int omgsr_attention(const omgsr_attn_args* a, void* stream);
 
-/* Row softmax for the unfused d=512 VAE attention: p = softmax(s) ; s f32 [rows][L], p bf16 [rows][L]. */
-int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t L, void* stream);
+/* Row softmax for the unfused d=512 VAE attention: p = softmax(s[:, :Lvalid]); s f32 [rows][L],
+ * p bf16 [rows][L]; columns >= Lvalid (zero-padded keys) come out as exactly 0. */
+int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t L, int32_t Lvalid, void* stream);
 
 /*
  * K11 — RMSNorm(q,k over head_dim) * w then interleaved-pair RoPE, in place

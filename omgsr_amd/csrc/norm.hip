@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 // ---------------------------------------------------------------------------------------------
 // Row softmax fp32 -> bf16, one 256-thread block per row, L <= 256*4*MAXV.
 template <int MAXV>
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, int L) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, int L, int Lvalid) {
     __shared__ float red[8];
     const int t = threadIdx.x;
     const float* sr = s + (int64_t)blockIdx.x * L;
@@ -180,6 +180,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         const int j = t + 256 * i;
         if (j < nv) {
             v[i] = *reinterpret_cast<const f32x4_t*>(sr + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (4 * j + e >= Lvalid) v[i][e] = -INFINITY;   // padded keys
             mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
         }
     }
@@ -300,15 +302,15 @@ extern "C" int omgsr_layernorm(const void* x, void* y, const float* a, const flo
     return (int)hipGetLastError();
 }
 
-extern "C" int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t L, void* stream) {
-    if (!s || !p || rows <= 0 || L <= 0) return OMGSR_E_BADARG;
+extern "C" int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t L, int32_t Lvalid, void* stream) {
+    if (!s || !p || rows <= 0 || L <= 0 || Lvalid <= 0 || Lvalid > L) return OMGSR_E_BADARG;
     if ((L & 3) || L > 256 * 4 * 16 || rows >= (1ll << 31)) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     omgsr::TimingScope ts(OMGSR_TK_SOFTMAX, 0.0, 6.0 * (double)rows * L, st);
     const int nv = (L / 4 + 255) / 256;
-    if (nv <= 1) hipLaunchKernelGGL(softmax_rows_kernel<1>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L);
-    else if (nv <= 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L);
-    else hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L);
+    if (nv <= 1) hipLaunchKernelGGL(softmax_rows_kernel<1>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L, Lvalid);
+    else if (nv <= 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L, Lvalid);
+    else hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L, Lvalid);
     return (int)hipGetLastError();
 }
 

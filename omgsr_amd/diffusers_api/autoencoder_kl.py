@@ -1,0 +1,285 @@
+"""AutoencoderKL with diffusers' API surface (config fields, attribute tree, state-dict keys,
+encode()/decode() signatures) running on the gfx950 kernels.
+
+Stands in for `diffusers.AutoencoderKL` at the reference call sites
+infer/omgsr_s_infer_model.py:11,84,166,173 and infer/omgsr_f_infer_model.py:16,99,211,318; the
+attribute tree is the one infer/vaehook.py:296-329,340-355 duck-types.
+
+Data layout: NCHW tensors at the API boundary (as diffusers), bf16 NHWC inside. GroupNorm+SiLU runs
+as a statistics pass + an apply pass feeding the implicit-GEMM conv; nearest-2x upsampling and the
+encoder's asymmetric pad are folded into the conv's gather; the d=512 single-head mid attention
+uses the batched-GEMM + masked row-softmax path.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..nn import Conv2d, GroupNorm, Linear
+from .modeling_utils import ConfigDict, ModelMixin
+
+SD21_VAE_CONFIG = dict(in_channels=3, out_channels=3, block_out_channels=[128, 256, 512, 512], layers_per_block=2,
+                       latent_channels=4, norm_num_groups=32, scaling_factor=0.18215, shift_factor=None,
+                       use_quant_conv=True, use_post_quant_conv=True, act_fn="silu", sample_size=768)
+FLUX_VAE_CONFIG = dict(in_channels=3, out_channels=3, block_out_channels=[128, 256, 512, 512], layers_per_block=2,
+                       latent_channels=16, norm_num_groups=32, scaling_factor=0.3611, shift_factor=0.1159,
+                       use_quant_conv=False, use_post_quant_conv=False, act_fn="silu", sample_size=1024)
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: Optional[int], groups: int, eps: float):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = GroupNorm(groups, in_channels, eps=eps)
+        self.conv1 = Conv2d(in_channels, out_channels, 3, padding=1)
+        self.time_emb_proj = Linear(temb_channels, out_channels) if temb_channels else None
+        self.norm2 = GroupNorm(groups, out_channels, eps=eps)
+        self.conv2 = Conv2d(out_channels, out_channels, 3, padding=1)
+        self.use_in_shortcut = in_channels != out_channels
+        self.conv_shortcut = Conv2d(in_channels, out_channels, 1) if self.use_in_shortcut else None
+        self.nonlinearity = nn.SiLU()
+
+    def nhwc(self, x, conv1_bias=None):
+        """conv1_bias: conv1.bias + time_emb_proj(silu(temb)) folded by the UNet (constant at fixed t*)."""
+        h = self.norm1.nhwc(x, ops.ACT_SILU)
+        h = self.conv1.nhwc(h, bias_override=conv1_bias)
+        h = self.norm2.nhwc(h, ops.ACT_SILU)
+        sc = self.conv_shortcut.nhwc(x, pad=0) if self.conv_shortcut is not None else x
+        return self.conv2.nhwc(h, residual=sc)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, channels: int, padding: int):
+        super().__init__()
+        self.padding = padding
+        self.conv = Conv2d(channels, channels, 3, stride=2, padding=padding)
+
+    def nhwc(self, x):
+        # VAE: F.pad(x, (0,1,0,1)) then a valid stride-2 conv; UNet: symmetric padding 1
+        pad = (0, 1, 0, 1) if self.padding == 0 else self.padding
+        return self.conv.nhwc(x, pad=pad)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, channels: int):
+        super().__init__()
+        self.conv = Conv2d(channels, channels, 3, padding=1)
+
+    def nhwc(self, x):
+        return self.conv.nhwc(x, upsample=True)
+
+
+class VaeAttention(nn.Module):
+    """diffusers Attention as built by the VAE mid block: 1 head of 512, GroupNorm, biased projections,
+    residual connection."""
+
+    def __init__(self, channels: int, groups: int):
+        super().__init__()
+        self.heads = 1
+        self.scale = channels ** -0.5
+        self.group_norm = GroupNorm(groups, channels, eps=1e-6)
+        self.to_q = Linear(channels, channels)
+        self.to_k = Linear(channels, channels)
+        self.to_v = Linear(channels, channels)
+        self.to_out = nn.ModuleList([Linear(channels, channels), nn.Dropout(0.0)])
+        self.norm_cross = None
+
+    def nhwc(self, x):
+        N, H, W, Cc = x.shape
+        L = H * W
+        g = self.group_norm.nhwc(x).reshape(N, L, Cc)
+        q = self.to_q.nhwc(g)
+        Lp = ops._round_up(L, 128)
+        k = self.to_k.nhwc(g)
+        if Lp != L:
+            kp = torch.zeros((N, Lp, Cc), device=x.device, dtype=torch.bfloat16)
+            kp[:, :L] = k
+            k = kp
+        vt = ops.linear_t(g, self.to_v.packed(), L, ld=Lp)                    # [N, C, Lp], zero padded keys
+        s = ops.bmm_nt(q, k, alpha=self.scale, out_dtype=ops.OUT_F32)         # [N, L, Lp] fp32 scores
+        p = ops.softmax_rows(s, valid=L)
+        del s
+        o = ops.bmm_nt(p, vt)                                                 # [N, L, C]
+        out = self.to_out[0].nhwc(o, residual=x.reshape(N, L, Cc))
+        return out.reshape(N, H, W, Cc)
+
+
+class _VaeMid(nn.Module):
+    def __init__(self, ch: int, groups: int):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, None, groups, 1e-6), ResnetBlock2D(ch, ch, None, groups, 1e-6)])
+        self.attentions = nn.ModuleList([VaeAttention(ch, groups)])
+
+    def nhwc(self, h):
+        h = self.resnets[0].nhwc(h)
+        h = self.attentions[0].nhwc(h)
+        return self.resnets[1].nhwc(h)
+
+
+class DownEncoderBlock2D(nn.Module):
+    def __init__(self, cin, cout, layers, groups, add_down):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if j == 0 else cout, cout, None, groups, 1e-6) for j in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout, 0)]) if add_down else None
+
+    def nhwc(self, h):
+        for r in self.resnets:
+            h = r.nhwc(h)
+        if self.downsamplers is not None:
+            h = self.downsamplers[0].nhwc(h)
+        return h
+
+
+class UpDecoderBlock2D(nn.Module):
+    def __init__(self, cin, cout, layers, groups, add_up):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if j == 0 else cout, cout, None, groups, 1e-6) for j in range(layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_up else None
+
+    def nhwc(self, h):
+        for r in self.resnets:
+            h = r.nhwc(h)
+        if self.upsamplers is not None:
+            h = self.upsamplers[0].nhwc(h)
+        return h
+
+
+class Encoder(nn.Module):
+    def __init__(self, c: ConfigDict):
+        super().__init__()
+        boc, g = c.block_out_channels, c.norm_num_groups
+        self.conv_in = Conv2d(c.in_channels, boc[0], 3, padding=1)
+        blocks, out = [], boc[0]
+        for i, ch in enumerate(boc):
+            cin, out = out, ch
+            blocks.append(DownEncoderBlock2D(cin, out, c.layers_per_block, g, add_down=i < len(boc) - 1))
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = _VaeMid(boc[-1], g)
+        self.conv_norm_out = GroupNorm(g, boc[-1], eps=1e-6)
+        self.conv_act = nn.SiLU()
+        self.conv_out = Conv2d(boc[-1], 2 * c.latent_channels, 3, padding=1)
+
+    def nhwc(self, x):
+        h = self.conv_in.nhwc(x)
+        for b in self.down_blocks:
+            h = b.nhwc(h)
+        h = self.mid_block.nhwc(h)
+        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU)
+        return self.conv_out.nhwc(h)
+
+    def run_nhwc(self, x):
+        """nhwc() or, when a tiled-VAE hook is installed (pipelines.vaehook.VAEHook), the hook."""
+        hook = getattr(self, "_tile_hook", None)
+        return hook(x) if hook is not None else self.nhwc(x)
+
+    def forward(self, x):  # NCHW in/out (diffusers convention)
+        y = self.run_nhwc(ops.nchw_to_nhwc(x.contiguous(), 8))
+        return ops.nhwc_to_nchw(y, channels=self.conv_out.out_channels, dtype=_io_dtype(x))
+
+
+class Decoder(nn.Module):
+    def __init__(self, c: ConfigDict):
+        super().__init__()
+        boc, g = c.block_out_channels, c.norm_num_groups
+        rev = list(reversed(boc))
+        self.conv_in = Conv2d(c.latent_channels, rev[0], 3, padding=1)
+        self.mid_block = _VaeMid(rev[0], g)
+        blocks, out = [], rev[0]
+        for i, ch in enumerate(rev):
+            cin, out = out, ch
+            blocks.append(UpDecoderBlock2D(cin, out, c.layers_per_block + 1, g, add_up=i < len(boc) - 1))
+        self.up_blocks = nn.ModuleList(blocks)
+        self.conv_norm_out = GroupNorm(g, boc[0], eps=1e-6)
+        self.conv_act = nn.SiLU()
+        self.conv_out = Conv2d(boc[0], c.out_channels, 3, padding=1)
+
+    def nhwc(self, z):
+        h = self.conv_in.nhwc(z)
+        h = self.mid_block.nhwc(h)
+        for b in self.up_blocks:
+            h = b.nhwc(h)
+        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU)
+        return self.conv_out.nhwc(h)
+
+    def run_nhwc(self, z):
+        hook = getattr(self, "_tile_hook", None)
+        return hook(z) if hook is not None else self.nhwc(z)
+
+    def forward(self, z):
+        y = self.run_nhwc(ops.nchw_to_nhwc(z.contiguous(), ops._round_up(z.shape[1], 8)))
+        return ops.nhwc_to_nchw(y, channels=self.conv_out.out_channels, dtype=_io_dtype(z))
+
+
+def _io_dtype(x):
+    return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.bfloat16
+
+
+class DiagonalGaussianDistribution:
+    """Posterior handle returned by encode(); `sample()` draws eps from torch's global RNG on the
+    device exactly like diffusers (SURVEY C-1) unless explicit noise was provided for parity runs."""
+
+    def __init__(self, moments_nhwc: torch.Tensor, latent_channels: int, noise: Optional[torch.Tensor], out_dtype):
+        self._m, self._c, self._noise, self._dt = moments_nhwc, latent_channels, noise, out_dtype
+
+    def sample_nhwc(self, shift: float = 0.0, scale: float = 1.0, generator=None) -> torch.Tensor:
+        N, h, w, _ = self._m.shape
+        if self._noise is not None:
+            eps = self._noise.to(device=self._m.device, dtype=torch.float32).permute(0, 2, 3, 1).contiguous()
+        else:
+            eps = torch.randn((N, h, w, self._c), device=self._m.device, dtype=torch.float32, generator=generator)
+        return ops.vae_sample(self._m, eps, self._c, shift, scale)
+
+    def sample(self, generator=None) -> torch.Tensor:
+        z = self.sample_nhwc(generator=generator)
+        return ops.nhwc_to_nchw(z, channels=self._c, dtype=self._dt)
+
+    def mode(self) -> torch.Tensor:
+        return ops.nhwc_to_nchw(self._m, channels=self._c, dtype=self._dt)
+
+
+class AutoencoderKL(ModelMixin):
+    config_name = "config.json"
+    default_config = SD21_VAE_CONFIG
+
+    def __init__(self, **cfg):
+        super().__init__()
+        c = ConfigDict({**SD21_VAE_CONFIG, **cfg})
+        self.config = c
+        self.encoder = Encoder(c)
+        self.decoder = Decoder(c)
+        self.quant_conv = Conv2d(2 * c.latent_channels, 2 * c.latent_channels, 1) if c.use_quant_conv else None
+        self.post_quant_conv = Conv2d(c.latent_channels, c.latent_channels, 1) if c.use_post_quant_conv else None
+        self.posterior_noise: Optional[torch.Tensor] = None   # explicit eps [N,C,h,w] for parity runs
+
+    # ---- fast NHWC entry points used by the pipelines -------------------------------------
+    def encode_moments_nhwc(self, x_nhwc8: torch.Tensor) -> torch.Tensor:
+        m = self.encoder.run_nhwc(x_nhwc8)
+        if self.quant_conv is not None:
+            m = self.quant_conv.nhwc(m, pad=0)
+        return m
+
+    def decode_nhwc(self, z_nhwc: torch.Tensor) -> torch.Tensor:
+        """z [N,h,w,C8] (latent channels first, zero padded to 8) -> image NHWC [N,8h,8w,8] (RGB + zero pad)."""
+        if self.post_quant_conv is not None:
+            z_nhwc = self.post_quant_conv.nhwc(z_nhwc, pad=0)
+        return self.decoder.run_nhwc(z_nhwc)
+
+    # ---- diffusers API ------------------------------------------------------------------
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        m = self.encode_moments_nhwc(ops.nchw_to_nhwc(x.contiguous(), 8))
+        post = DiagonalGaussianDistribution(m, self.config.latent_channels, self.posterior_noise, _io_dtype(x))
+        return SimpleNamespace(latent_dist=post) if return_dict else (post,)
+
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        img = self.decode_nhwc(ops.nchw_to_nhwc(z.contiguous(), ops._round_up(z.shape[1], 8)))
+        out = ops.nhwc_to_nchw(img, channels=self.config.out_channels, dtype=_io_dtype(z))
+        return SimpleNamespace(sample=out) if return_dict else (out,)
+
+    def forward(self, sample, sample_posterior: bool = False):
+        post = self.encode(sample).latent_dist
+        z = post.sample() if sample_posterior else post.mode()
+        return self.decode(z)

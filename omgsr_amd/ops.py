@@ -65,10 +65,18 @@ class PackedWeight:
         return self.w.shape[1]
 
 
-def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None) -> PackedWeight:
-    """[Cout, Cin, R, S] (torch conv layout) -> [Cout_pad, roundup(R*S*Cin8, 32)] bf16, k = (r*S+s)*Cin8 + c."""
+def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, cout_multiple: int = 1) -> PackedWeight:
+    """[Cout, Cin, R, S] (torch conv layout) -> [Cout_pad, roundup(R*S*Cin8, 32)] bf16, k = (r*S+s)*Cin8 + c.
+    cout_multiple=8 widens the LOGICAL output to a multiple of 8 channels (zero weights, zero bias) so a
+    3/4-channel conv writes 16-byte rows that the next kernel can consume directly."""
     cout, cin, R, S = weight.shape
     dev = device or weight.device
+    if cout % cout_multiple:
+        extra = _round_up(cout, cout_multiple) - cout
+        weight = torch.cat([weight.detach().to(dev), torch.zeros((extra, cin, R, S), device=dev, dtype=weight.dtype)], dim=0)
+        if bias is not None:
+            bias = torch.cat([bias.detach().to(dev), torch.zeros(extra, device=dev, dtype=bias.dtype)], dim=0)
+        cout += extra
     cin8 = _round_up(cin, 8)
     w = weight.detach().to(device=dev, dtype=torch.float32).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
     if cin8 != cin:
@@ -288,12 +296,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, he
     return out
 
 
-def softmax_rows(s: torch.Tensor) -> torch.Tensor:
+def softmax_rows(s: torch.Tensor, valid: Optional[int] = None) -> torch.Tensor:
+    """softmax over the first `valid` columns of each row (the rest come out 0)."""
     _req(s, torch.float32, "s")
     L = s.shape[-1]
     rows = s.numel() // L
     p = torch.empty(s.shape, device=s.device, dtype=torch.bfloat16)
-    check(_lib.load().omgsr_softmax_rows(s.data_ptr(), p.data_ptr(), rows, L, _stream()), "omgsr_softmax_rows")
+    check(_lib.load().omgsr_softmax_rows(s.data_ptr(), p.data_ptr(), rows, L, valid or L, _stream()), "omgsr_softmax_rows")
     return p
 
 

@@ -1,0 +1,63 @@
+"""Synthetic weights / inputs / metrics shared by tests, bench.py and __graft_entry__.smoke().
+
+There are no checkpoints on the GPU box (and no network), so every model runs with seeded random
+weights at the real architecture shapes. All values are bf16-representable so the
+fp32 CPU oracle and the bf16 HIP path start from bit-identical parameters.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+
+@torch.no_grad()
+def seeded_init_(model: nn.Module, seed: int = 0, device=None) -> nn.Module:
+    """Fan-in scaled normal weights, small random biases, norm affines near (1, 0); rounded to bf16 values.
+    Deterministic per parameter NAME (not traversal order), generated on CPU."""
+    for name, p in model.named_parameters():
+        g = torch.Generator().manual_seed((hash_name(name) + seed) & 0x7FFFFFFF)
+        shape = tuple(p.shape)
+        if p.dim() >= 2:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            v = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        elif name.endswith("weight"):       # norm scale / RMSNorm weight
+            v = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:                               # biases
+            v = 0.05 * torch.randn(shape, generator=g)
+        v = v.to(torch.bfloat16).to(p.dtype)
+        p.copy_(v.to(p.device))
+    return model
+
+
+def hash_name(name: str) -> int:
+    h = 2166136261
+    for ch in name.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+def synthetic_lq(batch: int, height: int, width: int, seed: int = 1234) -> torch.Tensor:
+    """[B,3,H,W] fp32 in [-1,1]: low-passed random field upsampled x4 (mimics the x4-upscaled LQ image the
+    reference feeds the model, infer/infer_omgsr_s.py:81-84)."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(batch, 3, height // 4, width // 4, generator=g)
+    for _ in range(3):
+        u = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(u, (1, 1, 1, 1), mode="replicate"), 3, stride=1)
+    x = torch.nn.functional.interpolate(u, size=(height, width), mode="bicubic", align_corners=False)
+    x = (x - x.amin(dim=(1, 2, 3), keepdim=True)) / (x.amax(dim=(1, 2, 3), keepdim=True) - x.amin(dim=(1, 2, 3), keepdim=True))
+    return (x * 2 - 1).to(torch.bfloat16).float()
+
+
+def rel_l2(got: torch.Tensor, ref: torch.Tensor) -> float:
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return ((got - ref).norm() / ref.norm().clamp_min(1e-20)).item()
+
+
+def psnr(got: torch.Tensor, ref: torch.Tensor, peak: float = 2.0) -> float:
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    mse = (got - ref).pow(2).mean().item()
+    return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)

@@ -1,0 +1,176 @@
+"""ORACLE — test infrastructure only (never imported by omgsr_amd/).
+
+CPU fp32 restatement of the reference's pipeline layer (L3): infer/omgsr_s_infer_model.py:56-184 and
+infer/omgsr_f_infer_model.py:15-76,157-336, written against duck-typed `unet` / `vae` /
+`flux_transformer` objects (oracle.diffusers_ref modules in the parity tests).
+
+Pinned: tests/golden/*.npz hold outputs of the REFERENCE's own `_forward_tile`, `_forward_no_tile`,
+`_gaussian_weights`, `_pack_latents`/`_unpack_latents`, `get_flux_setting_timesteps` and
+`_prepare_latent_image_ids`, captured by importing /root/reference in the build container
+(tests/golden/make_golden.py); tests/test_oracle_golden.py checks this file against them.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+
+# ---- infer/omgsr_s_infer_model.py:56-71 ---------------------------------------------------------
+def gaussian_weights(tile_width: int, tile_height: int, nbatches: int, channels: int) -> torch.Tensor:
+    """N(mid, var*size^2) pdf samples per axis, outer product; x-mid (w-1)/2, y-mid h/2 (sic), fp64."""
+    var = 0.01
+    xs, ys = np.arange(tile_width, dtype=np.float64), np.arange(tile_height, dtype=np.float64)
+    norm = math.sqrt(2 * math.pi * var)
+    x_probs = np.exp(-((xs - (tile_width - 1) / 2) ** 2) / (tile_width * tile_width) / (2 * var)) / norm
+    y_probs = np.exp(-((ys - tile_height / 2) ** 2) / (tile_height * tile_height) / (2 * var)) / norm
+    w = torch.from_numpy(np.outer(y_probs, x_probs))
+    return w[None, None].repeat(nbatches, channels, 1, 1)
+
+
+# ---- infer/omgsr_s_infer_model.py:94-123 (identical in F :220-249) -------------------------------
+def tile_offsets(h: int, w: int, tile_size: int, tile_overlap: int) -> Tuple[int, int, int, List[Tuple[int, int]]]:
+    tile_size = min(tile_size, min(h, w))
+    grid_rows = 0
+    cur_x = 0
+    while cur_x < w:
+        cur_x = max(grid_rows * tile_size - tile_overlap * grid_rows, 0) + tile_size
+        grid_rows += 1
+    grid_cols = 0
+    cur_y = 0
+    while cur_y < h:
+        cur_y = max(grid_cols * tile_size - tile_overlap * grid_cols, 0) + tile_size
+        grid_cols += 1
+    offs = []
+    ofs_x = ofs_y = 0
+    for row in range(grid_rows):
+        for col in range(grid_cols):
+            if col < grid_cols - 1 or row < grid_rows - 1:
+                ofs_x = max(row * tile_size - tile_overlap * row, 0)
+                ofs_y = max(col * tile_size - tile_overlap * col, 0)
+            if row == grid_rows - 1:
+                ofs_x = w - tile_size
+            if col == grid_cols - 1:
+                ofs_y = h - tile_size
+            offs.append((ofs_y, ofs_x))
+    return tile_size, grid_rows, grid_cols, offs
+
+
+def stitch(latent_shape, preds: List[torch.Tensor], offs, tile_size: int, channels: int) -> torch.Tensor:
+    """infer/omgsr_s_infer_model.py:137-161: fp32 buffers, fp64 weights."""
+    wts = gaussian_weights(tile_size, tile_size, 1, channels)
+    noise_pred = torch.zeros(latent_shape)
+    contributors = torch.zeros(latent_shape)
+    for p, (oy, ox) in zip(preds, offs):
+        noise_pred[:, :, oy:oy + tile_size, ox:ox + tile_size] += p * wts
+        contributors[:, :, oy:oy + tile_size, ox:ox + tile_size] += wts
+    noise_pred /= contributors
+    return noise_pred
+
+
+# ---- OMGSR-S ------------------------------------------------------------------------------------
+class OmgsrSRef:
+    def __init__(self, vae, unet, alpha_t: torch.Tensor, mid_timestep: int):
+        self.vae, self.unet, self.alpha_t, self.mid_timestep = vae, unet, alpha_t, mid_timestep
+
+    def forward_no_tile(self, lq_latent, prompt_embeds):       # :74-86
+        model_pred = self.unet(lq_latent, self.mid_timestep, encoder_hidden_states=prompt_embeds).sample
+        denoised = (lq_latent - (1 - self.alpha_t).sqrt() * model_pred) / self.alpha_t.sqrt()
+        return self.vae.decode(denoised / self.vae.config.scaling_factor).sample.clamp(-1, 1)
+
+    def forward_tile(self, lq_latent, prompt_embeds, tile_size, tile_overlap):   # :88-168
+        _, c, h, w = lq_latent.shape
+        ts, _, _, offs = tile_offsets(h, w, tile_size, tile_overlap)
+        preds = [self.unet(lq_latent[:, :, oy:oy + ts, ox:ox + ts], self.mid_timestep, encoder_hidden_states=prompt_embeds).sample
+                 for (oy, ox) in offs]
+        model_pred = stitch(lq_latent.shape, preds, offs, ts, c)
+        z = (lq_latent - (1 - self.alpha_t).sqrt() * model_pred.to(lq_latent.dtype)) / self.alpha_t.sqrt()
+        return self.vae.decode(z / self.vae.config.scaling_factor).sample.clamp(-1, 1)
+
+    def __call__(self, lq_img, prompt_embeds, tile_size, tile_overlap):      # :170-184 (minus cuda sync / timing)
+        lq_latent = self.vae.encode(lq_img).latent_dist.sample() * self.vae.config.scaling_factor
+        _, _, h, w = lq_latent.shape
+        if h * w <= tile_size * tile_size:
+            return self.forward_no_tile(lq_latent, prompt_embeds)
+        return self.forward_tile(lq_latent, prompt_embeds, tile_size, tile_overlap)
+
+
+# ---- OMGSR-F helpers (infer/omgsr_f_infer_model.py:15-76, infer/infer_omgsr_f.py:17-28) -----------
+def pack_latents(latents, batch_size, num_channels_latents, height, width):
+    """2x2 space-to-depth with channel order c*4 + dy*2 + dx (== F.pixel_unshuffle), tokens row-major."""
+    x = torch.nn.functional.pixel_unshuffle(latents, 2)                       # [B, 4C, h/2, w/2]
+    return x.flatten(2).transpose(1, 2).reshape(batch_size, (height // 2) * (width // 2), num_channels_latents * 4)
+
+
+def unpack_latents(latents, height, width, vae_scale_factor):
+    b, _, c4 = latents.shape
+    h2, w2 = int(height) // (vae_scale_factor * 2), int(width) // (vae_scale_factor * 2)
+    x = latents.transpose(1, 2).reshape(b, c4, h2, w2)
+    return torch.nn.functional.pixel_shuffle(x, 2)                            # [B, C, 2*h2, 2*w2]
+
+
+def flux_timesteps(n: int = 999) -> List[float]:
+    image_seq_len = (1024 // 8) * (1024 // 8) // 4
+    timesteps = torch.linspace(1, 0, n + 1)
+    m = (1.15 - 0.5) / (4096 - 256)
+    b = 0.5 - m * 256
+    mu = m * image_seq_len + b
+    timesteps = math.exp(mu) / (math.exp(mu) + (1 / timesteps - 1) ** 1.0)
+    return timesteps.tolist()
+
+
+def prepare_latent_image_ids(height: int, width: int, dtype=torch.float32) -> torch.Tensor:
+    yy, xx = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
+    return torch.stack([torch.zeros_like(yy), yy, xx], dim=-1).reshape(height * width, 3).to(dtype)
+
+
+class OmgsrFRef:
+    def __init__(self, vae, flux, mid_timestep: int = 244, guidance_scale: float = 1.0):
+        self.vae, self.flux = vae, flux
+        self.guidance_scale = guidance_scale
+        ts = flux_timesteps()
+        self.t_curr, self.t_prev = ts[-(mid_timestep + 1)], ts[-1]
+        self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
+
+    def encode_images(self, pixels):   # :15-18
+        z = self.vae.encode(pixels).latent_dist.sample()
+        return (z - self.vae.config.shift_factor) * self.vae.config.scaling_factor
+
+    def _flux(self, packed, prompt_embeds, pooled, text_ids, image_ids):
+        bsz = packed.shape[0]
+        guidance = torch.full((bsz,), self.guidance_scale, dtype=packed.dtype)
+        return self.flux(hidden_states=packed, timestep=torch.tensor([self.t_curr]), guidance=guidance,
+                         pooled_projections=pooled, encoder_hidden_states=prompt_embeds, txt_ids=text_ids,
+                         img_ids=image_ids, return_dict=False)[0]
+
+    def forward_no_tile(self, lq_latent, prompt_embeds, pooled, text_ids, image_ids):   # :174-212
+        bsz, c, h, w = lq_latent.shape
+        x = pack_latents(lq_latent, bsz, c, h, w)
+        v = self._flux(x, prompt_embeds, pooled, text_ids, image_ids)
+        x = x + (self.t_prev - self.t_curr) * v
+        z = unpack_latents(x, h * self.vae_scale_factor, w * self.vae_scale_factor, self.vae_scale_factor)
+        z = z / self.vae.config.scaling_factor + self.vae.config.shift_factor
+        return self.vae.decode(z, return_dict=False)[0]
+
+    def forward_tile(self, lq_latent, prompt_embeds, pooled, text_ids, image_ids, tile_size, tile_overlap):   # :214-320
+        _, c, h, w = lq_latent.shape
+        ts, _, _, offs = tile_offsets(h, w, tile_size, tile_overlap)
+        preds = []
+        for (oy, ox) in offs:
+            t = lq_latent[:, :, oy:oy + ts, ox:ox + ts]
+            bsz = t.shape[0]
+            v = self._flux(pack_latents(t, bsz, c, ts, ts), prompt_embeds, pooled, text_ids, image_ids)
+            preds.append(unpack_latents(v, ts * self.vae_scale_factor, ts * self.vae_scale_factor, self.vae_scale_factor))
+        v = stitch(lq_latent.shape, preds, offs, ts, c)
+        z = lq_latent + (self.t_prev - self.t_curr) * v
+        z = z / self.vae.config.scaling_factor + self.vae.config.shift_factor
+        return self.vae.decode(z.to(lq_latent.dtype), return_dict=False)[0]
+
+    def __call__(self, lq_img, prompt_embeds, pooled, text_ids, image_ids, tile_size, tile_overlap):   # :322-336
+        z = self.encode_images(lq_img)
+        _, _, h, w = z.shape
+        if h * w <= tile_size * tile_size:
+            return self.forward_no_tile(z, prompt_embeds, pooled, text_ids, image_ids)
+        return self.forward_tile(z, prompt_embeds, pooled, text_ids, image_ids, tile_size, tile_overlap)

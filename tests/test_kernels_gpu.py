@@ -157,7 +157,7 @@ def test_bmm_nt():
 @pytest.mark.parametrize("N,C,H,W,act", [(2, 128, 64, 64, 1), (1, 320, 16, 16, 0), (2, 1920, 8, 8, 1), (1, 512, 24, 40, 1), (1, 2560, 8, 8, 1)])
 def test_group_norm(N, C, H, W, act):
     ops = _ops()
-    x = rnd(N, C, H, W, seed=20) * 2.0 + 0.5
+    x = bf(rnd(N, C, H, W, seed=20) * 2.0 + 0.5).float()
     gamma = rnd(C, seed=21) + 1.0
     beta = rnd(C, seed=22)
     ref = F.group_norm(x, 32, gamma, beta, eps=1e-6)
@@ -175,7 +175,7 @@ def test_group_norm(N, C, H, W, act):
 @pytest.mark.parametrize("rows,C", [(100, 320), (64, 640), (50, 1280), (33, 3072)])
 def test_layer_norm(rows, C):
     ops = _ops()
-    x = rnd(rows, C, seed=23) * 3.0 + 1.0
+    x = bf(rnd(rows, C, seed=23) * 3.0 + 1.0).float()
     a = rnd(C, seed=24) + 1.0
     b = rnd(C, seed=25)
     ref = F.layer_norm(x, (C,), a, b, eps=1e-5)
@@ -253,6 +253,10 @@ def test_softmax_rows():
     assert_close(p, s.softmax(-1), "softmax_rows")
     s2 = torch.randn(3, 16384, generator=torch.Generator().manual_seed(35)) * 4
     assert_close(ops.softmax_rows(s2.to(DEV)), s2.softmax(-1), "softmax_rows 16k")
+    s3 = torch.randn(5, 1664, generator=torch.Generator().manual_seed(36)) * 4
+    p3 = ops.softmax_rows(s3.to(DEV), valid=1600)
+    assert_close(p3[:, :1600], s3[:, :1600].softmax(-1), "softmax_rows masked")
+    assert (p3[:, 1600:] == 0).all()
 
 
 def test_rmsnorm_rope():
