@@ -13,16 +13,16 @@ constexpr int GN_PPC = 256;   // pixels per statistics chunk
 // x [N][HW][C] bf16.  grid = (nchunk, N), 256 threads.  LDS: 2*C floats.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                           int64_t HW, int C, int G, int nchunk) {
+    // LDS: csum[P][C], csq[P][C] — one slot per (pixel lane, channel), reduced in a FIXED order
+    // afterwards (no atomics: results are bitwise reproducible and independent of the batch size)
     extern __shared__ __attribute__((aligned(16))) float gn_lds[];
-    float* csum = gn_lds;
-    float* csq = gn_lds + C;
     const int t = threadIdx.x;
     const int n = blockIdx.y, chunk = blockIdx.x;
-    for (int c = t; c < 2 * C; c += 256) gn_lds[c] = 0.0f;
-    __syncthreads();
     const int nch8 = C >> 3;
     const int TP = nch8 < 256 ? nch8 : 256;      // threads per pixel
     const int P = 256 / TP;                      // pixels in flight
+    float* csum = gn_lds;
+    float* csq = gn_lds + P * C;
     const int64_t p0 = (int64_t)chunk * GN_PPC;
     const int npx = (int)((HW - p0) < GN_PPC ? (HW - p0) : GN_PPC);
     if (t < TP * P) {
@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                atomicAdd(&csum[c8 * 8 + e], s[e]);
-                atomicAdd(&csq[c8 * 8 + e], q[e]);
+                csum[pl * C + c8 * 8 + e] = s[e];
+                csq[pl * C + c8 * 8 + e] = q[e];
             }
         }
     }
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     const int cpg = C / G;
     if (t < G) {
         float s = 0.0f, q = 0.0f;
-        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { s += csum[c]; q += csq[c]; }
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c)
+            for (int pl = 0; pl < P; ++pl) { s += csum[pl * C + c]; q += csq[pl * C + c]; }
         float* o = partial + (((int64_t)n * nchunk + chunk) * G + t) * 2;
         o[0] = s; o[1] = q;
     }
@@ -262,7 +263,9 @@ extern "C" int omgsr_groupnorm_stats(const void* x, float* partial, float* mean,
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = omgsr_groupnorm_nchunk(HW);
     omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 2.0 * N * (double)HW * C, st);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, N), dim3(256), 2 * C * sizeof(float), st,
+    const int tp = (C >> 3) < 256 ? (C >> 3) : 256;
+    const size_t lds = 2 * (size_t)(256 / tp) * C * sizeof(float);      // <= 20 KB
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, N), dim3(256), lds, st,
                        (const bf16_t*)x, partial, HW, C, G, nchunk);
     const int tot = N * G;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 127) / 128), dim3(128), 0, st, partial, mean, rstd, var_out,
