@@ -76,11 +76,21 @@ def collect_roofline(lib_mod):
     n = lib.omgsr_timing_collect(None, 0)
     buf = (TimingEntry * max(n, 1))()
     n = lib.omgsr_timing_collect(buf, n)
-    kinds = {}
+    kinds, shapes = {}, {}
     for i in range(n):
         e = buf[i]
         k = kinds.setdefault(int(e.kind), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
         k["launches"] += 1; k["ms"] += e.ms; k["flops"] += e.flops; k["bytes"] += e.bytes
+        if e.kind in (1, 2):
+            s = shapes.setdefault((int(e.kind), int(e.m), int(e.n), int(e.k)), dict(launches=0, ms=0.0, flops=0.0))
+            s["launches"] += 1; s["ms"] += e.ms; s["flops"] += e.flops
+    table = os.environ.get("OMGSR_KERNEL_TABLE")
+    if table:   # per-shape breakdown for DESIGN.md / profiles/
+        with open(table, "w") as f:
+            f.write("| kind | M | N | K | launches | total ms | TFLOP/s |\n|---|---|---|---|---|---|---|\n")
+            for (kind, m, nn, kk), s in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
+                tf = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
+                f.write(f"| {'igemm' if kind == 1 else 'attn'} | {m} | {nn} | {kk} | {s['launches']} | {s['ms']:.3f} | {tf:.1f} |\n")
     return kinds
 
 
@@ -187,7 +197,9 @@ def cpu_leg(lq1, eps1, prompt, hip_out_nhwc, tile, overlap, side):
     from omgsr_amd.testing import psnr, rel_l2, seeded_init_
     from oracle import diffusers_ref as R
     from oracle.pipeline_ref import OmgsrSRef
-    cores = os.cpu_count() or 1
+    # 16 threads is the fastest eager-fp32 configuration on the GPU box's 2 x EPYC 9575F (measured with
+    # tools/cpu_threads_probe.py: 16 thr 1.13 TFLOP/s, 32 thr 0.77, 64 thr 0.52, 128 thr 0.24)
+    cores = int(os.environ.get("OMGSR_CPU_THREADS", min(16, os.cpu_count() or 1)))
     torch.set_num_threads(cores)
     vae, unet = seeded_init_(R.AutoencoderKL(), 101).eval(), seeded_init_(R.UNet2DConditionModel(), 202).eval()
     vae.posterior_noise = eps1

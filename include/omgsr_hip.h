@@ -169,7 +169,7 @@ int omgsr_flux_pack(const void* src, void* dst, int32_t N, int32_t H, int32_t W,
 int omgsr_timing_enable(int on);
 int omgsr_timing_reset(void);
 /* Synchronises, then fills up to `cap` entries; returns the number of recorded launches. */
-typedef struct omgsr_timing_entry { int32_t kind; float ms; double flops; double bytes; } omgsr_timing_entry;
+typedef struct omgsr_timing_entry { int32_t kind; float ms; double flops; double bytes; int64_t m, n, k; } omgsr_timing_entry;
 int omgsr_timing_collect(omgsr_timing_entry* out, int cap);
 
 #ifdef __cplusplus

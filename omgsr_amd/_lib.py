@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class OmgsrError(RuntimeError):
@@ -49,7 +49,8 @@ class AttnArgs(C.Structure):
 
 
 class TimingEntry(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
+    _fields_ = [("kind", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double),
+                ("m", C.c_int64), ("n", C.c_int64), ("k", C.c_int64)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float

@@ -236,7 +236,7 @@ extern "C" int omgsr_attention(const omgsr_attn_args* ap, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const double flops = 4.0 * (double)a.B * a.H * (double)a.Lq * a.Lk * a.D;
     const double bytes = 2.0 * (double)a.B * a.H * a.D * (2.0 * a.Lq + 2.0 * a.Lk);
-    omgsr::TimingScope ts(OMGSR_TK_ATTN, flops, bytes, st);
+    omgsr::TimingScope ts(OMGSR_TK_ATTN, flops, bytes, st, (long long)a.B * a.H * a.Lq, a.Lk, a.D);
     if (a.D == 64) return launch_attn<64>(a, st);
     if (a.D == 128) return launch_attn<128>(a, st);
     return OMGSR_E_SHAPE;

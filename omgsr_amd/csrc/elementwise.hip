@@ -155,7 +155,7 @@ inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)((tot
 
 }  // namespace
 
-extern "C" int omgsr_abi_version(void) { return 1; }
+extern "C" int omgsr_abi_version(void) { return 2; }
 
 extern "C" int omgsr_check_device(void) {
     int dev = 0;
@@ -287,6 +287,7 @@ extern "C" int omgsr_timing_collect(omgsr_timing_entry* out, int cap) {
             float ms = 0.0f;
             (void)hipEventElapsedTime(&ms, r.e0, r.e1);
             out[n].kind = r.kind; out[n].ms = ms; out[n].flops = r.flops; out[n].bytes = r.bytes;
+            out[n].m = r.m; out[n].n = r.n; out[n].k = r.k;
         }
         ++n;
     }

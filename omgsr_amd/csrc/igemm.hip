@@ -291,7 +291,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     const double flops = 2.0 * (double)M64 * (double)a.R * a.S * a.Cin * (double)logical_cols * a.batch;
     const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.Cout_pad * a.K_pad +
                                 (double)M64 * a.Cout * (a.residual ? 2 : 1)) * a.batch;
-    omgsr::TimingScope ts(OMGSR_TK_IGEMM, flops, bytes, st);
+    omgsr::TimingScope ts(OMGSR_TK_IGEMM, flops, bytes, st, M64 * a.batch, logical_cols, (long long)a.R * a.S * a.Cin);
     // Tile choice: the 128x128 tile is the MFMA-efficient default; narrow outputs use 128x32 so
     // padded columns do not burn MFMA cycles; small problems drop to 64x64 to fill the 256 CUs.
     const int64_t tiles128 = ((M64 + 127) / 128) * (a.Cout_pad / 128) * a.batch;

@@ -59,14 +59,18 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 // pass 2: one thread per (n, g): fold the chunk partials in double.
 __global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ var_out, int N, int G, int nchunk, double count, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * G) return;
+    // one wave per (n, g): lanes stride the chunk list, fixed-order butterfly in double
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x;
     const int n = i / G, g = i - n * G;
     double s = 0.0, q = 0.0;
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = lane; c < nchunk; c += 64) {
         const float* p = partial + (((int64_t)n * nchunk + c) * G + g) * 2;
         s += (double)p[0]; q += (double)p[1];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (lane != 0) return;
     const double m = s / count;
     double v = q / count - m * m;
     if (v < 0.0) v = 0.0;
@@ -268,7 +272,7 @@ extern "C" int omgsr_groupnorm_stats(const void* x, float* partial, float* mean,
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, N), dim3(256), lds, st,
                        (const bf16_t*)x, partial, HW, C, G, nchunk);
     const int tot = N * G;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 127) / 128), dim3(128), 0, st, partial, mean, rstd, var_out,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(tot), dim3(64), 0, st, partial, mean, rstd, var_out,
                        N, G, nchunk, (double)HW * (C / G), eps);
     return (int)hipGetLastError();
 }
