@@ -19,6 +19,11 @@
 #include "common.hip.h"
 #include "../../include/omgsr_hip.h"
 #include "timing.hip.h"
+#include "igemm_epilogue.hip.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace omgsr { int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st); }
 
 namespace {
 
@@ -26,13 +31,7 @@ constexpr int BK = 32;        // K elements per pipeline step
 constexpr int ROWB = 80;      // LDS row pitch in bytes (64 B of data + 16 B pad)
 constexpr int NTHREADS = 256;
 
-struct Geo {
-    int M;          // N*Ho*Wo rows per batch entry
-    int HoWo;
-    int Hv, Wv;     // virtual (post-upsample) input extent
-    int nk;         // K_pad / BK
-    int ntm, ntn;   // tile counts
-};
+using Geo = IgemmGeo;
 
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args p, const Geo g) {
@@ -162,98 +161,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args 
 
     // ---- epilogue: fragments -> LDS (fp32) -> 8 consecutive channels per lane -------------
     float* epi = reinterpret_cast<float*>(lds) + wave * 32 * EPI_LD;
-    const bool geglu = (p.act == OMGSR_ACT_GEGLU);
-    // lanes per output row and rows per pass when reading back
-    constexpr int OUTW = WTN;                 // staged columns per wave
-    const int cols_per_row = geglu ? OUTW / 2 : OUTW;   // produced output columns
-    const int lanes_per_row = cols_per_row / 8;
-    const int rows_per_pass = 64 / lanes_per_row;
-    const int lrow = lane / lanes_per_row, lcol = (lane % lanes_per_row) * 8;
-    bf16_t* outb = (bf16_t*)p.out + (int64_t)bz * p.out_bstride;
-    float* outf = (float*)p.out + (int64_t)bz * p.out_bstride;
-    const bf16_t* resb = p.residual ? (const bf16_t*)p.residual + (int64_t)bz * p.out_bstride : nullptr;
-    const bool vec_ok = (p.Cout & 7) == 0;
-
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                epi[cfrag_row(lane, r) * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
-        __syncthreads();
-        for (int rb = 0; rb < 32; rb += rows_per_pass) {
-            const int row = rb + lrow;
-            const int m = m0 + wm * WTM + i * 32 + row;
-            float v[8];
-            int n;  // first logical output column of this lane
-            if (geglu) {
-                // staged columns: per 64-wide group [32 a | 32 g]
-                const int grp = lcol >> 5, within = lcol & 31;
-                const float* pa = epi + row * EPI_LD + grp * 64 + within;
-                const int nb = n0 + wn * WTN + grp * 64 + within;   // packed bias index of a
-                n = ((n0 + wn * WTN) >> 1) + lcol;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float a = pa[e] * p.alpha, gt = pa[32 + e] * p.alpha;
-                    if (p.bias) { a += p.bias[nb + e]; gt += p.bias[nb + 32 + e]; }
-                    v[e] = a * gelu_erf_f(gt);
-                }
-            } else {
-                const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(epi + row * EPI_LD + lcol);
-                const f32x4_t x1 = *reinterpret_cast<const f32x4_t*>(epi + row * EPI_LD + lcol + 4);
-                n = n0 + wn * WTN + lcol;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = x0[e] * p.alpha; v[4 + e] = x1[e] * p.alpha; }
-                if (p.bias) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) if (n + e < p.Cout) v[e] += p.bias[n + e];
-                }
-                if (p.act == OMGSR_ACT_SILU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-                } else if (p.act == OMGSR_ACT_GELU_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
-                }
-            }
-            if (m >= g.M || n >= p.Cout) continue;
-            if (p.gate) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (n + e < p.Cout) v[e] *= p.gate[n + e];
-            }
-            if (p.out_layout == OMGSR_LAYOUT_NHWC) {
-                const int64_t o = (int64_t)m * p.Cout + n;
-                if (vec_ok) {
-                    if (resb) {
-                        float rf[8];
-                        unpack8(*reinterpret_cast<const u32x4_t*>(resb + o), rf);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += rf[e];
-                    }
-                    if (p.out_dtype == OMGSR_OUT_BF16) {
-                        *reinterpret_cast<u32x4_t*>(outb + o) = pack8(v);
-                    } else {
-                        *reinterpret_cast<f32x4_t*>(outf + o) = (f32x4_t){v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4_t*>(outf + o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
-                    }
-                } else {
-                    for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
-                        float x = v[e];
-                        if (resb) x += (float)resb[o + e];
-                        if (p.out_dtype == OMGSR_OUT_BF16) outb[o + e] = (bf16_t)x; else outf[o + e] = x;
-                    }
-                }
-            } else {  // OMGSR_LAYOUT_T: out[(m / t_rows) * Cout + n][m % t_rows]
-                const int blk = m / p.t_rows, mr = m - blk * p.t_rows;
-                for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
-                    const int64_t o = ((int64_t)blk * p.Cout + n + e) * p.t_ld + mr;
-                    if (p.out_dtype == OMGSR_OUT_BF16) outb[o] = (bf16_t)v[e]; else outf[o] = v[e];
-                }
-            }
-        }
-    }
+    igemm_epilogue<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -295,6 +203,12 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     // Tile choice: the 128x128 tile is the MFMA-efficient default; narrow outputs use 128x32 so
     // padded columns do not burn MFMA cycles; small problems drop to 64x64 to fill the 256 CUs.
     const int64_t tiles128 = ((M64 + 127) / 128) * (a.Cout_pad / 128) * a.batch;
+    // Large problems: LDS-DMA kernel (256x128 tile, 3-stage ring). OMGSR_IGEMM_MODE=reg|dma overrides (A/B runs).
+    static const char* mode = getenv("OMGSR_IGEMM_MODE");
+    const int64_t tiles256 = ((M64 + 255) / 256) * ((logical_cols + 127) / 128) * a.batch;
+    const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0;   // the DMA kernel's K-steps never straddle taps
+    if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192)))
+        return omgsr::igemm_dma_launch(a, g, st);
     if (a.act == OMGSR_ACT_GEGLU) return launch<128, 128, 2, 2>(a, g, st);   // needs a 64-wide wave tile
     if (logical_cols <= 32) return launch<128, 32, 4, 1>(a, g, st);
     if (logical_cols <= 64 || tiles128 < 192) return launch<64, 64, 2, 2>(a, g, st);

@@ -1,0 +1,39 @@
+"""Micro-benchmark of the implicit-GEMM kernels on the OMGSR layer shapes (GPU box).
+Usage: OMGSR_IGEMM_MODE=reg|dma python tools/bench_igemm.py [reps]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omgsr_amd import ops
+
+SHAPES = [  # name, N, H, W, Cin, Cout, ksize
+    ("vae 128->128 @512", 8, 512, 512, 128, 128, 3),
+    ("vae 256->256 @256", 8, 256, 256, 256, 256, 3),
+    ("vae 512->512 @128", 8, 128, 128, 512, 512, 3),
+    ("vae 512->512 @64", 8, 64, 64, 512, 512, 3),
+    ("unet 320->320 @64", 8, 64, 64, 320, 320, 3),
+    ("unet 640->640 @32", 8, 32, 32, 640, 640, 3),
+    ("unet 1280->1280 @16", 8, 16, 16, 1280, 1280, 3),
+    ("unet lin 320->320 M=32768", 1, 1, 32768, 320, 320, 1),
+    ("unet lin 640->5120 M=8192", 1, 1, 8192, 640, 5120, 1),
+    ("flux lin 3072->3072 M=4608", 1, 1, 4608, 3072, 3072, 1),
+    ("flux lin 3072->12288 M=4608", 1, 1, 4608, 3072, 12288, 1),
+    ("flux lin 15360->3072 M=4608", 1, 1, 4608, 15360, 3072, 1),
+]
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+dev = "cuda"
+print("mode", os.environ.get("OMGSR_IGEMM_MODE", "auto"))
+FILTER = os.environ.get("SHAPE_FILTER", "")
+for name, N, H, W, Cin, Cout, k in [s for s in SHAPES if FILTER in s[0]]:
+    x = (torch.randn(N, H, W, Cin, device=dev) * 0.5).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5
+    pw = ops.pack_conv_weight(w, torch.zeros(Cout, device=dev))
+    pad = 1 if k == 3 else 0
+    y = ops.conv2d(x, pw, pad=pad)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        y = ops.conv2d(x, pw, pad=pad)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / reps
+    fl = 2.0 * N * H * W * Cin * k * k * Cout
+    print(f"{name:32s} {dt * 1e3:8.3f} ms  {fl / dt / 1e12:8.1f} TFLOP/s   finite={bool(torch.isfinite(y.float()).all())}", flush=True)
