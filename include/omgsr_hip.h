@@ -71,6 +71,7 @@ typedef struct omgsr_igemm_args {
     int32_t Ho, Wo;
     int32_t act, out_dtype, out_layout;
     int32_t t_rows, t_ld;  /* OMGSR_LAYOUT_T only                                      */
+    int32_t out_ld;        /* NHWC row stride of `out` in elements; 0 = Cout (residual always uses Cout) */
     int32_t batch;         /* grid.z; strides below are in elements                    */
     int64_t in_bstride, w_bstride, out_bstride;
     float alpha;
@@ -122,7 +123,8 @@ int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t L, int32_t
 /*
  * K11 — RMSNorm(q,k over head_dim) * w then interleaved-pair RoPE, in place
  * (FluxAttnProcessor2_0: norm_q/norm_k + apply_rotary_emb).  x bf16 rows [B*L] with stride ld,
- * head h at column col0 + h*D; w f32 [D]; cos/sin f32 [L][D] (repeat-interleaved pairs); rope may be NULL.
+ * head h at column col0 + h*D; w f32 [H][D] (per-head weight rows, so one call covers the q heads and the
+ * k heads of a fused [q|k] buffer); cos/sin f32 [>= pos0+L][D] (repeat-interleaved pairs); rope may be NULL.
  */
 int omgsr_rmsnorm_rope(void* x, const float* w, const float* cos_t, const float* sin_t, int32_t B,
                        int32_t L, int32_t H, int32_t D, int64_t ld, int32_t col0, int32_t pos0,

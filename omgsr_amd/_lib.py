@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class OmgsrError(RuntimeError):
@@ -31,7 +31,7 @@ class IgemmArgs(C.Structure):
         ("pad_left", C.c_int32), ("upsample", C.c_int32),
         ("Ho", C.c_int32), ("Wo", C.c_int32),
         ("act", C.c_int32), ("out_dtype", C.c_int32), ("out_layout", C.c_int32),
-        ("t_rows", C.c_int32), ("t_ld", C.c_int32),
+        ("t_rows", C.c_int32), ("t_ld", C.c_int32), ("out_ld", C.c_int32),
         ("batch", C.c_int32),
         ("in_bstride", C.c_int64), ("w_bstride", C.c_int64), ("out_bstride", C.c_int64),
         ("alpha", C.c_float),

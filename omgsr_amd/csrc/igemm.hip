@@ -189,6 +189,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     if (logical_cols > a.Cout_pad) return OMGSR_E_SHAPE;
     if (a.act == OMGSR_ACT_GEGLU && ((a.Cout & 31) || a.out_layout != OMGSR_LAYOUT_NHWC)) return OMGSR_E_SHAPE;
     if (a.out_layout == OMGSR_LAYOUT_T && (a.t_rows <= 0 || a.t_ld < a.t_rows || a.residual)) return OMGSR_E_BADARG;
+    if (a.out_ld != 0 && (a.out_ld < a.Cout || a.out_layout != OMGSR_LAYOUT_NHWC)) return OMGSR_E_BADARG;
     Geo g;
     g.M = (int)M64;
     g.HoWo = a.Ho * a.Wo;

@@ -18,7 +18,8 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, const int M, f32x16_
     bf16_t* outb = (bf16_t*)p.out + (int64_t)bz * p.out_bstride;
     float* outf = (float*)p.out + (int64_t)bz * p.out_bstride;
     const bf16_t* resb = p.residual ? (const bf16_t*)p.residual + (int64_t)bz * p.out_bstride : nullptr;
-    const bool vec_ok = (p.Cout & 7) == 0;
+    const bool vec_ok = (p.Cout & 7) == 0 && (p.out_ld & 7) == 0;
+    const int64_t ldo = p.out_ld > 0 ? p.out_ld : p.Cout;
 
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -70,11 +71,12 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, const int M, f32x16_
                 for (int e = 0; e < 8; ++e) if (n + e < p.Cout) v[e] *= p.gate[n + e];
             }
             if (p.out_layout == OMGSR_LAYOUT_NHWC) {
-                const int64_t o = (int64_t)m * p.Cout + n;
+                const int64_t o = (int64_t)m * ldo + n;
+                const int64_t ro = (int64_t)m * p.Cout + n;
                 if (vec_ok) {
                     if (resb) {
                         float rf[8];
-                        unpack8(*reinterpret_cast<const u32x4_t*>(resb + o), rf);
+                        unpack8(*reinterpret_cast<const u32x4_t*>(resb + ro), rf);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rf[e];
                     }
@@ -87,7 +89,7 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, const int M, f32x16_
                 } else {
                     for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
                         float x = v[e];
-                        if (resb) x += (float)resb[o + e];
+                        if (resb) x += (float)resb[ro + e];
                         if (p.out_dtype == OMGSR_OUT_BF16) outb[o + e] = (bf16_t)x; else outf[o + e] = x;
                     }
                 }

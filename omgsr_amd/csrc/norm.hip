@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
     for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float r = rsqrtf(q / (float)D + eps);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = f[e] * r * w[sub * 8 + e];
+    for (int e = 0; e < 8; ++e) f[e] = f[e] * r * w[h * D + sub * 8 + e];
     if (cos_t) {
         const int pos = pos0 + (int)(row % L);
         const float* cp = cos_t + (int64_t)pos * D + sub * 8;

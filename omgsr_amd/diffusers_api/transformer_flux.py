@@ -1,0 +1,299 @@
+"""FluxTransformer2DModel (FLUX.1-dev MM-DiT) with diffusers' API surface on the gfx950 kernels.
+
+Stands in for `diffusers.FluxTransformer2DModel` at infer/omgsr_f_infer_model.py:103-106,191-200,271-280:
+keyword call `flux(hidden_states=, timestep=, guidance=, pooled_projections=, encoder_hidden_states=,
+txt_ids=, img_ids=, return_dict=False)[0]`, `.dtype`. State-dict keys: SURVEY A.5.
+
+MI355X-first execution:
+  * OMGSR calls the DiT at ONE sigma(t*), ONE guidance value and ONE pooled prompt: `temb` is a constant,
+    so every AdaLN-Zero modulation vector (3.28 B parameters that only ever see that 1-token constant:
+    norm1/norm1_context/norm.linear/norm_out.linear and the three embedder MLPs) is folded once, in fp32,
+    into per-block (1+scale, shift, gate) vectors. Per image the blocks then run only the token GEMMs.
+  * LayerNorm+modulate is one row kernel (a[c]*x^+b[c]); gate*y+residual, GELU-tanh and biases are GEMM
+    epilogues; q|k come out of ONE fused projection GEMM per stream, written straight into the joint
+    [text ; image] sequence buffer; V is written transposed into the joint V^T buffer
+  * RMSNorm(q,k)*w + RoPE is one in-place pass over the fused [q|k] buffer (per-head weight table)
+  * joint attention (24 heads x 128, 4608 keys) is the fused MFMA attention kernel; in the single blocks it
+    writes directly into the [attn | mlp] concat buffer that proj_out consumes
+Batch: images are processed one sequence at a time (M = 4608 tokens already fills the chip; the joint
+buffers stay L2/MALL friendly); the reference itself is batch-1 (infer/infer_omgsr_f.py:95).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..nn import LayerNorm, Linear, RMSNormWeight, _key
+from .modeling_utils import ConfigDict, ModelMixin
+from .unet_2d_condition import TimestepEmbedding, timestep_sinusoid
+
+FLUX_DEV_CONFIG = dict(patch_size=1, in_channels=64, out_channels=None, num_layers=19, num_single_layers=38,
+                       attention_head_dim=128, num_attention_heads=24, joint_attention_dim=4096,
+                       pooled_projection_dim=768, guidance_embeds=True, axes_dims_rope=[16, 56, 56])
+
+
+class _Cached:
+    def _cache(self, name, builder, *tensors):
+        k = _key(*tensors)
+        slot = self.__dict__.setdefault("_pk_cache", {})
+        if name not in slot or slot[name][0] != k:
+            slot[name] = (k, builder())
+        return slot[name][1]
+
+
+class FluxAttention(nn.Module, _Cached):
+    def __init__(self, dim: int, heads: int, head_dim: int, joint: bool, pre_only: bool):
+        super().__init__()
+        inner = heads * head_dim
+        self.heads, self.head_dim, self.inner, self.scale = heads, head_dim, inner, head_dim ** -0.5
+        self.to_q, self.to_k, self.to_v = Linear(dim, inner), Linear(dim, inner), Linear(dim, inner)
+        self.norm_q, self.norm_k = RMSNormWeight(head_dim, 1e-6), RMSNormWeight(head_dim, 1e-6)
+        if joint:
+            self.add_q_proj, self.add_k_proj, self.add_v_proj = Linear(dim, inner), Linear(dim, inner), Linear(dim, inner)
+            self.norm_added_q, self.norm_added_k = RMSNormWeight(head_dim, 1e-6), RMSNormWeight(head_dim, 1e-6)
+            self.to_add_out = Linear(inner, dim)
+        self.to_out = None if pre_only else nn.ModuleList([Linear(inner, dim), nn.Dropout(0.0)])
+
+    def qk_packed(self, ctx: bool = False) -> ops.PackedWeight:
+        q, k = (self.add_q_proj, self.add_k_proj) if ctx else (self.to_q, self.to_k)
+        return self._cache("qk_ctx" if ctx else "qk", lambda: ops.pack_linear_weight(
+            torch.cat([q.weight, k.weight], 0), torch.cat([q.bias, k.bias], 0)), q.weight, k.weight, q.bias, k.bias)
+
+    def norm_table(self, ctx: bool = False) -> torch.Tensor:
+        nq, nk = (self.norm_added_q, self.norm_added_k) if ctx else (self.norm_q, self.norm_k)
+        return self._cache("nt_ctx" if ctx else "nt", lambda: torch.cat(
+            [nq.w32()[None].expand(self.heads, -1), nk.w32()[None].expand(self.heads, -1)], 0).contiguous(), nq.weight, nk.weight)
+
+
+class GELUProj(nn.Module):
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out)
+
+
+class FluxFeedForward(nn.Module):
+    def __init__(self, dim: int, mult: int = 4):
+        super().__init__()
+        self.net = nn.ModuleList([GELUProj(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim)])
+
+    def run(self, xn, residual, gate):
+        h = self.net[0].proj.nhwc(xn, act=ops.ACT_GELU_TANH)
+        return self.net[2].nhwc(h, residual=residual, gate=gate)
+
+
+class AdaLayerNormZero(nn.Module):
+    def __init__(self, dim: int, chunks: int):
+        super().__init__()
+        self.chunks = chunks
+        self.linear = Linear(dim, chunks * dim)
+        self.norm = LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+
+    @torch.no_grad()
+    def fold(self, act32: torch.Tensor):
+        """silu(temb) [dim] fp32 -> `chunks` fp32 vectors (constant folding, once per (t*, guidance, prompt))."""
+        m = F.linear(act32, self.linear.weight.float(), self.linear.bias.float())
+        return [c.contiguous() for c in m.chunk(self.chunks)]
+
+
+class FluxTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, head_dim):
+        super().__init__()
+        self.norm1 = AdaLayerNormZero(dim, 6)
+        self.norm1_context = AdaLayerNormZero(dim, 6)
+        self.attn = FluxAttention(dim, heads, head_dim, joint=True, pre_only=False)
+        self.norm2 = LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.ff = FluxFeedForward(dim)
+        self.norm2_context = LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.ff_context = FluxFeedForward(dim)
+
+    def fold(self, act32):
+        def six(norm):
+            shift_a, scale_a, gate_a, shift_m, scale_m, gate_m = norm.fold(act32)
+            return dict(a1=(1 + scale_a).contiguous(), b1=shift_a, g1=gate_a, a2=(1 + scale_m).contiguous(), b2=shift_m, g2=gate_m)
+        return dict(img=six(self.norm1), ctx=six(self.norm1_context))
+
+    def run(self, h, c, mod, rope, ws):
+        """h [Li, D] image tokens, c [Lc, D] text tokens (bf16); ws = joint work buffers."""
+        at = self.attn
+        Lc, Li, D = c.shape[0], h.shape[0], h.shape[1]
+        mi, mc = mod["img"], mod["ctx"]
+        hn = ops.layer_norm(h, mi["a1"], mi["b1"], 1e-6)
+        cn = ops.layer_norm(c, mc["a1"], mc["b1"], 1e-6)
+        qk, vt, o = ws["qk"], ws["vt"], ws["o"]
+        ops.linear_into(cn, at.qk_packed(ctx=True), qk, 0, 0)
+        ops.linear_into(hn, at.qk_packed(), qk, Lc, 0)
+        ops.linear_t_into(cn, at.add_v_proj.packed(), vt, 0)
+        ops.linear_t_into(hn, at.to_v.packed(), vt, Lc)
+        cos, sin = rope
+        ops.rmsnorm_rope_(qk[None, :Lc], at.norm_table(ctx=True), cos, sin, 2 * at.heads, at.head_dim, pos0=0)
+        ops.rmsnorm_rope_(qk[None, Lc:], at.norm_table(), cos, sin, 2 * at.heads, at.head_dim, pos0=Lc)
+        ops.attention(qk[None], qk[None], vt[None], at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=Lc + Li, out=o[None])
+        h = at.to_out[0].nhwc(o[Lc:], residual=h, gate=mi["g1"])
+        c = at.to_add_out.nhwc(o[:Lc], residual=c, gate=mc["g1"])
+        h = self.ff.run(ops.layer_norm(h, mi["a2"], mi["b2"], 1e-6), h, mi["g2"])
+        c = self.ff_context.run(ops.layer_norm(c, mc["a2"], mc["b2"], 1e-6), c, mc["g2"])
+        return h, c
+
+
+class FluxSingleTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, head_dim, mlp_ratio=4.0):
+        super().__init__()
+        self.mlp_hidden = int(dim * mlp_ratio)
+        self.norm = AdaLayerNormZero(dim, 3)
+        self.proj_mlp = Linear(dim, self.mlp_hidden)
+        self.act_mlp = nn.GELU(approximate="tanh")
+        self.proj_out = Linear(dim + self.mlp_hidden, dim)
+        self.attn = FluxAttention(dim, heads, head_dim, joint=False, pre_only=True)
+
+    def fold(self, act32):
+        shift, scale, gate = self.norm.fold(act32)
+        return dict(a=(1 + scale).contiguous(), b=shift, g=gate)
+
+    def run(self, x, mod, rope, ws):
+        at = self.attn
+        L, D = x.shape
+        xn = ops.layer_norm(x, mod["a"], mod["b"], 1e-6)
+        qk, vt, cat = ws["qk"], ws["vt"], ws["cat"]
+        ops.linear_into(xn, at.qk_packed(), qk, 0, 0)
+        ops.linear_t_into(xn, at.to_v.packed(), vt, 0)
+        ops.rmsnorm_rope_(qk[None], at.norm_table(), rope[0], rope[1], 2 * at.heads, at.head_dim, pos0=0)
+        ops.attention(qk[None], qk[None], vt[None], at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=L, out=cat[None])
+        ops.linear_into(xn, self.proj_mlp.packed(), cat, 0, D, act=ops.ACT_GELU_TANH)
+        return self.proj_out.nhwc(cat, residual=x, gate=mod["g"])
+
+
+class _TextProj(nn.Module):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.linear_1 = Linear(in_dim, dim)
+        self.act_1 = nn.SiLU()
+        self.linear_2 = Linear(dim, dim)
+
+    def fp32(self, x):
+        h = F.linear(x, self.linear_1.weight.float(), self.linear_1.bias.float())
+        return F.linear(F.silu(h), self.linear_2.weight.float(), self.linear_2.bias.float())
+
+
+class _TimeTextEmbed(nn.Module):
+    def __init__(self, dim, pooled_dim, guidance: bool):
+        super().__init__()
+        self.timestep_embedder = TimestepEmbedding(256, dim)
+        self.guidance_embedder = TimestepEmbedding(256, dim) if guidance else None
+        self.text_embedder = _TextProj(pooled_dim, dim)
+
+    @torch.no_grad()
+    def fp32(self, timestep, guidance, pooled):
+        e = self.timestep_embedder.fp32(timestep_sinusoid(timestep, 256, True, 0.0))
+        if self.guidance_embedder is not None:
+            e = e + self.guidance_embedder.fp32(timestep_sinusoid(guidance, 256, True, 0.0))
+        return e + self.text_embedder.fp32(pooled.float())
+
+
+class AdaLayerNormContinuous(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.linear = Linear(dim, 2 * dim)
+        self.norm = LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+
+
+def rope_tables(ids: torch.Tensor, axes_dim, theta: float = 10000.0):
+    """FluxPosEmbed: per axis float64 angles, cos/sin repeat-interleaved (real pairs) -> fp32 [L, sum(axes)]."""
+    cos, sin = [], []
+    pos = ids.to(torch.float64)
+    for i, d in enumerate(axes_dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64, device=ids.device) / d))
+        ang = torch.outer(pos[:, i], freqs)
+        cos.append(ang.cos().repeat_interleave(2, dim=1).float())
+        sin.append(ang.sin().repeat_interleave(2, dim=1).float())
+    return torch.cat(cos, -1).contiguous(), torch.cat(sin, -1).contiguous()
+
+
+class FluxTransformer2DModel(ModelMixin, _Cached):
+    default_config = FLUX_DEV_CONFIG
+
+    def __init__(self, **cfg):
+        super().__init__()
+        c = ConfigDict({**FLUX_DEV_CONFIG, **cfg})
+        self.config = c
+        dim = c.num_attention_heads * c.attention_head_dim
+        self.inner_dim = dim
+        if sum(c.axes_dims_rope) != c.attention_head_dim or c.attention_head_dim != 128:
+            raise ValueError("the gfx950 Flux path is specialised for head_dim 128 = sum(axes_dims_rope)")
+        self.x_embedder = Linear(c.in_channels, dim)
+        self.context_embedder = Linear(c.joint_attention_dim, dim)
+        self.time_text_embed = _TimeTextEmbed(dim, c.pooled_projection_dim, c.guidance_embeds)
+        self.transformer_blocks = nn.ModuleList([FluxTransformerBlock(dim, c.num_attention_heads, c.attention_head_dim) for _ in range(c.num_layers)])
+        self.single_transformer_blocks = nn.ModuleList([FluxSingleTransformerBlock(dim, c.num_attention_heads, c.attention_head_dim) for _ in range(c.num_single_layers)])
+        self.norm_out = AdaLayerNormContinuous(dim)
+        self.proj_out = Linear(dim, c.patch_size * c.patch_size * (c.out_channels or c.in_channels))
+        self._mod_cache = None
+
+    # ---- constant folding ------------------------------------------------------------------
+    @torch.no_grad()
+    def _modulation(self, timestep: torch.Tensor, guidance: Optional[torch.Tensor], pooled: torch.Tensor):
+        t = float(timestep.reshape(-1)[0])
+        g = None if guidance is None else float(guidance.reshape(-1)[0].float())
+        key = (t, g, _key(pooled), _key(self.norm_out.linear.weight, self.x_embedder.weight))
+        if self._mod_cache is None or self._mod_cache[0] != key:
+            dev = self.x_embedder.weight.device
+            # fp32 timestep path (the fp32 oracle's semantics; the bf16 reference rounds t*1000 to 504.0, SURVEY C-7)
+            tt = torch.tensor([t * 1000.0], dtype=torch.float32, device=dev)
+            gg = None if g is None else torch.tensor([g * 1000.0], dtype=torch.float32, device=dev)
+            temb = self.time_text_embed.fp32(tt, gg, pooled.to(dev)[:1])[0]
+            act = F.silu(temb)
+            double = [b.fold(act) for b in self.transformer_blocks]
+            single = [b.fold(act) for b in self.single_transformer_blocks]
+            scale, shift = F.linear(act, self.norm_out.linear.weight.float(), self.norm_out.linear.bias.float()).chunk(2)   # scale FIRST
+            out = dict(a=(1 + scale).contiguous(), b=shift.contiguous())
+            self._mod_cache = (key, dict(double=double, single=single, out=out))
+        return self._mod_cache[1]
+
+    def _rope(self, txt_ids, img_ids):
+        return self._cache("rope", lambda: rope_tables(torch.cat([txt_ids, img_ids], 0).float(), self.config.axes_dims_rope), txt_ids, img_ids)
+
+    def _context(self, ehs):
+        return self._cache("ctx", lambda: self.context_embedder.nhwc(ehs.to(torch.bfloat16).contiguous()), ehs,
+                           self.context_embedder.weight)
+
+    # ---- token executor --------------------------------------------------------------------
+    def tokens(self, x_tok: torch.Tensor, timestep, guidance, pooled, ehs, txt_ids, img_ids) -> torch.Tensor:
+        """x_tok [B, Li, in_channels] bf16 -> velocity [B, Li, in_channels] bf16."""
+        mod = self._modulation(timestep, guidance, pooled)
+        rope = self._rope(txt_ids, img_ids)
+        ctx0 = self._context(ehs)                               # [1|B, Lc, D]
+        B, Li, _ = x_tok.shape
+        Lc, D = ctx0.shape[1], self.inner_dim
+        L = Lc + Li
+        dev = x_tok.device
+        mlp = self.single_transformer_blocks[0].mlp_hidden if len(self.single_transformer_blocks) else 0
+        ws = dict(qk=torch.empty((L, 2 * D), device=dev, dtype=torch.bfloat16),
+                  vt=torch.empty((D, ops._round_up(L, 8)), device=dev, dtype=torch.bfloat16),
+                  o=torch.empty((L, D), device=dev, dtype=torch.bfloat16),
+                  cat=torch.empty((L, D + mlp), device=dev, dtype=torch.bfloat16))
+        if ws["vt"].shape[1] != L:
+            ws["vt"].zero_()
+        outs = []
+        for b in range(B):
+            h = self.x_embedder.nhwc(x_tok[b])
+            c = ctx0[b if ctx0.shape[0] > 1 else 0]
+            for blk, m in zip(self.transformer_blocks, mod["double"]):
+                h, c = blk.run(h, c, m, rope, ws)
+            x = torch.cat([c, h], 0)
+            for blk, m in zip(self.single_transformer_blocks, mod["single"]):
+                x = blk.run(x, m, rope, ws)
+            hn = ops.layer_norm(x[Lc:], mod["out"]["a"], mod["out"]["b"], 1e-6)
+            outs.append(self.proj_out.nhwc(hn))
+        return torch.stack(outs, 0)
+
+    # ---- diffusers API ---------------------------------------------------------------------
+    def forward(self, hidden_states, timestep, guidance=None, pooled_projections=None, encoder_hidden_states=None,
+                txt_ids=None, img_ids=None, return_dict: bool = True, **_):
+        x = hidden_states.to(torch.bfloat16).contiguous()
+        out = self.tokens(x, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids)
+        out = out.to(hidden_states.dtype)
+        return SimpleNamespace(sample=out) if return_dict else (out,)

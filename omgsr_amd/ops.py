@@ -169,6 +169,51 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, act: int = ACT_NONE, residual: 
     return y.reshape(*lead, pw.cout)
 
 
+def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int, col0: int, *, act: int = ACT_NONE,
+                residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None) -> None:
+    """out[row0:row0+M, col0:col0+Cout] = epilogue(x @ W^T): writes a projection straight into a slice of a
+    larger 2-D token buffer `out` [rows, ld] (joint text+image sequences, [attn | mlp] concat)."""
+    _req(x, torch.bfloat16, "x"); _req(out, torch.bfloat16, "out")
+    M, K = x.numel() // x.shape[-1], x.shape[-1]
+    ld = out.shape[-1]
+    if K != pw.cin or out.dim() != 2 or row0 + M > out.shape[0] or col0 + pw.cout > ld or (col0 & 7):
+        raise ValueError("linear_into: slice does not fit")
+    if residual is not None:
+        _req(residual, torch.bfloat16, "residual")
+        if residual.numel() != M * pw.cout:
+            raise ValueError("linear_into: residual must be a dense [M, Cout]")
+    a = IgemmArgs()
+    a.in_, a.weight, a.bias, a.gate = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
+    a.residual, a.out = _ptr(residual), out.data_ptr() + 2 * (row0 * ld + col0)
+    a.N, a.H, a.W, a.Cin = 1, 1, M, K
+    a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
+    a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
+    a.Ho, a.Wo = 1, M
+    a.act, a.out_dtype, a.out_layout = act, OUT_BF16, LAYOUT_NHWC
+    a.out_ld = ld
+    a.batch, a.alpha = 1, 1.0
+    check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_into)")
+
+
+def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: int) -> None:
+    """out_t[n, key0 + l] = (x W^T + b)[l, n] for x [L, K]: transposed projection into a slice of a joint
+    V^T buffer [Cout, ld]."""
+    _req(x, torch.bfloat16, "x"); _req(out_t, torch.bfloat16, "out_t")
+    L, K = x.numel() // x.shape[-1], x.shape[-1]
+    if out_t.dim() != 2 or out_t.shape[0] != pw.cout or key0 + L > out_t.shape[1]:
+        raise ValueError("linear_t_into: slice does not fit")
+    a = IgemmArgs()
+    a.in_, a.weight, a.bias, a.out = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), out_t.data_ptr() + 2 * key0
+    a.N, a.H, a.W, a.Cin = 1, 1, L, K
+    a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
+    a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
+    a.Ho, a.Wo = 1, L
+    a.act, a.out_dtype, a.out_layout = ACT_NONE, OUT_BF16, LAYOUT_T
+    a.t_rows, a.t_ld = L, out_t.shape[1]
+    a.batch, a.alpha = 1, 1.0
+    check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_t_into)")
+
+
 def linear_t(x: torch.Tensor, pw: PackedWeight, rows_per_batch: int, ld: Optional[int] = None) -> torch.Tensor:
     """Transposed-output projection: x [B, L, K] -> out [B, Cout, ld] with out[b, n, l] = (x W^T + bias)[b, l, n].
     This is how V reaches omgsr_attention (key index contiguous). Columns l >= L are zero."""
@@ -308,9 +353,12 @@ def softmax_rows(s: torch.Tensor, valid: Optional[int] = None) -> torch.Tensor:
 
 def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor],
                   heads: int, head_dim: int, col0: int = 0, pos0: int = 0, eps: float = 1e-6) -> torch.Tensor:
-    """In place on x [B, L, ld]: per head RMSNorm(head_dim)*w then RoPE with cos/sin [Lpos, D] (f32)."""
+    """In place on x [B, L, ld]: per head RMSNorm(head_dim) * w[h] then RoPE with cos/sin [>= pos0+L, D] (f32).
+    w is [heads, D]: one call can cover the q heads and the k heads of a fused [q|k] buffer."""
     _req(x, torch.bfloat16, "x"); _req(w, torch.float32, "w")
     B, L, ld = x.shape
+    if tuple(w.shape) != (heads, head_dim):
+        raise ValueError(f"rmsnorm_rope_: w must be [{heads}, {head_dim}], got {tuple(w.shape)}")
     check(_lib.load().omgsr_rmsnorm_rope(x.data_ptr(), w.data_ptr(), _ptr(cos), _ptr(sin), B, L, heads, head_dim, ld,
                                          col0, pos0, eps, _stream()), "omgsr_rmsnorm_rope")
     return x

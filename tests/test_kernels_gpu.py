@@ -144,6 +144,27 @@ def test_linear_transposed_out():
     assert (yt[:, :, L:] == 0).all()
 
 
+def test_linear_into_slices():
+    """Projections written straight into slices of joint buffers (Flux joint sequence / [attn|mlp] concat)."""
+    ops = _ops()
+    Lc, Li, K, Nout = 24, 200, 256, 384
+    xc, xi = rnd(Lc, K, seed=60), rnd(Li, K, seed=61)
+    wc, wi = rnd(Nout, K, seed=62, scale=K ** -0.5), rnd(Nout, K, seed=63, scale=K ** -0.5)
+    bc, bi = rnd(Nout, seed=64), rnd(Nout, seed=65)
+    joint = torch.full((Lc + Li, 2 * Nout + 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.linear_into(bf(xc).to(DEV), ops.pack_linear_weight(wc, bc, device=DEV), joint, 0, Nout)
+    ops.linear_into(bf(xi).to(DEV), ops.pack_linear_weight(wi, bi, device=DEV), joint, Lc, Nout, act=ops.ACT_GELU_TANH)
+    j = joint.float().cpu()
+    assert_close(j[:Lc, Nout:2 * Nout], F.linear(xc, wc, bc), "linear_into ctx")
+    assert_close(j[Lc:, Nout:2 * Nout], F.gelu(F.linear(xi, wi, bi), approximate="tanh"), "linear_into img")
+    assert (j[:, :Nout] == 7).all() and (j[:, 2 * Nout:] == 7).all()          # nothing outside the slice is touched
+    vt = torch.zeros((Nout, Lc + Li), dtype=torch.bfloat16, device=DEV)
+    ops.linear_t_into(bf(xc).to(DEV), ops.pack_linear_weight(wc, bc, device=DEV), vt, 0)
+    ops.linear_t_into(bf(xi).to(DEV), ops.pack_linear_weight(wi, bi, device=DEV), vt, Lc)
+    ref = torch.cat([F.linear(xc, wc, bc), F.linear(xi, wi, bi)], 0).t()
+    assert_close(vt, ref, "linear_t_into")
+
+
 def test_bmm_nt():
     ops = _ops()
     B, M, K, Nn = 2, 200, 512, 256
@@ -263,7 +284,7 @@ def test_rmsnorm_rope():
     ops = _ops()
     B, L, H, D = 2, 96, 3, 128
     x = rnd(B, L, 2 * H * D, seed=36)
-    w = rnd(D, seed=37) + 1.0
+    w = rnd(H, D, seed=37) + 1.0          # per-head weight rows (q heads / k heads of a fused buffer)
     pos = torch.arange(L + 8, dtype=torch.float64)
     freqs = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float64) / D))
     ang = torch.outer(pos, freqs)
@@ -271,7 +292,7 @@ def test_rmsnorm_rope():
     sin = ang.sin().repeat_interleave(2, dim=1).float()
     col0, pos0 = H * D, 8
     xs = x[..., col0:].reshape(B, L, H, D)
-    xn = xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    xn = xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-6) * w[None, None]
     c = cos[pos0:pos0 + L][None, :, None, :]
     s = sin[pos0:pos0 + L][None, :, None, :]
     xr = torch.stack([-xn[..., 1::2], xn[..., 0::2]], dim=-1).flatten(-2)

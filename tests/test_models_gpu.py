@@ -104,3 +104,60 @@ def test_omgsr_s_pipeline(h, w, tile, overlap):
         got, secs = pipe(x.to(DEV), ehs.to(DEV), tile, overlap)
     assert got.shape == ref.shape and secs > 0 and got.abs().max() <= 1.0
     _report(f"OMGSR-S {h}x{w} tile {tile}", got, ref, 3e-2)
+
+
+SMALL_FLUX = dict(num_layers=2, num_single_layers=3, num_attention_heads=2, attention_head_dim=128, joint_attention_dim=64,
+                  pooled_projection_dim=32, in_channels=64)
+SMALL_FLUX_VAE = dict(SMALL_VAE, latent_channels=16, use_quant_conv=False, use_post_quant_conv=False, scaling_factor=0.3611, shift_factor=0.1159)
+
+
+def _flux_inputs(B, h, w, Lc, seed):
+    from oracle.pipeline_ref import prepare_latent_image_ids
+    g = torch.Generator().manual_seed(seed)
+    pe = torch.randn(1, Lc, 64, generator=g).to(torch.bfloat16).float()
+    pooled = torch.randn(1, 32, generator=g).to(torch.bfloat16).float()
+    return pe, pooled, torch.zeros(Lc, 3), prepare_latent_image_ids(h // 2, w // 2)
+
+
+def test_flux_transformer_forward():
+    from omgsr_amd.diffusers_api import FluxTransformer2DModel
+    from oracle import diffusers_ref as R
+    p, o = _pair(FluxTransformer2DModel, R.FluxTransformer2DModel, SMALL_FLUX, 21)
+    B, h, w, Lc = 2, 16, 24, 40
+    pe, pooled, tids, iids = _flux_inputs(B, h, w, Lc, 22)
+    x = torch.randn(B, (h // 2) * (w // 2), 64, generator=torch.Generator().manual_seed(23)).to(torch.bfloat16).float()
+    t = torch.tensor([0.5051124691963196])
+    gd = torch.full((B,), 1.0)
+    with torch.no_grad():
+        ref = o(hidden_states=x, timestep=t, guidance=gd, pooled_projections=pooled, encoder_hidden_states=pe,
+                txt_ids=tids, img_ids=iids, return_dict=False)[0]
+        got = p(hidden_states=x.to(DEV).to(torch.bfloat16), timestep=t.to(DEV), guidance=gd.to(DEV).to(torch.bfloat16),
+                pooled_projections=pooled.to(DEV).to(torch.bfloat16), encoder_hidden_states=pe.to(DEV).to(torch.bfloat16),
+                txt_ids=tids.to(DEV).to(torch.bfloat16), img_ids=iids.to(DEV).to(torch.bfloat16), return_dict=False)[0]
+    assert got.dtype == torch.bfloat16 and got.shape == ref.shape
+    _report("flux velocity", got, ref, 2e-2)
+
+
+@pytest.mark.parametrize("h,w,tile,overlap", [(16, 16, 16, 8), (24, 16, 16, 8)])
+def test_omgsr_f_pipeline(h, w, tile, overlap):
+    from omgsr_amd.diffusers_api import AutoencoderKL, FluxTransformer2DModel
+    from omgsr_amd.pipelines.omgsr_f import OMGSR_F_Infer
+    from omgsr_amd.testing import synthetic_lq
+    from oracle import diffusers_ref as R
+    from oracle.pipeline_ref import OmgsrFRef
+    pv, ov = _pair(AutoencoderKL, R.AutoencoderKL, SMALL_FLUX_VAE, 31)
+    pf, of = _pair(FluxTransformer2DModel, R.FluxTransformer2DModel, SMALL_FLUX, 32)
+    B, Lc = 2, 24
+    pe, pooled, tids, iids = _flux_inputs(B, tile, tile, Lc, 33)       # ids cover one (tile x tile) latent
+    x = synthetic_lq(B, h * 8, w * 8)
+    eps = torch.randn(B, 16, h, w, generator=torch.Generator().manual_seed(34))
+    ov.posterior_noise = eps
+    pv.posterior_noise = eps
+    ref_pipe = OmgsrFRef(ov, of, 244, 1.0)
+    pipe = OMGSR_F_Infer(None, None, DEV, torch.bfloat16, 244, 1.0, vae=pv, flux_transformer=pf)
+    assert pipe.t_curr == ref_pipe.t_curr and pipe.t_prev == 0.0
+    with torch.no_grad():
+        ref = ref_pipe(x, pe, pooled, tids, iids, tile, overlap)
+        got, secs = pipe(x.to(DEV), pe.to(DEV), pooled.to(DEV), tids.to(DEV), iids.to(DEV), tile, overlap)
+    assert got.shape == ref.shape and secs > 0
+    _report(f"OMGSR-F {h}x{w} tile {tile}", got, ref, 3e-2)
