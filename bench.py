@@ -70,6 +70,29 @@ def build_s(device, rank, world):
     return pipe, moved
 
 
+def build_f(device, rank, world):
+    """OMGSR-F: FLUX.1-dev-shaped DiT (11.9 B params) + FLUX VAE, seeded random weights generated on the GPU."""
+    from omgsr_amd import dist as D
+    from omgsr_amd.diffusers_api import AutoencoderKL, FLUX_VAE_CONFIG, FluxTransformer2DModel
+    from omgsr_amd.pipelines.omgsr_f import OMGSR_F_Infer
+    from omgsr_amd.testing import seeded_init_, seeded_init_device_
+    with torch.device("meta"):
+        flux = FluxTransformer2DModel()
+    flux = flux.to_empty(device=device).to(torch.bfloat16)
+    if rank == 0 or world == 1:
+        vae = seeded_init_(AutoencoderKL(**FLUX_VAE_CONFIG), 303)
+        seeded_init_device_(flux, 404)
+    else:
+        with torch.device("meta"):
+            vae = AutoencoderKL(**FLUX_VAE_CONFIG)
+        vae = vae.to_empty(device=device).to(torch.bfloat16)
+    pipe = OMGSR_F_Infer(None, None, device, torch.bfloat16, 244, 1.0, vae=vae, flux_transformer=flux)
+    moved = D.broadcast_module_(pipe.vae) + D.broadcast_module_(pipe.flux_transformer)
+    if not (D.replicas_identical(pipe.vae) and D.replicas_identical(pipe.flux_transformer)):
+        raise RuntimeError("weight replicas differ after broadcast")
+    return pipe, moved
+
+
 def collect_roofline(lib_mod):
     from omgsr_amd._lib import TimingEntry
     lib = lib_mod.load()
@@ -111,25 +134,33 @@ def main():
 
     family, side, dbatch, tile, overlap, tflop_per_img = WORKLOADS[args.workload]
     B = args.batch or dbatch
-    if family != "S":
-        raise SystemExit(f"workload {args.workload}: OMGSR-F bench lands with the Flux kernels (see DESIGN.md)")
-
     t0 = time.time()
-    pipe, moved = build_s(device, rank, world)
+    pipe, moved = (build_s if family == "S" else build_f)(device, rank, world)
     if args.tiled_vae:
         pipe._init_tiled_vae(encoder_tile_size=256, decoder_tile_size=64)
     build_s_secs = time.time() - t0
 
     # synthetic inputs, resident in HBM before the timed region (per-rank seed: every rank has its own images)
     g = torch.Generator().manual_seed(4321)
-    prompt = torch.randn(1, 77, 1024, generator=g).to(torch.bfloat16).to(device)
     lq_cpu = synthetic_lq(B, side, side, seed=1234 + rank)
     lq = ops_nhwc(lq_cpu.to(device))
-    eps_cpu = torch.randn(B, 4, side // 8, side // 8, generator=torch.Generator().manual_seed(99 + rank))
+    lat_c = 4 if family == "S" else 16
+    eps_cpu = torch.randn(B, lat_c, side // 8, side // 8, generator=torch.Generator().manual_seed(99 + rank))
     pipe.vae.posterior_noise = eps_cpu.to(device)
+    if family == "S":
+        prompt = torch.randn(1, 77, 1024, generator=g).to(torch.bfloat16).to(device)
 
-    def step():
-        return pipe.sr_nhwc(lq, prompt, tile, overlap)
+        def step():
+            return pipe.sr_nhwc(lq, prompt, tile, overlap)
+    else:
+        from omgsr_amd.pipelines.omgsr_f import prepare_latent_image_ids
+        prompt = torch.randn(1, 512, 4096, generator=g).to(torch.bfloat16).to(device)
+        pooled = torch.randn(1, 768, generator=g).to(torch.bfloat16).to(device)
+        text_ids = torch.zeros(512, 3, device=device, dtype=torch.bfloat16)
+        image_ids = prepare_latent_image_ids(tile // 2, tile // 2, device, torch.bfloat16)
+
+        def step():
+            return pipe.sr_nhwc(lq, prompt, pooled, text_ids, image_ids, tile, overlap)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -168,7 +199,7 @@ def main():
         extra["pipeline_frac_of_mfma_peak"] = round(tflop_per_img * B * args.steps / elapsed / PEAK_BF16_DENSE_TFLOPS, 4) if world == 1 else None
 
     cpu_baseline, parity = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and family == "S":
         cpu_baseline, parity = cpu_leg(lq_cpu[:1], eps_cpu[:1], prompt.float().cpu(), out[:1], tile, overlap, side)
 
     if rank == 0:
@@ -176,9 +207,9 @@ def main():
             "metric": "SR images/sec", "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"OMGSR-{family} {side // 4}->{side}, batch={B}/GPU, bf16, seeded random weights at SD2.1-base shapes"
+            "config": {"workload": f"OMGSR-{family} {side // 4}->{side}, batch={B}/GPU, bf16, seeded random weights at {'SD2.1-base' if family == 'S' else 'FLUX.1-dev'} shapes"
                                    + (" , tiled VAE" if args.tiled_vae else ""),
-                       "global_batch": B * world, "latent_tile": tile, "tile_overlap": overlap, "mid_timestep": 273,
+                       "global_batch": B * world, "latent_tile": tile, "tile_overlap": overlap, "mid_timestep": 273 if family == "S" else 244,
                        "parallelism": f"dp{world} (images sharded, RCCL weight broadcast {moved >> 20} MiB)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
             "setup_s": round(build_s_secs, 1), **extra,

@@ -25,7 +25,7 @@
 namespace {
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_kernel(const omgsr_attn_args p, const int ntiles) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, const int ntiles) {
     constexpr int KP = 2 * D + 16;
     constexpr int VP = 136;
     constexpr int K_BYTES = 64 * KP, V_BYTES = D * VP;

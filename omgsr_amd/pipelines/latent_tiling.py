@@ -51,18 +51,24 @@ def tile_grid(h: int, w: int, tile_size: int, tile_overlap: int) -> Tuple[int, L
 
 
 def tiled_denoise(latent_nhwc: torch.Tensor, channels: int, tile_size: int, tile_overlap: int,
-                  denoise: Callable[[torch.Tensor], torch.Tensor]) -> torch.Tensor:
-    """latent_nhwc [B,h,w,C8] bf16; `denoise(tile [B,t,t,C8]) -> [B,t,t,>=channels]` is called once per tile
-    (the reference's "batching" never batches, SURVEY C-4). Returns the Gaussian-blended prediction
-    [B,h,w,C8] bf16 (channels >= `channels` zero)."""
+                  denoise: Callable[[torch.Tensor], torch.Tensor], tiles_per_call: int = 16) -> torch.Tensor:
+    """latent_nhwc [B,h,w,C8] bf16; `denoise(tiles [n*B,t,t,C8]) -> [n*B,t,t,>=channels]`. Returns the
+    Gaussian-blended prediction [B,h,w,C8] bf16 (channels >= `channels` zero).
+
+    The reference runs one denoiser call per tile (its "batching" never batches, SURVEY C-4). Tiles are
+    independent samples, so here up to `tiles_per_call` tiles ride in ONE call along the batch axis — the
+    result per tile is bit-identical (tests/test_models_gpu.py::test_unet_forward checks batch == B x batch-1)
+    while the low-resolution UNet layers see 9x more rows and fill the 256 CUs. Stitch order is unchanged."""
     B, h, w, ld = latent_nhwc.shape
     ts, offsets = tile_grid(h, w, tile_size, tile_overlap)
     wts = torch.tensor(gaussian_weights(ts, ts), dtype=torch.float32, device=latent_nhwc.device)
     acc = torch.zeros((B, h, w, channels), device=latent_nhwc.device, dtype=torch.float32)
     wsum = torch.zeros((1, h, w, 1), device=latent_nhwc.device, dtype=torch.float32)
-    for (oy, ox) in offsets:
-        tile = ops.crop_nhwc(latent_nhwc, oy, ox, ts, ts)
-        pred = denoise(tile)
-        ops.tile_accumulate(pred, wts, acc, oy, ox)
-        ops.tile_accumulate(None, wts, wsum, oy, ox)
+    for i0 in range(0, len(offsets), max(1, tiles_per_call)):
+        group = offsets[i0:i0 + max(1, tiles_per_call)]
+        tiles = [ops.crop_nhwc(latent_nhwc, oy, ox, ts, ts) for (oy, ox) in group]
+        preds = denoise(torch.cat(tiles, 0) if len(tiles) > 1 else tiles[0])
+        for j, (oy, ox) in enumerate(group):
+            ops.tile_accumulate(preds[j * B:(j + 1) * B].contiguous(), wts, acc, oy, ox)
+            ops.tile_accumulate(None, wts, wsum, oy, ox)
     return ops.tile_normalise(acc, wsum, ld=ld)
