@@ -162,6 +162,11 @@ int omgsr_tile_normalise(const float* acc, const float* wsum, void* out, int32_t
 /* bf16 window copy: dst[n,y,x,:] = src[n,y0+y,x0+x,:] */
 int omgsr_crop_nhwc(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t y0,
                     int32_t x0, int32_t th, int32_t tw, void* stream);
+/* bf16 window paste: dst[n, dy0+y, dx0+x, :] = src[n, sy0+y, sx0+x, :] for y < th, x < tw (tiled-VAE
+ * crop_valid_region + result[...] = tile, infer/vaehook.py:416-427,805). */
+int omgsr_paste_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t sH, int32_t sW, int32_t sy0,
+                     int32_t sx0, int32_t dH, int32_t dW, int32_t dy0, int32_t dx0, int32_t th, int32_t tw,
+                     void* stream);
 /* Flux 2x2 pack / unpack between NHWC [N,H,W,C(ld)] and tokens [N,(H/2)(W/2),4C] with channel
  * order c*4 + dy*2 + dx (infer/omgsr_f_infer_model.py:21-41). dir 0 = pack, 1 = unpack. */
 int omgsr_flux_pack(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ld,

@@ -76,6 +76,7 @@ SIGNATURES = {
     "omgsr_tile_accumulate": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "omgsr_tile_normalise": (C.c_int, [_P, _P, _P, _I, _L, _I, _I, _P]),
     "omgsr_crop_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "omgsr_paste_nhwc": (C.c_int, [_P, _P] + [_I] * 12 + [_P]),
     "omgsr_flux_pack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "omgsr_timing_enable": (C.c_int, [C.c_int]),
     "omgsr_timing_reset": (C.c_int, []),

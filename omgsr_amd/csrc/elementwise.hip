@@ -137,6 +137,20 @@ __global__ void crop_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__
         *reinterpret_cast<const u32x4_t*>(src + (((int64_t)n * H + y0 + y) * W + x0 + x) * C + g * 8);
 }
 
+__global__ void paste_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int C, int sH, int sW, int sy0, int sx0,
+                             int dH, int dW, int dy0, int dx0, int th, int tw) {
+    const int ng = C >> 3;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * th * tw * ng) return;
+    const int g = (int)(i % ng);
+    int64_t r = i / ng;
+    const int x = (int)(r % tw); r /= tw;
+    const int y = (int)(r % th);
+    const int n = (int)(r / th);
+    *reinterpret_cast<u32x4_t*>(dst + (((int64_t)n * dH + dy0 + y) * dW + dx0 + x) * C + g * 8) =
+        *reinterpret_cast<const u32x4_t*>(src + (((int64_t)n * sH + sy0 + y) * sW + sx0 + x) * C + g * 8);
+}
+
 // Flux 2x2 pack: tokens[n, (y/2)*(W/2) + x/2, c*4 + (y&1)*2 + (x&1)] <-> nhwc[n, y, x, c]
 __global__ void flux_pack_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int H, int W, int C, int ld, int dir) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,6 +269,18 @@ extern "C" int omgsr_crop_nhwc(const void* src, void* dst, int32_t N, int32_t H,
     const int64_t total = (int64_t)N * th * tw * (C >> 3);
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 32.0 * total, st);
     hipLaunchKernelGGL(crop_kernel, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, H, W, C, y0, x0, th, tw);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_paste_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t sH, int32_t sW, int32_t sy0, int32_t sx0,
+                                int32_t dH, int32_t dW, int32_t dy0, int32_t dx0, int32_t th, int32_t tw, void* stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || th <= 0 || tw <= 0) return OMGSR_E_BADARG;
+    if ((C & 7) || sy0 < 0 || sx0 < 0 || dy0 < 0 || dx0 < 0 || sy0 + th > sH || sx0 + tw > sW || dy0 + th > dH || dx0 + tw > dW)
+        return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)N * th * tw * (C >> 3);
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 32.0 * total, st);
+    hipLaunchKernelGGL(paste_kernel, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, C, sH, sW, sy0, sx0, dH, dW, dy0, dx0, th, tw);
     return (int)hipGetLastError();
 }
 

@@ -89,9 +89,14 @@ class VaeAttention(nn.Module):
         self.norm_cross = None
 
     def nhwc(self, x):
-        N, H, W, Cc = x.shape
+        return self.attend(self.group_norm.nhwc(x), x)
+
+    def attend(self, g, residual):
+        """g: GroupNorm'ed input [N,H,W,C] (the tiled VAE supplies cross-tile statistics); returns residual + attn."""
+        N, H, W, Cc = g.shape
         L = H * W
-        g = self.group_norm.nhwc(x).reshape(N, L, Cc)
+        x = residual
+        g = g.reshape(N, L, Cc)
         q = self.to_q.nhwc(g)
         Lp = ops._round_up(L, 128)
         k = self.to_k.nhwc(g)
@@ -178,7 +183,9 @@ class Encoder(nn.Module):
 
     def forward(self, x):  # NCHW in/out (diffusers convention)
         y = self.run_nhwc(ops.nchw_to_nhwc(x.contiguous(), 8))
-        return ops.nhwc_to_nchw(y, channels=self.conv_out.out_channels, dtype=_io_dtype(x))
+        # the reference's VAEHook returns an fp32 buffer whatever the net dtype (infer/vaehook.py:804, SURVEY C-10)
+        dt = torch.float32 if getattr(self, "_tile_hook", None) is not None else _io_dtype(x)
+        return ops.nhwc_to_nchw(y, channels=self.conv_out.out_channels, dtype=dt)
 
 
 class Decoder(nn.Module):
@@ -211,7 +218,8 @@ class Decoder(nn.Module):
 
     def forward(self, z):
         y = self.run_nhwc(ops.nchw_to_nhwc(z.contiguous(), ops._round_up(z.shape[1], 8)))
-        return ops.nhwc_to_nchw(y, channels=self.conv_out.out_channels, dtype=_io_dtype(z))
+        dt = torch.float32 if getattr(self, "_tile_hook", None) is not None else _io_dtype(z)
+        return ops.nhwc_to_nchw(y, channels=self.conv_out.out_channels, dtype=dt)
 
 
 def _io_dtype(x):

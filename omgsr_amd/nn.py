@@ -76,7 +76,8 @@ class GroupNorm(nn.GroupNorm, _Packed):
     def stats(self, x):
         return ops.group_norm_stats(x, self.num_groups, self.eps)
 
-    def apply(self, x, mean, rstd, act=ops.ACT_NONE):
+    def apply_stats(self, x, mean, rstd, act=ops.ACT_NONE):
+        """Normalise with externally supplied per-(n, group) statistics (tiled VAE)."""
         g, b = self._affine()
         return ops.group_norm_apply(x, mean, rstd, g, b, self.num_groups, act)
 

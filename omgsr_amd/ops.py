@@ -455,6 +455,16 @@ def crop_nhwc(x: torch.Tensor, y0: int, x0: int, th: int, tw: int) -> torch.Tens
     return out
 
 
+def paste_nhwc(src: torch.Tensor, dst: torch.Tensor, sy0: int, sx0: int, dy0: int, dx0: int, th: int, tw: int) -> None:
+    """dst[:, dy0:dy0+th, dx0:dx0+tw, :] = src[:, sy0:sy0+th, sx0:sx0+tw, :] (bf16 NHWC, same N and C)."""
+    _req(src, torch.bfloat16, "src"); _req(dst, torch.bfloat16, "dst")
+    N, sH, sW, Cc = src.shape
+    if dst.shape[0] != N or dst.shape[3] != Cc:
+        raise ValueError("paste_nhwc: batch/channel mismatch")
+    check(_lib.load().omgsr_paste_nhwc(src.data_ptr(), dst.data_ptr(), N, Cc, sH, sW, sy0, sx0, dst.shape[1], dst.shape[2],
+                                       dy0, dx0, th, tw, _stream()), "omgsr_paste_nhwc")
+
+
 def flux_pack(x: torch.Tensor, channels: int) -> torch.Tensor:
     """NHWC [N,H,W,ld] (first `channels`) -> tokens [N, (H/2)(W/2), 4*channels]."""
     _req(x, torch.bfloat16, "x")

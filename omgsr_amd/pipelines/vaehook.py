@@ -1,0 +1,199 @@
+"""Tiled VAE on MI355X — counterpart of infer/vaehook.py::VAEHook (same constructor arguments, same
+`__call__` dispatch, same tile geometry and cross-tile GroupNorm semantics), re-designed for one GPU
+with 288 GB of HBM:
+
+  * the reference parks every tile but one on the CPU between its 22 (encoder) / 30 (decoder) GroupNorm
+    barriers and walks a Python task queue per tile (PCIe-bound); here ALL tiles stay resident in HBM, tiles
+    of equal shape are stacked along the batch axis, and each layer runs as ONE kernel launch per shape group
+  * at every GroupNorm the per-tile (mean, biased var) come from the statistics kernel, are merged per image
+    with pixel-count weights exactly like GroupNormParam.summary() (a weighted mean of variances, NOT the
+    pooled variance), and the apply(+SiLU) kernel runs with the externally supplied statistics (eps 1e-6)
+  * mid-block attention stays tile-local, valid regions are cropped and pasted without blending
+Fast mode (fast_encoder / fast_decoder) estimates every GroupNorm's statistics once on a nearest-exact
+down-sampled, re-standardised copy of the whole input, then all tiles use those fixed statistics.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def get_best_tile_size(lowerbound: int, upperbound: int) -> int:
+    divider = 32
+    while divider >= 2:
+        rem = lowerbound % divider
+        if rem == 0:
+            return lowerbound
+        cand = lowerbound - rem + divider
+        if cand <= upperbound:
+            return cand
+        divider //= 2
+    return lowerbound
+
+
+def split_tiles(h: int, w: int, tile_size: int, pad: int, is_decoder: bool) -> Tuple[List[List[int]], List[List[int]]]:
+    """(input bboxes, output bboxes), each [x1, x2, y1, y2]; behaviour of VAEHook.split_tiles (infer/vaehook.py:577-634)."""
+    nh = max(math.ceil((h - 2 * pad) / tile_size), 1)
+    nw = max(math.ceil((w - 2 * pad) / tile_size), 1)
+    th = get_best_tile_size(math.ceil((h - 2 * pad) / nh), tile_size)
+    tw = get_best_tile_size(math.ceil((w - 2 * pad) / nw), tile_size)
+    ins, outs = [], []
+    for i in range(nh):
+        for j in range(nw):
+            ib = [pad + j * tw, min(pad + (j + 1) * tw, w), pad + i * th, min(pad + (i + 1) * th, h)]
+            ob = [ib[0] if ib[0] > pad else 0, ib[1] if ib[1] < w - pad else w,
+                  ib[2] if ib[2] > pad else 0, ib[3] if ib[3] < h - pad else h]
+            outs.append([v * 8 if is_decoder else v // 8 for v in ob])
+            ins.append([max(0, ib[0] - pad), min(w, ib[1] + pad), max(0, ib[2] - pad), min(h, ib[3] + pad)])
+    return ins, outs
+
+
+class VAEHook:
+    def __init__(self, net, tile_size, is_decoder, fast_decoder, fast_encoder, color_fix, to_gpu=False):
+        self.net = net                      # omgsr_amd Encoder | Decoder
+        self.tile_size = tile_size
+        self.is_decoder = is_decoder
+        self.fast_mode = (fast_encoder and not is_decoder) or (fast_decoder and is_decoder)
+        self.color_fix = color_fix and not is_decoder
+        self.to_gpu = to_gpu
+        self.pad = 11 if is_decoder else 32
+
+    # ---- op list (order of build_task_queue, infer/vaehook.py:332-359) ----------------------
+    def _ops(self):
+        net, dec = self.net, self.is_decoder
+        seq = [("f", lambda x: net.conv_in.nhwc(x))]
+
+        def resblock(b):
+            seq.append(("res_push", (lambda x, b=b: b.conv_shortcut.nhwc(x, pad=0)) if b.conv_shortcut is not None else None))
+            seq.append(("gn", b.norm1, ops.ACT_SILU))
+            seq.append(("f", lambda x, b=b: b.conv1.nhwc(x)))
+            seq.append(("gn", b.norm2, ops.ACT_SILU))
+            seq.append(("conv_res", b.conv2))                      # conv2 + residual in the GEMM epilogue
+
+        def attn(a):
+            seq.append(("res_push", None))
+            seq.append(("gn", a.group_norm, ops.ACT_NONE))
+            seq.append(("attn_res", a))
+
+        def mid():
+            resblock(net.mid_block.resnets[0]); attn(net.mid_block.attentions[0]); resblock(net.mid_block.resnets[1])
+
+        if dec:
+            mid()
+            blocks = net.up_blocks
+        else:
+            blocks = net.down_blocks
+        for i, blk in enumerate(blocks):
+            for r in blk.resnets:
+                resblock(r)
+            if i != len(blocks) - 1:
+                samp = blk.upsamplers[0] if dec else blk.downsamplers[0]
+                seq.append(("f", lambda x, s=samp: s.nhwc(x)))
+        if not dec:
+            mid()
+        seq.append(("gn", net.conv_norm_out, ops.ACT_SILU))
+        seq.append(("f", lambda x: net.conv_out.nhwc(x)))
+        return seq
+
+    # ---- public entry (NHWC bf16) -------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        N, H, W, _ = x.shape
+        if max(H, W) <= self.pad * 2 + self.tile_size:
+            return self.net.nhwc(x)            # "[Tiled VAE]: the input size is tiny and unnecessary to tile."
+        return self.vae_tile_forward(x)
+
+    def _run(self, seq, groups: Dict[tuple, torch.Tensor], counts: Dict[tuple, int], N: int, fixed=None, record=None):
+        """Layer-synchronous execution over shape groups. groups[shape] = [T_g*N, h, w, C] (tile-major)."""
+        res: Dict[tuple, list] = {k: [] for k in groups}
+        gi = 0
+        for op in seq:
+            kind = op[0]
+            if kind == "gn":
+                norm, act = op[1], op[2]
+                G = norm.num_groups
+                if fixed is not None:
+                    mean, var = fixed[gi]
+                else:
+                    # per-tile statistics, merged per image with pixel-count weights (GroupNormParam.summary)
+                    tot_w, mean, var = 0.0, None, None
+                    stats = {}
+                    for k, t in groups.items():
+                        m, _, v = ops.group_norm_stats(t, G, norm.eps)
+                        stats[k] = (m.view(counts[k], N, G), v.view(counts[k], N, G))
+                        tot_w += counts[k] * t.shape[1] * t.shape[2]
+                    for k, (m, v) in stats.items():
+                        wgt = groups[k].shape[1] * groups[k].shape[2] / tot_w
+                        mean = m.sum(0) * wgt if mean is None else mean + m.sum(0) * wgt
+                        var = v.sum(0) * wgt if var is None else var + v.sum(0) * wgt
+                if record is not None:
+                    record.append((mean, var))
+                gi += 1
+                rstd = torch.rsqrt(var + 1e-6)                     # custom_group_norm: eps 1e-6
+                for k in groups:
+                    mm = mean[None].expand(counts[k], N, G).reshape(-1, G).contiguous()
+                    rr = rstd[None].expand(counts[k], N, G).reshape(-1, G).contiguous()
+                    groups[k] = norm.apply_stats(groups[k], mm, rr, act)
+            elif kind == "f":
+                for k in groups:
+                    groups[k] = op[1](groups[k])
+            elif kind == "res_push":
+                for k in groups:
+                    res[k].append(op[1](groups[k]) if op[1] is not None else groups[k])
+            elif kind == "conv_res":
+                for k in groups:
+                    groups[k] = op[1].nhwc(groups[k], residual=res[k].pop())
+            elif kind == "attn_res":
+                for k in groups:
+                    groups[k] = op[1].attend(groups[k], residual=res[k].pop())
+        return groups
+
+    @torch.no_grad()
+    def vae_tile_forward(self, x: torch.Tensor) -> torch.Tensor:
+        N, H, W, _ = x.shape
+        ins, outs = split_tiles(H, W, self.tile_size, self.pad, self.is_decoder)
+        seq = self._ops()
+        fixed = None
+        if self.fast_mode:
+            fixed = self._estimate(x, seq)
+        # stack tiles of equal shape along the batch axis (tile-major)
+        order: Dict[tuple, List[int]] = {}
+        for i, b in enumerate(ins):
+            order.setdefault((b[3] - b[2], b[1] - b[0]), []).append(i)
+        groups = {k: torch.cat([ops.crop_nhwc(x, ins[i][2], ins[i][0], k[0], k[1]) for i in idx], 0) for k, idx in order.items()}
+        counts = {k: len(idx) for k, idx in order.items()}
+        groups = self._run(seq, groups, counts, N, fixed=fixed)
+        Ho, Wo = (H * 8, W * 8) if self.is_decoder else (H // 8, W // 8)
+        Cout = next(iter(groups.values())).shape[-1]
+        result = torch.zeros((N, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16)
+        for k, idx in order.items():
+            t = groups[k]
+            for j, i in enumerate(idx):
+                ib, ob = ins[i], outs[i]
+                pb = [v * 8 if self.is_decoder else v // 8 for v in ib]
+                mg = [ob[q] - pb[q] for q in range(4)]                 # crop_valid_region
+                th, tw = ob[3] - ob[2], ob[1] - ob[0]
+                ops.paste_nhwc(t[j * N:(j + 1) * N], result, mg[2], mg[0], ob[2], ob[0], th, tw)
+        return result
+
+    def _estimate(self, x: torch.Tensor, seq):
+        """Fast mode (infer/vaehook.py:714-735, 637-677): statistics of every GroupNorm from one pass over a
+        nearest-exact down-sampled copy of the input whose per-channel mean/std are restored. The resampling and
+        re-standardisation act on one small tensor and use torch (plumbing); the network pass uses the HIP kernels."""
+        N, H, W, Cp = x.shape
+        scale = self.tile_size / max(H, W)
+        xc = x.permute(0, 3, 1, 2).float()
+        small = F.interpolate(xc, scale_factor=scale, mode="nearest-exact")
+        std_o, mean_o = torch.std_mean(xc, dim=[0, 2, 3], keepdim=True)
+        std_n, mean_n = torch.std_mean(small, dim=[0, 2, 3], keepdim=True)
+        std_n = torch.where(std_n == 0, torch.ones_like(std_n), std_n)      # zero-padded channels
+        small = ((small - mean_n) / std_n * std_o + mean_o).clamp_(min=float(xc.min()), max=float(xc.max()))
+        small = small.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+        record: list = []
+        self._run(seq, {(small.shape[1], small.shape[2]): small}, {(small.shape[1], small.shape[2]): 1}, N, record=record)
+        return record

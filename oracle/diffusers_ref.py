@@ -134,6 +134,23 @@ class Attention(nn.Module):
             self.add_q_proj = None
         self.to_out = None if pre_only else nn.ModuleList([nn.Linear(inner, query_dim, bias=True), nn.Identity()])
 
+    # --- the diffusers Attention helper surface that infer/vaehook.py:137-171 calls op by op ---------
+    norm_cross = None
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size):
+        return attention_mask            # the hook only ever passes None
+
+    def head_to_batch_dim(self, t):
+        B, L, Cc = t.shape
+        return t.reshape(B, L, self.heads, Cc // self.heads).permute(0, 2, 1, 3).reshape(B * self.heads, L, Cc // self.heads)
+
+    def batch_to_head_dim(self, t):
+        BH, L, d = t.shape
+        return t.reshape(BH // self.heads, self.heads, L, d).permute(0, 2, 1, 3).reshape(BH // self.heads, L, d * self.heads)
+
+    def get_attention_scores(self, query, key, attention_mask=None):
+        return torch.softmax(torch.bmm(query, key.transpose(-1, -2)).float() * self.scale, dim=-1).to(query.dtype)
+
     def _heads(self, x):
         B, L, _ = x.shape
         return x.view(B, L, self.heads, self.dim_head).transpose(1, 2)

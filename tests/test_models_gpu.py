@@ -161,3 +161,70 @@ def test_omgsr_f_pipeline(h, w, tile, overlap):
         got, secs = pipe(x.to(DEV), pe.to(DEV), pooled.to(DEV), tids.to(DEV), iids.to(DEV), tile, overlap)
     assert got.shape == ref.shape and secs > 0
     _report(f"OMGSR-F {h}x{w} tile {tile}", got, ref, 3e-2)
+
+
+HOOK_VAE = dict(block_out_channels=[32, 32, 64, 64], layers_per_block=2, norm_num_groups=32)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_tiled_vae_hook(fast):
+    """Product VAEHook (HBM-resident, shape-batched tiles) vs the oracle restatement of the reference's
+    infer/vaehook.py algorithm (itself pinned to the reference by tests/test_vaehook_golden.py)."""
+    from omgsr_amd.diffusers_api import AutoencoderKL
+    from omgsr_amd.pipelines.vaehook import VAEHook
+    from oracle import diffusers_ref as R
+    from oracle import vaehook_ref as V
+    p, o = _pair(AutoencoderKL, R.AutoencoderKL, HOOK_VAE, 9)
+    g = torch.Generator().manual_seed(41)
+    img = torch.randn(2, 3, 160, 224, generator=g).clamp(-2, 2).to(torch.bfloat16).float()
+    z = torch.randn(2, 4, 28, 36, generator=g).to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref_e = V.tiled_forward(o.encoder, img, 64, is_decoder=False, fast=fast)
+        ref_d = V.tiled_forward(o.decoder, z, 12, is_decoder=True, fast=fast)
+        p.encoder._tile_hook = VAEHook(p.encoder, 64, is_decoder=False, fast_decoder=fast, fast_encoder=fast, color_fix=False)
+        p.decoder._tile_hook = VAEHook(p.decoder, 12, is_decoder=True, fast_decoder=fast, fast_encoder=fast, color_fix=False)
+        got_e = p.encoder(img.to(DEV))
+        got_d = p.decoder(z.to(DEV))
+    assert got_e.dtype == torch.float32 and got_d.dtype == torch.float32 and got_e.shape == ref_e.shape and got_d.shape == ref_d.shape
+    tag = "fast" if fast else "exact"
+    _report(f"tiled encoder ({tag})", got_e, ref_e, 3e-2)
+    _report(f"tiled decoder ({tag})", got_d, ref_d, 3e-2)
+    # tiled != untiled by construction (tile-local attention, merged statistics): make sure we follow the TILED algorithm
+    untiled = o.decoder(z)
+    from omgsr_amd.testing import rel_l2
+    assert rel_l2(got_d, ref_d) < 0.5 * rel_l2(untiled, ref_d)
+
+
+def test_omgsr_s_with_tiled_vae():
+    from omgsr_amd.diffusers_api import AutoencoderKL, UNet2DConditionModel
+    from omgsr_amd.pipelines.omgsr_s import OMGSR_S_Infer
+    from omgsr_amd.testing import synthetic_lq
+    from oracle import diffusers_ref as R
+    from oracle import vaehook_ref as V
+    from oracle.pipeline_ref import OmgsrSRef
+    pv, ov = _pair(AutoencoderKL, R.AutoencoderKL, HOOK_VAE, 51)
+    pu, ou = _pair(UNet2DConditionModel, R.UNet2DConditionModel, SMALL_UNET, 52)
+    g = torch.Generator().manual_seed(53)
+    x = synthetic_lq(1, 256, 256)
+    ehs = torch.randn(1, 77, 128, generator=g).to(torch.bfloat16).float()
+    eps = torch.randn(1, 4, 32, 32, generator=g)
+    ov.posterior_noise = eps
+    pv.posterior_noise = eps
+
+    class HookedVae:     # oracle VAE with the tiled encoder/decoder swapped in (what _init_tiled_vae does)
+        config = ov.config
+
+        def encode(self, im):
+            m = ov.quant_conv(V.tiled_forward(ov.encoder, im, 96, False))
+            return type("P", (), {"latent_dist": R.DiagonalGaussianDistribution(m, eps)})()
+
+        def decode(self, zz, return_dict=True):
+            return type("D", (), {"sample": V.tiled_forward(ov.decoder, ov.post_quant_conv(zz), 8, True)})()
+
+    ref_pipe = OmgsrSRef(HookedVae(), ou, R.DDPMScheduler().alphas_cumprod[273], 273)
+    pipe = OMGSR_S_Infer(None, None, 273, DEV, torch.bfloat16, vae=pv, unet=pu)
+    pipe._init_tiled_vae(encoder_tile_size=96, decoder_tile_size=8)
+    with torch.no_grad():
+        ref = ref_pipe(x, ehs, 16, 8)
+        got, _ = pipe(x.to(DEV), ehs.to(DEV), 16, 8)
+    _report("OMGSR-S 256 with tiled VAE", got, ref, 4e-2)
