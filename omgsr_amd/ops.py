@@ -245,8 +245,12 @@ def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_
     _req(b_mat, torch.bfloat16, "b")
     B, M, K = a_mat.shape
     Bb, Np, Kb = b_mat.shape
-    if Bb != B or Kb != K or Np % 128 or K % 32:
+    if Bb != B or Kb != K or K % 32:
         raise ValueError(f"bmm_nt: incompatible shapes {tuple(a_mat.shape)} x {tuple(b_mat.shape)}")
+    if Np % 128:    # reduced test configs only (the real VAE has 512 channels / 128-padded key counts)
+        bp = torch.zeros((B, _round_up(Np, 128), K), device=b_mat.device, dtype=torch.bfloat16)
+        bp[:, :Np] = b_mat
+        return bmm_nt(a_mat, bp, alpha=alpha, out_dtype=out_dtype)[:, :, :Np].contiguous()
     out = torch.empty((B, M, Np), device=a_mat.device, dtype=torch.bfloat16 if out_dtype == OUT_BF16 else torch.float32)
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate, a.residual, a.out = a_mat.data_ptr(), b_mat.data_ptr(), None, None, None, out.data_ptr()
