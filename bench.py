@@ -33,8 +33,8 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md:
 
 WORKLOADS = {
     # name: (family, image side, default batch, latent tile, overlap, algorithmic TFLOP per image [BASELINE.md §3])
-    "s512": ("S", 512, 8, 64, 32, 4.436),
-    "s1024": ("S", 1024, 4, 64, 32, 22.59),
+    "s512": ("S", 512, 8, 64, 32, 4.436),          # BASELINE.json configs[1]
+    "s1024": ("S", 1024, 4, 64, 32, 22.59),        # configs[2]: 1k output, tiled VAE (encoder tile 256, decoder tile 64)
     "f1024": ("F", 1024, 1, 128, 64, 89.8),
 }
 
@@ -44,11 +44,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=os.environ.get("OMGSR_BENCH_WORKLOAD", "s512"), choices=sorted(WORKLOADS))
+    # default = the first "1k out" configuration of BASELINE.json's metric that fits one GPU (configs[2])
+    ap.add_argument("--workload", default=os.environ.get("OMGSR_BENCH_WORKLOAD", "s1024"), choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--tiled-vae", action="store_true", help="OMGSR-S 1024: run the VAE through the tiled VAEHook (config 3)")
+    ap.add_argument("--no-tiled-vae", action="store_true", help="s1024 only: run the VAE untiled (the reference's shipped default)")
     return ap.parse_args()
 
 
@@ -136,7 +137,8 @@ def main():
     B = args.batch or dbatch
     t0 = time.time()
     pipe, moved = (build_s if family == "S" else build_f)(device, rank, world)
-    if args.tiled_vae:
+    tiled_vae = args.workload == "s1024" and not args.no_tiled_vae
+    if tiled_vae:
         pipe._init_tiled_vae(encoder_tile_size=256, decoder_tile_size=64)
     build_s_secs = time.time() - t0
 
@@ -200,7 +202,7 @@ def main():
 
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and family == "S":
-        cpu_baseline, parity = cpu_leg(lq_cpu[:1], eps_cpu[:1], prompt.float().cpu(), out[:1], tile, overlap, side)
+        cpu_baseline, parity = cpu_leg(lq_cpu[:1], eps_cpu[:1], prompt.float().cpu(), out[:1], tile, overlap, side, tiled_vae)
 
     if rank == 0:
         line = {
@@ -208,7 +210,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"OMGSR-{family} {side // 4}->{side}, batch={B}/GPU, bf16, seeded random weights at {'SD2.1-base' if family == 'S' else 'FLUX.1-dev'} shapes"
-                                   + (" , tiled VAE" if args.tiled_vae else ""),
+                                   + (", tiled VAE (VAEHook enc 256 / dec 64)" if tiled_vae else ""),
                        "global_batch": B * world, "latent_tile": tile, "tile_overlap": overlap, "mid_timestep": 273 if family == "S" else 244,
                        "parallelism": f"dp{world} (images sharded, RCCL weight broadcast {moved >> 20} MiB)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
@@ -222,19 +224,19 @@ def ops_nhwc(x_nchw):
     return ops.nchw_to_nhwc(x_nchw.contiguous(), 8)
 
 
-def cpu_leg(lq1, eps1, prompt, hip_out_nhwc, tile, overlap, side):
+def cpu_leg(lq1, eps1, prompt, hip_out_nhwc, tile, overlap, side, tiled_vae=False):
     """fp32 CPU oracle on ONE image of the workload (bounded sample), and parity of the HIP output vs it."""
     from omgsr_amd import ops
     from omgsr_amd.testing import psnr, rel_l2, seeded_init_
     from oracle import diffusers_ref as R
-    from oracle.pipeline_ref import OmgsrSRef
+    from oracle.pipeline_ref import OmgsrSRef, TiledVaeRef
     # 16 threads is the fastest eager-fp32 configuration on the GPU box's 2 x EPYC 9575F (measured with
     # tools/cpu_threads_probe.py: 16 thr 1.13 TFLOP/s, 32 thr 0.77, 64 thr 0.52, 128 thr 0.24)
     cores = int(os.environ.get("OMGSR_CPU_THREADS", min(16, os.cpu_count() or 1)))
     torch.set_num_threads(cores)
     vae, unet = seeded_init_(R.AutoencoderKL(), 101).eval(), seeded_init_(R.UNet2DConditionModel(), 202).eval()
     vae.posterior_noise = eps1
-    ref = OmgsrSRef(vae, unet, R.DDPMScheduler().alphas_cumprod[273], 273)
+    ref = OmgsrSRef(TiledVaeRef(vae, 256, 64) if tiled_vae else vae, unet, R.DDPMScheduler().alphas_cumprod[273], 273)
     with torch.no_grad():
         t0 = time.perf_counter()
         img = ref(lq1, prompt, tile, overlap)

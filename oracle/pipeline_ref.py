@@ -70,6 +70,29 @@ def stitch(latent_shape, preds: List[torch.Tensor], offs, tile_size: int, channe
     return noise_pred
 
 
+class TiledVaeRef:
+    """The VAE as OMGSR_{S,F}_Infer._init_tiled_vae leaves it (infer/omgsr_s_infer_model.py:34-54): encoder and
+    decoder forward replaced by the tiled VAEHook; quant / post-quant convs and the posterior are untouched."""
+
+    def __init__(self, vae, encoder_tile_size: int, decoder_tile_size: int, fast: bool = False):
+        from . import vaehook_ref as V
+        from .diffusers_ref import DiagonalGaussianDistribution
+        self.vae, self.config, self._V, self._D = vae, vae.config, V, DiagonalGaussianDistribution
+        self.et, self.dt, self.fast = encoder_tile_size, decoder_tile_size, fast
+
+    def encode(self, x):
+        m = self._V.tiled_forward(self.vae.encoder, x, self.et, False, self.fast)
+        if self.vae.quant_conv is not None:
+            m = self.vae.quant_conv(m)
+        return type("EncOut", (), {"latent_dist": self._D(m, self.vae.posterior_noise)})()
+
+    def decode(self, z, return_dict: bool = True):
+        if self.vae.post_quant_conv is not None:
+            z = self.vae.post_quant_conv(z)
+        img = self._V.tiled_forward(self.vae.decoder, z, self.dt, True, self.fast)
+        return type("DecOut", (), {"sample": img})() if return_dict else (img,)
+
+
 # ---- OMGSR-S ------------------------------------------------------------------------------------
 class OmgsrSRef:
     def __init__(self, vae, unet, alpha_t: torch.Tensor, mid_timestep: int):
