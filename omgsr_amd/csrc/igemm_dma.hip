@@ -4,37 +4,38 @@
 // 16 bytes, and gfx950's register->LDS path sustains only ~79 B/clk/CU (MI355X_MICROARCH.md §LDS):
 // at a 128x128 tile that is ~0.8 LDS-write cycles per MFMA cycle, which caps the kernel near 30 % of
 // the MFMA peak. Here the operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave
-// instruction, no VGPR round trip, no ds_write), the tile is 256 x 128 (8 waves, 64x64 per wave:
-// 12 KB staged per MFLOP instead of 16) and three K-stages are in flight.
+// instruction, no VGPR round trip, no ds_write), the tile is 256 x 128 and three K-stages are in flight.
 //
 //  * LDS image is LINEAR ([row][64 B], BK = 32) because the DMA writes base + lane*16; bank
 //    conflicts are removed by a swizzle applied to the SOURCE chunk and to the read
 //    (position = chunk ^ ((row >> 2) & 3)): every 16-lane ds_read_b128 service group then covers
 //    16 distinct 16-B slots
-//  * the conv halo / rows past M / taps past R*S read a 16-byte ZERO PAGE instead of being predicated
-//    (an LDS-DMA lane that is masked off would leave stale bytes in its slot)
+//  * the conv halo / rows past M read a 16-byte ZERO PAGE instead of being predicated (an LDS-DMA lane
+//    that is masked off would leave stale bytes in its slot)
+//  * K order is tap-major (Cin % 32 == 0): validity + pointer of each gathered row are recomputed once
+//    per TAP; inside a tap a K-step only advances pointers (the first version was instruction-issue
+//    bound: ~10 VALU + 8 SALU per MFMA, profiles/r01_pmc_igemm.md)
 //  * 3-deep LDS ring, prefetch distance 2, ONE raw s_barrier per K-step; waits are counted
-//    (s_waitcnt vmcnt(3) = "my copies for this step have landed, next step's may still fly");
+//    (s_waitcnt vmcnt(P) = "my copies for this step have landed, next step's may still fly");
 //    the DMA is issued from inline asm so hipcc neither drains it at the barrier nor before ds_reads
+//  * two wave shapes: WGM = 4 -> 8 waves of 64x64 (1 ds_read_b128 per MFMA, 8 MFMA per barrier),
+//    WGM = 2 -> 4 waves of 128x64 (0.75 reads per MFMA, 16 MFMA per barrier, 128 accumulator VGPRs)
 //  * epilogue shared with igemm.hip
 #include "common.hip.h"
 #include "../../include/omgsr_hip.h"
 #include "igemm_epilogue.hip.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BK = 32;
-constexpr int NT = 512;            // 8 waves
 constexpr int BM = 256, BN = 128;
-constexpr int WGM = 4, WGN = 2;
-constexpr int WTM = 64, WTN = 64, FM = 2, FN = 2;
+constexpr int WGN = 2, WTN = 64, FN = 2;
 constexpr int A_BYTES = BM * BK * 2;          // 16 KB
 constexpr int B_BYTES = BN * BK * 2;          //  8 KB
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
 constexpr int NSTAGE = 3;
-constexpr int EPI_LD = WTN + 4;
-constexpr int EPI_BYTES = 8 * 32 * EPI_LD * 4;
-constexpr int LDS_BYTES = (NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;   // 72 KB (>= the epilogue's 8 x 32 x 68 x 4 B)
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
 
@@ -52,8 +53,24 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-__global__ __launch_bounds__(NT) void igemm_dma_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // LDS_BYTES (72 KB), dynamic
+template <int N>
+OMGSR_DEVINL void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else static_assert(N == 0, "unsupported count");
+}
+
+// ABL (ablation, A/B runs only): 0 = the kernel; 1 = no DMA; 2 = DMA + ds_reads, no MFMA; 3 = DMA only
+template <int WGM, int ABL = 0>
+__global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
+    constexpr int NW = WGM * WGN;              // waves
+    constexpr int WTM = BM / WGM, FM = WTM / 32;
+    constexpr int APW = 16 / NW, BPW = 8 / NW; // 1-KiB DMA pieces per wave per K-step (A: 16, B: 8 in total)
+    constexpr int PIECES = APW + BPW;
+    constexpr int EPI_LD = WTN + 4;
+    static_assert(NW * 32 * EPI_LD * 4 <= LDS_BYTES, "epilogue staging must fit the ring");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // LDS_BYTES, dynamic
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -71,13 +88,13 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const omgsr_igemm_args p,
     const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;            // LDS byte offset of the ring
 
     // ---- DMA coordinates: a wave instruction fills 16 rows x 64 B ---------------------------
-    // A: wave w fills rows [32w, 32w+32) with two pieces; B: rows [16w, 16w+16) with one piece.
+    // A piece j of wave w covers rows [16*(w*APW+j), +16); B piece j rows [16*(w*BPW+j), +16).
     const int lrow = lane >> 2;                              // 0..15 row inside the piece
     const int kc = (lane & 3) ^ ((lane >> 4) & 3);           // source chunk for LDS position (lane & 3)
-    int a_img[2], a_vy0[2], a_vx0[2];
+    int a_img[APW], a_vy0[APW], a_vx0[APW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + 32 * wave + 16 * i + lrow;
+    for (int i = 0; i < APW; ++i) {
+        const int m = m0 + 16 * (wave * APW + i) + lrow;
         if (m < g.M) {
             const int img = m / g.HoWo;
             const int rem = m - img * g.HoWo;
@@ -89,20 +106,19 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const omgsr_igemm_args p,
             a_img[i] = -1; a_vy0[i] = 0; a_vx0[i] = 0;
         }
     }
-    // K order is tap-major: K-step kt = (tap, channel step). Cin % 32 == 0 here, so a step never
-    // straddles taps: the (validity, pointer) pair of each row is recomputed once per TAP and the
-    // steps inside a tap only advance the pointers by 64 B (0 B for rows parked on the zero page):
-    // ~3 VALU per K-step instead of ~80 (the kernel was instruction-issue bound, profiles/r01_pmc_*).
-    const unsigned char* b_ptr = reinterpret_cast<const unsigned char*>(wt + (int64_t)(n0 + 16 * wave + lrow) * p.K_pad + kc * 8);
-    const unsigned char* a_ptr[2];
-    int a_inc[2];
+    const unsigned char* b_ptr[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i)
+        b_ptr[i] = reinterpret_cast<const unsigned char*>(wt + (int64_t)(n0 + 16 * (wave * BPW + i) + lrow) * p.K_pad + kc * 8);
+    const unsigned char* a_ptr[APW];
+    int a_inc[APW];
     const int steps_per_tap = p.Cin / BK;
     int kin = 0, tap_r = 0, tap_s = 0;       // wave-uniform cursor of the NEXT step to issue
 
     auto issue = [&](int stage) {
         if (kin == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < APW; ++i) {
                 const int vy = a_vy0[i] + tap_r, vx = a_vx0[i] + tap_s;
                 const bool ok = a_img[i] >= 0 && (unsigned)vy < (unsigned)g.Hv && (unsigned)vx < (unsigned)g.Wv;
                 const int iy = vy >> p.upsample, ix = vx >> p.upsample;
@@ -112,14 +128,18 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const omgsr_igemm_args p,
                 a_inc[i] = ok ? BK * 2 : 0;
             }
         }
-        const unsigned sa = lds_base + stage * STAGE_BYTES + (32 * wave) * 64;
-        const unsigned sb = lds_base + stage * STAGE_BYTES + A_BYTES + (16 * wave) * 64;
-        glds16(a_ptr[0], __builtin_amdgcn_readfirstlane(sa));
-        glds16(a_ptr[1], __builtin_amdgcn_readfirstlane(sa + 1024));
-        glds16(b_ptr, __builtin_amdgcn_readfirstlane(sb));
-        a_ptr[0] += a_inc[0];
-        a_ptr[1] += a_inc[1];
-        b_ptr += BK * 2;
+        const unsigned sa = lds_base + stage * STAGE_BYTES + (16 * wave * APW) * 64;
+        const unsigned sb = lds_base + stage * STAGE_BYTES + A_BYTES + (16 * wave * BPW) * 64;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            glds16(a_ptr[i], __builtin_amdgcn_readfirstlane(sa + i * 1024));
+            a_ptr[i] += a_inc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            glds16(b_ptr[i], __builtin_amdgcn_readfirstlane(sb + i * 1024));
+            b_ptr[i] += BK * 2;
+        }
         if (++kin == steps_per_tap) { kin = 0; if (++tap_s == p.S) { tap_s = 0; ++tap_r; } }
     };
 
@@ -131,8 +151,7 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const omgsr_igemm_args p,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    issue(0);
-    if (g.nk > 1) issue(1);
+    if constexpr (ABL != 1) { issue(0); if (g.nk > 1) issue(1); }
 
     // fragment read offsets (swizzled): row = base + (lane & 31); chunk = 2*ks + (lane >> 5)
     const int frow = lane & 31;
@@ -142,14 +161,19 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const omgsr_igemm_args p,
 
     int stage = 0;
     for (int kt = 0; kt < g.nk; ++kt) {
-        if (kt + 1 < g.nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (ABL != 1) {
+            if (kt + 1 < g.nk) wait_vmcnt<PIECES>();
+            else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 2 < g.nk) {
-            int s2 = stage + 2; if (s2 >= NSTAGE) s2 -= NSTAGE;
-            issue(s2);
+        if constexpr (ABL != 1) {
+            if (kt + 2 < g.nk) {
+                int s2 = stage + 2; if (s2 >= NSTAGE) s2 -= NSTAGE;
+                issue(s2);
+            }
         }
+        if constexpr (ABL == 3) { if (++stage == NSTAGE) stage = 0; continue; }
         const unsigned char* As = lds + stage * STAGE_BYTES + (wm * WTM) * 64;
         const unsigned char* Bs = lds + stage * STAGE_BYTES + A_BYTES + (wn * WTN) * 64;
         bf16x8_t af[2][FM], bf[2][FN];
@@ -163,17 +187,41 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const omgsr_igemm_args p,
             bf[0][j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 32 * 64 + foff0);
             bf[1][j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 32 * 64 + foff1);
         }
+        if constexpr (ABL == 2) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i) asm volatile("" :: "v"(af[ks][i]));
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(af[ks][i], bf[ks][j], acc[i][j]);
+                for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(bf[ks][j]));
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(af[ks][i], bf[ks][j], acc[i][j]);
+        }
         if (++stage == NSTAGE) stage = 0;
     }
 
     float* epi = reinterpret_cast<float*>(lds) + wave * 32 * EPI_LD;
     igemm_epilogue<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
+}
+
+template <int WGM, int ABL = 0>
+int launch_dma(const omgsr_igemm_args& a, const IgemmGeo& g, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<WGM, ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(g.ntm * g.ntn, 1, a.batch);
+    hipLaunchKernelGGL((igemm_dma_kernel<WGM, ABL>), grid, dim3(WGM * WGN * 64), LDS_BYTES, st, a, g);
+    return (int)hipGetLastError();
 }
 
 }  // namespace
@@ -184,15 +232,12 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     g.nk = a.K_pad / BK;
     g.ntm = (g.M + BM - 1) / BM;
     g.ntn = (logical_cols + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    dim3 grid(g.ntm * g.ntn, 1, a.batch);
-    hipLaunchKernelGGL(igemm_dma_kernel, grid, dim3(NT), LDS_BYTES, st, a, g);
-    return (int)hipGetLastError();
+    static const char* shape = getenv("OMGSR_DMA_WAVES");      // "8" forces the 8-wave shape (A/B runs)
+    static const char* abl = getenv("OMGSR_DMA_ABLATE");      // timing experiments only: results are garbage
+    if (abl && abl[0] == '1') return launch_dma<2, 1>(a, g, st);
+    if (abl && abl[0] == '2') return launch_dma<2, 2>(a, g, st);
+    if (abl && abl[0] == '3') return launch_dma<2, 3>(a, g, st);
+    if (shape && shape[0] == '8') return launch_dma<4>(a, g, st);
+    return launch_dma<2>(a, g, st);
 }
 }  // namespace omgsr
