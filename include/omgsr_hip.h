@@ -75,6 +75,8 @@ typedef struct omgsr_igemm_args {
     int32_t batch;         /* grid.z; strides below are in elements                    */
     int64_t in_bstride, w_bstride, out_bstride;
     float alpha;
+    const void* weight_cm; /* optional second packing of a 3x3 weight, chunk-major K order
+                              k = ((c/32)*9 + r*3+s)*32 + c%32 (Cin % 32 == 0): enables the halo-tile kernel | NULL */
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
 

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class OmgsrError(RuntimeError):
@@ -34,7 +34,7 @@ class IgemmArgs(C.Structure):
         ("t_rows", C.c_int32), ("t_ld", C.c_int32), ("out_ld", C.c_int32),
         ("batch", C.c_int32),
         ("in_bstride", C.c_int64), ("w_bstride", C.c_int64), ("out_bstride", C.c_int64),
-        ("alpha", C.c_float),
+        ("alpha", C.c_float), ("weight_cm", C.c_void_p),
     ]
 
 

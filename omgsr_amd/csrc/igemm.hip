@@ -23,7 +23,11 @@
 #include <stdlib.h>
 #include <string.h>
 
-namespace omgsr { int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st); }
+namespace omgsr {
+int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
+int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
+int igemm_halo_tiles(const omgsr_igemm_args& a);
+}
 
 namespace {
 
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args 
 
     // ---- epilogue: fragments -> LDS (fp32) -> 8 consecutive channels per lane -------------
     float* epi = reinterpret_cast<float*>(lds) + wave * 32 * EPI_LD;
-    igemm_epilogue<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
+    igemm_epilogue_linear<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -207,6 +211,13 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     // Large problems: LDS-DMA kernel (256x128 tile, 3-stage ring). OMGSR_IGEMM_MODE=reg|dma overrides (A/B runs).
     static const char* mode = getenv("OMGSR_IGEMM_MODE");
     const int64_t tiles256 = ((M64 + 255) / 256) * ((logical_cols + 127) / 128) * a.batch;
+    // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
+    const bool halo_ok = a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 &&
+                         !a.upsample && (a.Cin % 32) == 0 && a.batch == 1 && a.Ho == a.H && a.Wo == a.W && a.W >= 16 &&
+                         logical_cols >= 96 && a.out_layout == OMGSR_LAYOUT_NHWC;
+    if (halo_ok && !(mode && (!strcmp(mode, "reg") || !strcmp(mode, "dma"))) &&
+        ((mode && !strcmp(mode, "halo")) || omgsr::igemm_halo_tiles(a) >= 192))
+        return omgsr::igemm_halo_launch(a, g, st);
     const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0;   // the DMA kernel's K-steps never straddle taps
     if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192)))
         return omgsr::igemm_dma_launch(a, g, st);

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
     }
 
     float* epi = reinterpret_cast<float*>(lds) + wave * 32 * EPI_LD;
-    igemm_epilogue<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
+    igemm_epilogue_linear<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
 }
 
 template <int WGM, int ABL = 0>

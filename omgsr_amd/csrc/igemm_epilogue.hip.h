@@ -4,11 +4,12 @@
 #include "common.hip.h"
 #include "../../include/omgsr_hip.h"
 
-// epi: this wave's private LDS region of 32 x (WTN + 4) floats. m_base / n_base: first output row /
-// packed column of the wave tile. Must be called by every wave of the block (contains barriers).
+// epi: this wave's private LDS region of 32 x (WTN + 4) floats. Fragment row-block i covers output rows
+// mb[i] .. mb[i] + nvalid[i] - 1 (nvalid <= 32: rows past the tensor / past the image edge are dropped);
+// n_base: first packed column of the wave tile. Must be called by every wave of the block (barriers).
 template <int WTN, int FM, int FN>
-OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, const int M, f32x16_t (&acc)[FM][FN], float* epi,
-                                 const int lane, const int m_base, const int n_base, const int bz) {
+OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
+                                 const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz) {
     constexpr int EPI_LD = WTN + 4;
     const bool geglu = (p.act == OMGSR_ACT_GEGLU);
     const int cols_per_row = geglu ? WTN / 2 : WTN;     // produced output columns per staged row
@@ -32,7 +33,7 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, const int M, f32x16_
         __syncthreads();
         for (int rb = 0; rb < 32; rb += rows_per_pass) {
             const int row = rb + lrow;
-            const int m = m_base + i * 32 + row;
+            const int m = mb[i] + row;
             float v[8];
             int n;  // first logical output column of this lane
             if (geglu) {
@@ -65,7 +66,7 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, const int M, f32x16_
                     for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
                 }
             }
-            if (m >= M || n >= p.Cout) continue;
+            if (row >= nvalid[i] || n >= p.Cout) continue;
             if (p.gate) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (n + e < p.Cout) v[e] *= p.gate[n + e];
@@ -104,7 +105,22 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, const int M, f32x16_
     }
 }
 
+// linear-M helper for the GEMM-shaped kernels: row block i starts at m_base + 32*i
+template <int WTN, int FM, int FN>
+OMGSR_DEVINL void igemm_epilogue_linear(const omgsr_igemm_args& p, const int M, f32x16_t (&acc)[FM][FN], float* epi,
+                                        const int lane, const int m_base, const int n_base, const int bz) {
+    int mb[FM], nv[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        mb[i] = m_base + 32 * i;
+        const int left = M - mb[i];
+        nv[i] = left < 0 ? 0 : (left > 32 ? 32 : left);
+    }
+    igemm_epilogue<WTN, FM, FN>(p, acc, epi, lane, mb, nv, n_base, bz);
+}
+
 struct IgemmGeo {
+    int tiles_x, tiles_y;   // halo kernel: spatial tile grid per image
     int M;          // N*Ho*Wo rows per batch entry
     int HoWo;
     int Hv, Wv;     // virtual (post-upsample) input extent

@@ -1,0 +1,209 @@
+// 3x3 stride-1 pad-1 convolution, halo-tile variant of the LDS-DMA implicit GEMM (gfx950).
+//
+// profiles/r01_pmc_igemm.md: the LDS-DMA GEMM kernel spends ~70 % of its time just streaming operands
+// L2 -> LDS (24 KB per 2.1 MFLOP K-step); 9 of every 10 A bytes are the SAME input pixels fetched again
+// for another tap. This kernel cuts the bytes instead of chasing the stream:
+//
+//  * an output tile is SPATIAL: 8 rows x 32 pixels (256 outputs) x 128 channels; for one 32-channel chunk
+//    the (8+2) x (32+2) input patch is DMA'd into LDS ONCE (21.3 KB) and all 9 taps read their MFMA A
+//    fragments from it at shifted rows (fragment = 32 consecutive pixels of one tile row, so the swizzled
+//    linear image stays conflict-free at any shift)      -> A traffic 144 KB -> 24 KB per chunk
+//  * K order is chunk-major: k = (cc*9 + tap)*32 + c, the weights are packed that way (`weight_cm`);
+//    a K-step = (chunk, tap) streams only its 8 KB weight slice through a 3-deep ring
+//  * per 18.9 MFLOP chunk: 24 KB (A, double-buffered, prefetched one chunk ahead) + 72 KB (B) = 5.1 KB/MFLOP
+//    vs 12 KB/MFLOP for the GEMM-shaped kernel
+//  * 4 waves, 128 x 64 per wave (4 tile rows x 64 couts), one raw s_barrier per K-step, counted vmcnt
+//  * image borders / ragged W,H: patch pixels outside the image come from the zero page, output columns
+//    past W and rows past H are dropped in the epilogue (tiled-VAE tiles are 86, 172, 320 ... wide)
+#include "common.hip.h"
+#include "../../include/omgsr_hip.h"
+#include "igemm_epilogue.hip.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, PROWS = PH * PW;   // 340 patch pixels
+constexpr int APIECES = 24, APW = 6;                                        // 1-KiB DMA pieces (16 rows) per chunk / per wave
+constexpr int A_BYTES = APIECES * 1024;
+constexpr int BN = 128, B_BYTES = BN * 64, BPW = 2, NB = 3;
+constexpr int LDS_BYTES = 2 * A_BYTES + NB * B_BYTES;                        // 72 KB
+constexpr int WTN = 64, FM = 4, FN = 2, EPI_LD = WTN + 4;
+static_assert(4 * 32 * EPI_LD * 4 <= LDS_BYTES, "epilogue staging fits");
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page_h[4] = {0u, 0u, 0u, 0u};
+
+OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+__global__ __launch_bounds__(256) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tile = xcd_remap(blockIdx.x, g.ntm * g.ntn);
+    const int tn = tile % g.ntn, tm = tile / g.ntn;
+    const int per_img = g.tiles_x * g.tiles_y;
+    const int img = tm / per_img;
+    const int trem = tm - img * per_img;
+    const int ty = trem / g.tiles_x, tx = trem - ty * g.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+
+    const bf16_t* __restrict__ in = (const bf16_t*)p.in;
+    const bf16_t* __restrict__ wt = (const bf16_t*)p.weight_cm;
+    typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+    const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;
+
+    const int lrow = lane >> 2;
+    const int kc = (lane & 3) ^ ((lane >> 4) & 3);           // source chunk for LDS position (lane & 3)
+
+    // A patch pieces: piece j = wave*6 + i covers patch rows [16j, 16j+16); patch row -> (py, px)
+    const unsigned char* a_ptr[APW];
+    int a_inc[APW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int pr = 16 * (wave * APW + i) + lrow;
+        const int py = pr / PW, px = pr - py * PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const int64_t pix = ((int64_t)img * p.H + iy) * p.W + ix;
+        a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * p.Cin + kc * 8)
+                      : reinterpret_cast<const unsigned char*>(g_zero_page_h);
+        a_inc[i] = ok ? 64 : 0;
+    }
+    const unsigned char* b_ptr[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i)
+        b_ptr[i] = reinterpret_cast<const unsigned char*>(wt + (int64_t)(n0 + 16 * (wave * BPW + i) + lrow) * p.K_pad + kc * 8);
+
+    auto issue_a = [&](int buf) {
+        const unsigned dst = lds_base + buf * A_BYTES + (wave * APW) * 1024;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            glds16(a_ptr[i], __builtin_amdgcn_readfirstlane(dst + i * 1024));
+            a_ptr[i] += a_inc[i];
+        }
+    };
+    auto issue_b = [&](int stage) {
+        const unsigned dst = lds_base + 2 * A_BYTES + stage * B_BYTES + (wave * BPW) * 1024;
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            glds16(b_ptr[i], __builtin_amdgcn_readfirstlane(dst + i * 1024));
+            b_ptr[i] += 64;
+        }
+    };
+
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int ncc = g.nk;                  // 32-channel chunks
+    const int nsteps = ncc * 9;
+    issue_a(0);
+    issue_b(0);
+    int after = 0;                         // DMA instructions issued after the slice the next wait needs
+    if (nsteps > 1) { issue_b(1); after = BPW; }
+
+    // B fragment offsets (fixed): row = wn*64 + j*32 + (lane & 31)
+    const int frow = lane & 31;
+    const int half = lane >> 5;
+    const int bsw = (frow >> 2) & 3;
+    const int boff0 = frow * 64 + ((half) ^ bsw) * 16;
+    const int boff1 = frow * 64 + ((2 + half) ^ bsw) * 16;
+    // A fragment base rows: tile row (4*wm + i), pixel (lane & 31)
+    const int arow0 = (4 * wm) * PW + frow;
+
+    int cc = 0, tap = 0, bstage = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        if (after == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (after == BPW) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        after = 0;
+        if (tap == 0 && cc + 1 < ncc) { issue_a((cc + 1) & 1); after += APW; }
+        if (s + 2 < nsteps) { int s2 = bstage + 2; if (s2 >= NB) s2 -= NB; issue_b(s2); after += BPW; }
+
+        const unsigned char* As = lds + (cc & 1) * A_BYTES;
+        const unsigned char* Bs = lds + 2 * A_BYTES + bstage * B_BYTES + (wn * WTN) * 64;
+        const int tr = tap / 3, tsft = tap - tr * 3;
+        const int toff = tr * PW + tsft;
+        bf16x8_t af[2][FM], bf[2][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = arow0 + i * PW + toff;
+            const int sw = (row >> 2) & 3;
+            af[0][i] = *reinterpret_cast<const bf16x8_t*>(As + row * 64 + ((half ^ sw) << 4));
+            af[1][i] = *reinterpret_cast<const bf16x8_t*>(As + row * 64 + (((2 + half) ^ sw) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            bf[0][j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 32 * 64 + boff0);
+            bf[1][j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 32 * 64 + boff1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(af[ks][i], bf[ks][j], acc[i][j]);
+
+        if (++bstage == NB) bstage = 0;
+        if (++tap == 9) { tap = 0; ++cc; }
+    }
+
+    int mb[FM], nv[FM];
+    int colsv = p.W - x0; colsv = colsv > TW ? TW : colsv;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int y = y0 + 4 * wm + i;
+        mb[i] = (img * p.H + y) * p.W + x0;
+        nv[i] = (y < p.H) ? colsv : 0;
+    }
+    float* epi = reinterpret_cast<float*>(lds) + wave * 32 * EPI_LD;
+    igemm_epilogue<WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0);
+}
+
+}  // namespace
+
+namespace omgsr {
+// Preconditions (checked by the dispatcher): R = S = 3, stride 1, pad 1, no upsample, Cin % 32 == 0,
+// weight_cm != NULL, batch == 1, W >= 16.
+int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    g.nk = a.Cin / 32;
+    g.tiles_x = (a.W + TW - 1) / TW;
+    g.tiles_y = (a.H + TH - 1) / TH;
+    g.ntm = a.N * g.tiles_x * g.tiles_y;
+    g.ntn = (logical_cols + BN - 1) / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(g.ntm * g.ntn, 1, 1);
+    hipLaunchKernelGGL(igemm_halo_kernel, grid, dim3(256), LDS_BYTES, st, a, g);
+    return (int)hipGetLastError();
+}
+int igemm_halo_tiles(const omgsr_igemm_args& a) {
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    return a.N * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * ((logical_cols + BN - 1) / BN);
+}
+}  // namespace omgsr

@@ -42,7 +42,7 @@ class Conv2d(nn.Conv2d, _Packed):
         """x [N,H,W,Cin8] -> [N,Ho,Wo,Cout8]; channels beyond out_channels are exact zeros."""
         pw = self.packed()
         if bias_override is not None:
-            pw = ops.PackedWeight(pw.w, bias_override, pw.cout, pw.cin, pw.R, pw.S)
+            pw = ops.PackedWeight(pw.w, bias_override, pw.cout, pw.cin, pw.R, pw.S, w_cm=pw.w_cm)
         p = self.padding[0] if pad is None else pad
         return ops.conv2d(x, pw, stride=stride or self.stride[0], pad=p, upsample=upsample, act=act, residual=residual)
 

@@ -55,6 +55,7 @@ class PackedWeight:
     R: int
     S: int
     geglu: bool = False
+    w_cm: Optional[torch.Tensor] = None   # chunk-major second packing (3x3, Cin % 32 == 0): halo-tile kernel
 
     @property
     def cout_pad(self) -> int:
@@ -87,7 +88,12 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
     out = torch.zeros(cout_pad, k_pad, device=dev, dtype=torch.bfloat16)
     out[:cout, : w.shape[1]] = w.to(torch.bfloat16)
     b = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
-    return PackedWeight(out, b, cout, cin8, R, S)
+    w_cm = None
+    if R == 3 and S == 3 and cin8 % 32 == 0:
+        # k = ((c // 32) * 9 + tap) * 32 + c % 32
+        w_cm = torch.zeros_like(out)
+        w_cm[:cout] = out[:cout].view(cout, 9, cin8 // 32, 32).permute(0, 2, 1, 3).reshape(cout, 9 * cin8)
+    return PackedWeight(out, b, cout, cin8, R, S, w_cm=w_cm)
 
 
 def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None) -> PackedWeight:
@@ -144,6 +150,7 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
     a.residual, a.out = _ptr(residual), out.data_ptr()
+    a.weight_cm = _ptr(pw.w_cm)
     a.N, a.H, a.W, a.Cin = N, H, W, Cin
     a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
     a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = pw.R, pw.S, stride, pt, pl, int(upsample)

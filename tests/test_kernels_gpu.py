@@ -61,6 +61,11 @@ CONV_CASES = [
     (1, 256, 256, 12, 20, 1, (1, 1, 1, 1), True, True, False, 0),       # nearest-2x folded into the gather
     (1, 40, 72, 9, 7, 1, (1, 1, 1, 1), False, False, False, 0),         # ragged everything
     (3, 640, 1280, 8, 8, 1, (1, 1, 1, 1), False, True, True, 0),
+    # ragged spatial sizes (tiled-VAE tiles): exercise the halo-tile kernel's border handling
+    (1, 64, 128, 86, 43, 1, (1, 1, 1, 1), False, True, False, 0),
+    (2, 128, 256, 20, 50, 1, (1, 1, 1, 1), False, True, True, 1),
+    (1, 32, 128, 9, 33, 1, (1, 1, 1, 1), False, False, False, 0),
+    (2, 256, 128, 64, 64, 1, (1, 1, 1, 1), False, True, True, 0),
 ]
 
 
