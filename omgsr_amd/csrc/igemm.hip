@@ -46,8 +46,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args 
     static_assert(FM >= 1 && FN >= 1 && A_CH >= 1, "tile");
     constexpr int B_CHN = (B_CH >= 1) ? B_CH : 1;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
-    constexpr int EPI_LD = WTN + 4;                 // floats
-    constexpr int EPI_BYTES = 4 * 32 * EPI_LD * 4;
+    constexpr int EPI_BYTES = 4 * 32 * (WTN + 4) * 4;
     constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -157,14 +156,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args 
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(bf[j], af[i], acc[i][j]);   // transposed tile
         }
         if (kt + 1 < g.nk) write_stage(buf ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue: fragments -> LDS (fp32) -> 8 consecutive channels per lane -------------
-    float* epi = reinterpret_cast<float*>(lds) + wave * 32 * EPI_LD;
+    float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
     igemm_epilogue_linear<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
 }
 

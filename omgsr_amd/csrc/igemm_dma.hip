@@ -68,8 +68,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
     constexpr int WTM = BM / WGM, FM = WTM / 32;
     constexpr int APW = 16 / NW, BPW = 8 / NW; // 1-KiB DMA pieces per wave per K-step (A: 16, B: 8 in total)
     constexpr int PIECES = APW + BPW;
-    constexpr int EPI_LD = WTN + 4;
-    static_assert(NW * 32 * EPI_LD * 4 <= LDS_BYTES, "epilogue staging must fit the ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // LDS_BYTES, dynamic
 
     const int t = threadIdx.x;
@@ -201,12 +199,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(af[ks][i], bf[ks][j], acc[i][j]);
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);   // transposed tile
         }
         if (++stage == NSTAGE) stage = 0;
     }
 
-    float* epi = reinterpret_cast<float*>(lds) + wave * 32 * EPI_LD;
+    static_assert(NW * 32 * (WTN + 4) * 4 <= LDS_BYTES, "epilogue staging must fit the ring");
+    float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
     igemm_epilogue_linear<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
 }
 

@@ -1,16 +1,29 @@
-// Shared epilogue of the implicit-GEMM kernels: 32x32 MFMA fragments -> per-wave fp32 LDS region ->
-// 8 consecutive output channels per lane -> bias / activation / gate / residual -> 16-byte stores.
+// Shared epilogue of the implicit-GEMM kernels.
+//
+// The kernels accumulate the TRANSPOSED tile, acc = mfma(W_frag, X_frag): a 32x32 fragment then holds, per
+// lane, ONE output pixel (col = lane & 31) and 16 output channels in registers, 4 consecutive channels per
+// register quad (channel = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)). Each wave stages a 32-pixel row block in
+// its PRIVATE fp32 LDS region with ds_write_b128 (4 channels per write; the 272-B row pitch puts the 8
+// lanes of a write group on 32 distinct banks), reads it back as 8 consecutive channels per lane and
+// issues 16-byte global stores: every output row leaves the CU as full 128-B segments (per-lane
+// register stores at a row stride were measured 3x slower, profiles/r01_pmc_igemm.md §5).
+// Only ONE block barrier (the staging region overlaps the operand ring); the rest is wave-local, LDS
+// operations of one wave execute in program order.
 #pragma once
 #include "common.hip.h"
 #include "../../include/omgsr_hip.h"
 
+OMGSR_DEVINL void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // epi: this wave's private LDS region of 32 x (WTN + 4) floats. Fragment row-block i covers output rows
-// mb[i] .. mb[i] + nvalid[i] - 1 (nvalid <= 32: rows past the tensor / past the image edge are dropped);
-// n_base: first packed column of the wave tile. Must be called by every wave of the block (barriers).
+// (pixels) mb[i] .. mb[i] + nvalid[i] - 1; n_base: first PACKED column of the wave tile (GEGLU: packed
+// [32 a | 32 g] per 64). Must be called by every wave of the block.
 template <int WTN, int FM, int FN>
 OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
                                  const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz) {
     constexpr int EPI_LD = WTN + 4;
+    static_assert(WTN == FN * 32, "wave tile width");
+    const int half = lane >> 5, px = lane & 31;
     const bool geglu = (p.act == OMGSR_ACT_GEGLU);
     const int cols_per_row = geglu ? WTN / 2 : WTN;     // produced output columns per staged row
     const int lanes_per_row = cols_per_row / 8;
@@ -19,18 +32,35 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
     bf16_t* outb = (bf16_t*)p.out + (int64_t)bz * p.out_bstride;
     float* outf = (float*)p.out + (int64_t)bz * p.out_bstride;
     const bf16_t* resb = p.residual ? (const bf16_t*)p.residual + (int64_t)bz * p.out_bstride : nullptr;
-    const bool vec_ok = (p.Cout & 7) == 0 && (p.out_ld & 7) == 0;
     const int64_t ldo = p.out_ld > 0 ? p.out_ld : p.Cout;
+    const bool vec_ok = (p.Cout & 7) == 0 && (ldo & 7) == 0;
 
+    // a lane's output columns are the same for every row pass: fetch bias / gate ONCE (per-pass scalar
+    // loads made the epilogue latency-bound: ~30 % of a 128-channel conv's time)
+    float bias_a[8], bias_g[8], gate8[8];
+    {
+        const int grp = lcol >> 5, within = lcol & 31;
+        const int nb = geglu ? n_base + grp * 64 + within : n_base + lcol;     // packed index
+        const int nlog = geglu ? (n_base >> 1) + lcol : n_base + lcol;         // logical output column
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool in = geglu ? true : (nb + e < p.Cout);
+            bias_a[e] = (p.bias && in) ? p.bias[nb + e] : 0.0f;
+            bias_g[e] = (p.bias && geglu) ? p.bias[nb + 32 + e] : 0.0f;
+            gate8[e] = (p.gate && nlog + e < p.Cout) ? p.gate[nlog + e] : 1.0f;
+        }
+    }
+    __syncthreads();            // every wave is done reading the operand ring the staging region overlaps
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        __syncthreads();
+        float* wr = epi + px * EPI_LD + 4 * half;
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                epi[cfrag_row(lane, r) * EPI_LD + j * 32 + (lane & 31)] = acc[i][j][r];
-        __syncthreads();
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4_t*>(wr + j * 32 + 8 * q) =
+                    (f32x4_t){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        wave_lds_fence();
         for (int rb = 0; rb < 32; rb += rows_per_pass) {
             const int row = rb + lrow;
             const int m = mb[i] + row;
@@ -40,12 +70,10 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                 // staged columns: per 64-wide group [32 a | 32 g]
                 const int grp = lcol >> 5, within = lcol & 31;
                 const float* pa = epi + row * EPI_LD + grp * 64 + within;
-                const int nb = n_base + grp * 64 + within;   // packed bias index of a
                 n = (n_base >> 1) + lcol;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float a = pa[e] * p.alpha, gt = pa[32 + e] * p.alpha;
-                    if (p.bias) { a += p.bias[nb + e]; gt += p.bias[nb + 32 + e]; }
+                    const float a = pa[e] * p.alpha + bias_a[e], gt = pa[32 + e] * p.alpha + bias_g[e];
                     v[e] = a * gelu_erf_f(gt);
                 }
             } else {
@@ -53,11 +81,7 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                 const f32x4_t x1 = *reinterpret_cast<const f32x4_t*>(epi + row * EPI_LD + lcol + 4);
                 n = n_base + lcol;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = x0[e] * p.alpha; v[4 + e] = x1[e] * p.alpha; }
-                if (p.bias) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) if (n + e < p.Cout) v[e] += p.bias[n + e];
-                }
+                for (int e = 0; e < 4; ++e) { v[e] = x0[e] * p.alpha + bias_a[e]; v[4 + e] = x1[e] * p.alpha + bias_a[4 + e]; }
                 if (p.act == OMGSR_ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
@@ -69,7 +93,7 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
             if (row >= nvalid[i] || n >= p.Cout) continue;
             if (p.gate) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (n + e < p.Cout) v[e] *= p.gate[n + e];
+                for (int e = 0; e < 8; ++e) v[e] *= gate8[e];
             }
             if (p.out_layout == OMGSR_LAYOUT_NHWC) {
                 const int64_t o = (int64_t)m * ldo + n;
@@ -102,6 +126,7 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                 }
             }
         }
+        wave_lds_fence();       // this wave's reads are done before the next row block overwrites the region
     }
 }
 

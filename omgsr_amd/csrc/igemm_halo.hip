@@ -18,6 +18,7 @@
 #include "common.hip.h"
 #include "../../include/omgsr_hip.h"
 #include "igemm_epilogue.hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,8 +27,7 @@ constexpr int APIECES = 24, APW = 6;                                        // 1
 constexpr int A_BYTES = APIECES * 1024;
 constexpr int BN = 128, B_BYTES = BN * 64, BPW = 2, NB = 3;
 constexpr int LDS_BYTES = 2 * A_BYTES + NB * B_BYTES;                        // 72 KB
-constexpr int WTN = 64, FM = 4, FN = 2, EPI_LD = WTN + 4;
-static_assert(4 * 32 * EPI_LD * 4 <= LDS_BYTES, "epilogue staging fits");
+constexpr int WTN = 64, FM = 4, FN = 2;
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_h[4] = {0u, 0u, 0u, 0u};
 
@@ -44,6 +44,7 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
+template <int ABL>
 __global__ __launch_bounds__(256) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void igemm_halo_kernel(const omgsr_igemm_args 
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(af[ks][i], bf[ks][j], acc[i][j]);
+                for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);   // transposed tile
 
         if (++bstage == NB) bstage = 0;
         if (++tap == 9) { tap = 0; ++cc; }
@@ -175,8 +176,15 @@ __global__ __launch_bounds__(256) void igemm_halo_kernel(const omgsr_igemm_args 
         mb[i] = (img * p.H + y) * p.W + x0;
         nv[i] = (y < p.H) ? colsv : 0;
     }
-    float* epi = reinterpret_cast<float*>(lds) + wave * 32 * EPI_LD;
-    igemm_epilogue<WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0);
+    if constexpr (ABL == 1) {      // timing experiment: keep the accumulators alive, skip the epilogue
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else {
+        float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
+        igemm_epilogue<WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0);
+    }
 }
 
 }  // namespace
@@ -193,13 +201,17 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     g.ntn = (logical_cols + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel<1>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(g.ntm * g.ntn, 1, 1);
-    hipLaunchKernelGGL(igemm_halo_kernel, grid, dim3(256), LDS_BYTES, st, a, g);
+    static const char* abl = getenv("OMGSR_HALO_ABLATE");      // timing experiments only
+    if (abl && abl[0] == '1') hipLaunchKernelGGL(igemm_halo_kernel<1>, grid, dim3(256), LDS_BYTES, st, a, g);
+    else hipLaunchKernelGGL(igemm_halo_kernel<0>, grid, dim3(256), LDS_BYTES, st, a, g);
     return (int)hipGetLastError();
 }
 int igemm_halo_tiles(const omgsr_igemm_args& a) {
