@@ -19,14 +19,17 @@
 #include "../../include/omgsr_hip.h"
 #include "igemm_epilogue.hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, PROWS = PH * PW;   // 340 patch pixels
-constexpr int APIECES = 24, APW = 6;                                        // 1-KiB DMA pieces (16 rows) per chunk / per wave
+constexpr int APIECES = 22, APW = 6;        // 1-KiB DMA pieces (16 patch rows): 22 real ones; every wave issues 6 so the
+                                            // vmcnt arithmetic is uniform - pieces 22, 23 copy the zero page to a dummy KiB
 constexpr int A_BYTES = APIECES * 1024;
+constexpr int DUMMY_OFF = 2 * A_BYTES, B_OFF = DUMMY_OFF + 2048;
 constexpr int BN = 128, B_BYTES = BN * 64, BPW = 2, NB = 3;
-constexpr int LDS_BYTES = 2 * A_BYTES + NB * B_BYTES;                        // 72 KB
+constexpr int LDS_BYTES = B_OFF + NB * B_BYTES;                              // 70 KB: two workgroups per CU
 constexpr int WTN = 64, FM = 4, FN = 2;
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_h[4] = {0u, 0u, 0u, 0u};
@@ -45,7 +48,7 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 }
 
 template <int ABL>
-__global__ __launch_bounds__(256) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
+__global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int t = threadIdx.x;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void igemm_halo_kernel(const omgsr_igemm_args 
         const int pr = 16 * (wave * APW + i) + lrow;
         const int py = pr / PW, px = pr - py * PW;
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-        const bool ok = pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const bool ok = (wave * APW + i) < APIECES && pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const int64_t pix = ((int64_t)img * p.H + iy) * p.W + ix;
         a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * p.Cin + kc * 8)
                       : reinterpret_cast<const unsigned char*>(g_zero_page_h);
@@ -89,15 +92,17 @@ __global__ __launch_bounds__(256) void igemm_halo_kernel(const omgsr_igemm_args 
         b_ptr[i] = reinterpret_cast<const unsigned char*>(wt + (int64_t)(n0 + 16 * (wave * BPW + i) + lrow) * p.K_pad + kc * 8);
 
     auto issue_a = [&](int buf) {
-        const unsigned dst = lds_base + buf * A_BYTES + (wave * APW) * 1024;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
-            glds16(a_ptr[i], __builtin_amdgcn_readfirstlane(dst + i * 1024));
+            const int piece = wave * APW + i;
+            const unsigned dst = piece < APIECES ? lds_base + buf * A_BYTES + piece * 1024
+                                                 : lds_base + DUMMY_OFF + (piece - APIECES) * 1024;
+            glds16(a_ptr[i], __builtin_amdgcn_readfirstlane(dst));
             a_ptr[i] += a_inc[i];
         }
     };
     auto issue_b = [&](int stage) {
-        const unsigned dst = lds_base + 2 * A_BYTES + stage * B_BYTES + (wave * BPW) * 1024;
+        const unsigned dst = lds_base + B_OFF + stage * B_BYTES + (wave * BPW) * 1024;
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
             glds16(b_ptr[i], __builtin_amdgcn_readfirstlane(dst + i * 1024));
@@ -114,43 +119,57 @@ __global__ __launch_bounds__(256) void igemm_halo_kernel(const omgsr_igemm_args 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int ncc = g.nk;                  // 32-channel chunks
-    const int nsteps = ncc * 9;
-    issue_a(0);
-    issue_b(0);
-    int after = 0;                         // DMA instructions issued after the slice the next wait needs
-    if (nsteps > 1) { issue_b(1); after = BPW; }
+    const int nsteps = ncc * 9;            // >= 9
 
-    // B fragment offsets (fixed): row = wn*64 + j*32 + (lane & 31)
+    // The first versions of this loop were instruction-issue bound (profiles/r01_pmc_igemm.md §6: 5.3 VALU +
+    // 4.4 SALU per MFMA, mostly LDS address arithmetic and tap bookkeeping). Everything is now static:
+    //   * the 9 taps are unrolled; the weight-ring stage of step (cc, tap) is tap % 3 because 9 % 3 == 0
+    //   * chunks are unrolled by 2 so the patch buffer parity is an immediate offset
+    //   * the swizzled LDS offset of each lane's A fragment is precomputed per (tap, tile row): 36 VGPRs;
+    //     the second half-K fragment is the same address ^ 32
     const int frow = lane & 31;
     const int half = lane >> 5;
     const int bsw = (frow >> 2) & 3;
-    const int boff0 = frow * 64 + ((half) ^ bsw) * 16;
-    const int boff1 = frow * 64 + ((2 + half) ^ bsw) * 16;
-    // A fragment base rows: tile row (4*wm + i), pixel (lane & 31)
-    const int arow0 = (4 * wm) * PW + frow;
+    const int boff0 = (wn * WTN) * 64 + frow * 64 + ((half) ^ bsw) * 16;
+    const int boff1 = (wn * WTN) * 64 + frow * 64 + ((2 + half) ^ bsw) * 16;
+    int aoff[9][FM];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = (4 * wm + i) * PW + frow + (tp / 3) * PW + (tp % 3);
+            aoff[tp][i] = row * 64 + ((half ^ ((row >> 2) & 3)) << 4);
+        }
 
-    int cc = 0, tap = 0, bstage = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        if (after == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (after == BPW) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    issue_a(0);
+    issue_b(0);
+    issue_b(1);
+
+    // one K-step with compile-time tap and patch parity
+    auto step = [&](auto tap_c, auto par_c, const int cc, const int s) {
+        constexpr int tap = decltype(tap_c)::value, par = decltype(par_c)::value;
+        // wait for slice s: only what the PREVIOUS step issued may still be in flight
+        if constexpr (tap == 1) {
+            if (cc + 1 < ncc) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else if constexpr (tap == 8) {
+            if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        after = 0;
-        if (tap == 0 && cc + 1 < ncc) { issue_a((cc + 1) & 1); after += APW; }
-        if (s + 2 < nsteps) { int s2 = bstage + 2; if (s2 >= NB) s2 -= NB; issue_b(s2); after += BPW; }
+        if constexpr (tap == 0) { if (cc + 1 < ncc) issue_a(par ^ 1); }
+        if (s + 2 < nsteps) issue_b((tap + 2) % NB);
 
-        const unsigned char* As = lds + (cc & 1) * A_BYTES;
-        const unsigned char* Bs = lds + 2 * A_BYTES + bstage * B_BYTES + (wn * WTN) * 64;
-        const int tr = tap / 3, tsft = tap - tr * 3;
-        const int toff = tr * PW + tsft;
+        const unsigned char* As = lds + par * A_BYTES;
+        const unsigned char* Bs = lds + B_OFF + (tap % NB) * B_BYTES;
         bf16x8_t af[2][FM], bf[2][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int row = arow0 + i * PW + toff;
-            const int sw = (row >> 2) & 3;
-            af[0][i] = *reinterpret_cast<const bf16x8_t*>(As + row * 64 + ((half ^ sw) << 4));
-            af[1][i] = *reinterpret_cast<const bf16x8_t*>(As + row * 64 + (((2 + half) ^ sw) << 4));
+            af[0][i] = *reinterpret_cast<const bf16x8_t*>(As + aoff[tap][i]);
+            af[1][i] = *reinterpret_cast<const bf16x8_t*>(As + (aoff[tap][i] ^ 32));
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -163,9 +182,22 @@ __global__ __launch_bounds__(256) void igemm_halo_kernel(const omgsr_igemm_args 
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);   // transposed tile
-
-        if (++bstage == NB) bstage = 0;
-        if (++tap == 9) { tap = 0; ++cc; }
+    };
+    auto chunk = [&](auto par_c, const int cc) {
+        const int s0 = cc * 9;
+        step(std::integral_constant<int, 0>{}, par_c, cc, s0 + 0);
+        step(std::integral_constant<int, 1>{}, par_c, cc, s0 + 1);
+        step(std::integral_constant<int, 2>{}, par_c, cc, s0 + 2);
+        step(std::integral_constant<int, 3>{}, par_c, cc, s0 + 3);
+        step(std::integral_constant<int, 4>{}, par_c, cc, s0 + 4);
+        step(std::integral_constant<int, 5>{}, par_c, cc, s0 + 5);
+        step(std::integral_constant<int, 6>{}, par_c, cc, s0 + 6);
+        step(std::integral_constant<int, 7>{}, par_c, cc, s0 + 7);
+        step(std::integral_constant<int, 8>{}, par_c, cc, s0 + 8);
+    };
+    for (int cc = 0; cc < ncc; cc += 2) {
+        chunk(std::integral_constant<int, 0>{}, cc);
+        if (cc + 1 < ncc) chunk(std::integral_constant<int, 1>{}, cc + 1);
     }
 
     int mb[FM], nv[FM];
