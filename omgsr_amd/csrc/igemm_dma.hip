@@ -25,17 +25,17 @@
 #include "../../include/omgsr_hip.h"
 #include "igemm_epilogue.hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int BK = 32;
-constexpr int BM = 256, BN = 128;
-constexpr int WGN = 2, WTN = 64, FN = 2;
+constexpr int BM = 256;
+constexpr int WTN = 64, FN = 2;
 constexpr int A_BYTES = BM * BK * 2;          // 16 KB
-constexpr int B_BYTES = BN * BK * 2;          //  8 KB
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
 constexpr int NSTAGE = 3;
-constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;   // 72 KB (>= the epilogue's 8 x 32 x 68 x 4 B)
+// BN = 64 * WGN: 128 (24 KB / stage, 12 KB of operands per MFLOP) or 256 (32 KB / stage, 8 KB per MFLOP)
+constexpr int lds_bytes(int wgn) { return NSTAGE * (A_BYTES + wgn * 64 * BK * 2); }
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
 
@@ -57,16 +57,19 @@ template <int N>
 OMGSR_DEVINL void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else static_assert(N == 0, "unsupported count");
 }
 
 // ABL (ablation, A/B runs only): 0 = the kernel; 1 = no DMA; 2 = DMA + ds_reads, no MFMA; 3 = DMA only
-template <int WGM, int ABL = 0>
+template <int WGM, int WGN, int ABL = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     constexpr int NW = WGM * WGN;              // waves
+    constexpr int BN = WGN * WTN;
+    constexpr int B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = NSTAGE * STAGE_BYTES;
     constexpr int WTM = BM / WGM, FM = WTM / 32;
-    constexpr int APW = 16 / NW, BPW = 8 / NW; // 1-KiB DMA pieces per wave per K-step (A: 16, B: 8 in total)
+    constexpr int APW = 16 / NW, BPW = (BN / 16) / NW; // 1-KiB DMA pieces per wave per K-step (A: 16, B: BN/16 in total)
     constexpr int PIECES = APW + BPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // LDS_BYTES, dynamic
 
@@ -75,8 +78,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
 
+    // L2-aware order: the XCD remap hands each XCD a contiguous id range; inside it ids walk 8 m-tiles before
+    // advancing n, so the ~64 workgroups resident on an XCD form an 8 x 8 super-tile sharing 8 A and 8 B panels
+    // (n-fastest order shared ONE A panel and streamed 64 distinct B panels: 14x the ideal HBM traffic on the
+    // Flux linears, profiles/r01_pmc_igemm.md §3)
     const int tile = xcd_remap(blockIdx.x, g.ntm * g.ntn);
-    const int tn = tile % g.ntn, tm = tile / g.ntn;
+    const int per_group = 8 * g.ntn;
+    const int grp = tile / per_group, in_grp = tile - grp * per_group;
+    const int first_m = grp * 8;
+    const int gsz = (g.ntm - first_m) < 8 ? (g.ntm - first_m) : 8;
+    const int tm = first_m + in_grp % gsz, tn = in_grp / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
     const int bz = blockIdx.z;
 
@@ -157,8 +168,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
     const int foff0 = frow * 64 + (((lane >> 5)) ^ fsw) * 16;        // ks = 0
     const int foff1 = frow * 64 + ((2 + (lane >> 5)) ^ fsw) * 16;    // ks = 1
 
-    int stage = 0;
-    for (int kt = 0; kt < g.nk; ++kt) {
+    // K loop unrolled by the ring depth: every LDS address (fragment reads, DMA destinations) is then a
+    // per-lane base + compile-time immediate; what is left per K-step is 3 pointer increments, the DMA
+    // issues, 12 ds_read_b128 and 16 MFMAs (the dynamic-stage version spent ~4 VALU + 5 SALU per MFMA).
+    const unsigned char* fa0 = lds + (wm * WTM) * 64 + foff0;
+    const unsigned char* fa1 = lds + (wm * WTM) * 64 + foff1;
+    const unsigned char* fb0 = lds + A_BYTES + (wn * WTN) * 64 + foff0;
+    const unsigned char* fb1 = lds + A_BYTES + (wn * WTN) * 64 + foff1;
+    auto kstep = [&](auto stage_c, const int kt) {
+        constexpr int stage = decltype(stage_c)::value;
         if constexpr (ABL != 1) {
             if (kt + 1 < g.nk) wait_vmcnt<PIECES>();
             else wait_vmcnt<0>();
@@ -166,24 +184,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (ABL != 1) {
-            if (kt + 2 < g.nk) {
-                int s2 = stage + 2; if (s2 >= NSTAGE) s2 -= NSTAGE;
-                issue(s2);
-            }
+            if (kt + 2 < g.nk) issue((stage + 2) % NSTAGE);
         }
-        if constexpr (ABL == 3) { if (++stage == NSTAGE) stage = 0; continue; }
-        const unsigned char* As = lds + stage * STAGE_BYTES + (wm * WTM) * 64;
-        const unsigned char* Bs = lds + stage * STAGE_BYTES + A_BYTES + (wn * WTN) * 64;
+        if constexpr (ABL == 3) return;
         bf16x8_t af[2][FM], bf[2][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            af[0][i] = *reinterpret_cast<const bf16x8_t*>(As + i * 32 * 64 + foff0);
-            af[1][i] = *reinterpret_cast<const bf16x8_t*>(As + i * 32 * 64 + foff1);
+            af[0][i] = *reinterpret_cast<const bf16x8_t*>(fa0 + stage * STAGE_BYTES + i * 32 * 64);
+            af[1][i] = *reinterpret_cast<const bf16x8_t*>(fa1 + stage * STAGE_BYTES + i * 32 * 64);
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            bf[0][j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 32 * 64 + foff0);
-            bf[1][j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 32 * 64 + foff1);
+            bf[0][j] = *reinterpret_cast<const bf16x8_t*>(fb0 + stage * STAGE_BYTES + j * 32 * 64);
+            bf[1][j] = *reinterpret_cast<const bf16x8_t*>(fb1 + stage * STAGE_BYTES + j * 32 * 64);
         }
         if constexpr (ABL == 2) {
 #pragma unroll
@@ -201,7 +214,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);   // transposed tile
         }
-        if (++stage == NSTAGE) stage = 0;
+    };
+    for (int kt = 0; kt < g.nk; kt += NSTAGE) {
+        kstep(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < g.nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
+        if (kt + 2 < g.nk) kstep(std::integral_constant<int, 2>{}, kt + 2);
     }
 
     static_assert(NW * 32 * (WTN + 4) * 4 <= LDS_BYTES, "epilogue staging must fit the ring");
@@ -209,17 +226,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
     igemm_epilogue_linear<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
 }
 
-template <int WGM, int ABL = 0>
-int launch_dma(const omgsr_igemm_args& a, const IgemmGeo& g, hipStream_t st) {
+template <int WGM, int WGN, int ABL = 0>
+int launch_dma(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    g.ntn = (logical_cols + WGN * WTN - 1) / (WGN * WTN);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<WGM, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<WGM, WGN, ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(WGN));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(g.ntm * g.ntn, 1, a.batch);
-    hipLaunchKernelGGL((igemm_dma_kernel<WGM, ABL>), grid, dim3(WGM * WGN * 64), LDS_BYTES, st, a, g);
+    hipLaunchKernelGGL((igemm_dma_kernel<WGM, WGN, ABL>), grid, dim3(WGM * WGN * 64), lds_bytes(WGN), st, a, g);
     return (int)hipGetLastError();
 }
 
@@ -230,13 +249,17 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     g.nk = a.K_pad / BK;
     g.ntm = (g.M + BM - 1) / BM;
-    g.ntn = (logical_cols + BN - 1) / BN;
-    static const char* shape = getenv("OMGSR_DMA_WAVES");      // "8" forces the 8-wave shape (A/B runs)
+    static const char* shape = getenv("OMGSR_DMA_WAVES");      // A/B runs: "8" = 8 waves of 64x64, "n128" = never use BN 256
     static const char* abl = getenv("OMGSR_DMA_ABLATE");      // timing experiments only: results are garbage
-    if (abl && abl[0] == '1') return launch_dma<2, 1>(a, g, st);
-    if (abl && abl[0] == '2') return launch_dma<2, 2>(a, g, st);
-    if (abl && abl[0] == '3') return launch_dma<2, 3>(a, g, st);
-    if (shape && shape[0] == '8') return launch_dma<4>(a, g, st);
-    return launch_dma<2>(a, g, st);
+    if (abl && abl[0] == '1') return launch_dma<2, 2, 1>(a, g, st);
+    if (abl && abl[0] == '2') return launch_dma<2, 2, 2>(a, g, st);
+    if (abl && abl[0] == '3') return launch_dma<2, 2, 3>(a, g, st);
+    if (shape && shape[0] == '8') return launch_dma<4, 2>(a, g, st);
+    // 256 x 256 tile (8 waves of 128x64): a third fewer operand bytes per FLOP; needs 256-row weight padding and
+    // enough tiles to fill the chip
+    const int64_t t256 = (int64_t)g.ntm * ((logical_cols + 255) / 256) * a.batch;
+    if (!(shape && shape[0] == 'n') && (a.Cout_pad % 256) == 0 && logical_cols >= 256 && t256 >= 200)
+        return launch_dma<2, 4>(a, g, st);
+    return launch_dma<2, 2>(a, g, st);
 }
 }  // namespace omgsr

@@ -84,7 +84,7 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
         w = torch.nn.functional.pad(w, (0, cin8 - cin))
     w = w.reshape(cout, R * S * cin8)
     k_pad = _round_up(w.shape[1], 32)
-    cout_pad = _round_up(cout, 128)
+    cout_pad = _round_up(cout, 256 if cout >= 256 else 128)   # 256-row padding lets the 256x256 GEMM tile run
     out = torch.zeros(cout_pad, k_pad, device=dev, dtype=torch.bfloat16)
     out[:cout, : w.shape[1]] = w.to(torch.bfloat16)
     b = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
