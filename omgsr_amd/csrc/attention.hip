@@ -134,36 +134,42 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
                 s[sb] = mfma32(kf, qf[ks], s[sb]);
             }
         }
-        // online softmax (one query per lane pair)
+        // online softmax (one query per lane pair), base 2. The raw scores stay unscaled: the row maximum is
+        // taken on them (scale > 0), and p = exp2(fma(s, sc, -m*sc)) folds scale, max-subtract and the base change
+        // into ONE fma + v_exp_f32 per score. The O / l rescale is skipped when no row of the wave saw its
+        // maximum move (the common case after the first tiles).
         const bool tail = (kt == ntiles - 1) && (p.Lk & 63);
         float mt = -INFINITY;
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = s[sb][r] * sc;
-                if (tail && (kt * 64 + 32 * sb + cfrag_row(lane, r) >= p.Lk)) v = -INFINITY;
-                s[sb][r] = v;
-                mt = fmaxf(mt, v);
+                if (tail && (kt * 64 + 32 * sb + cfrag_row(lane, r) >= p.Lk)) s[sb][r] = -INFINITY;
+                mt = fmaxf(mt, s[sb][r]);
             }
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        const float neg_m = -m_new * sc;
+        const bool moved = m_new != m_run;
         float rs = 0.0f;
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(s[sb][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[sb][r], sc, neg_m));
                 s[sb][r] = e;
                 rs += e;
             }
-        l_run = l_run * alpha + rs;
+        if (__any(moved)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);    // m_run = -inf on the first tile -> 0
+            l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < NDB; ++i)
+            for (int i = 0; i < NDB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        m_run = m_new;
+        l_run += rs;
 
         // P^T operand: score registers converted in place (key permutation, see header)
         bf16x8_t pf[2][2];
