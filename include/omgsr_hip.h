@@ -77,8 +77,12 @@ typedef struct omgsr_igemm_args {
     float alpha;
     const void* weight_cm; /* optional second packing of a 3x3 weight, chunk-major K order
                               k = ((c/32)*9 + r*3+s)*32 + c%32 (Cin % 32 == 0): enables the halo-tile kernel | NULL */
+    void* workspace;       /* split-K scratch (f32), omgsr_igemm_workspace_bytes() bytes | NULL = never split */
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
+/* Bytes of `workspace` that would let omgsr_igemm split the contraction of a small-M / large-K problem over
+ * several workgroups (fp32 partial tiles + a reduce pass that applies the epilogue); 0 = no split for this shape. */
+int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* a);
 
 /*
  * K4 — GroupNorm statistics and apply (replaces F.group_norm; the externally supplied

@@ -169,7 +169,7 @@ inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)((tot
 
 }  // namespace
 
-extern "C" int omgsr_abi_version(void) { return 4; }
+extern "C" int omgsr_abi_version(void) { return 5; }
 
 extern "C" int omgsr_check_device(void) {
     int dev = 0;

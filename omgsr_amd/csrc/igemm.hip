@@ -177,7 +177,82 @@ int launch(const omgsr_igemm_args& a, Geo g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// split-K reduce: out[m][n] = epilogue(sum_s partial[s][m][n]); one thread per 8 output channels.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_args p, const float* __restrict__ ws, const int M,
+                                                            const int ldw, const int splits) {
+    const bool geglu = (p.act == OMGSR_ACT_GEGLU);
+    const int oct_per_row = (p.Cout + 7) >> 3;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * oct_per_row) return;
+    const int m = (int)(i / oct_per_row), n = (int)(i - (int64_t)m * oct_per_row) * 8;
+    float v[8];
+    if (geglu) {
+        // packed columns: output n..n+7 <- a at (n/32)*64 + n%32, gate 32 further
+        const int pc = (n >> 5) * 64 + (n & 31);
+        float a[8], gt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = 0.0f; gt[e] = 0.0f; }
+        for (int sidx = 0; sidx < splits; ++sidx) {
+            const float* r = ws + ((int64_t)sidx * M + m) * ldw + pc;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[e] += r[e]; gt[e] += r[32 + e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = a[e] * p.alpha, y = gt[e] * p.alpha;
+            if (p.bias) { x += p.bias[pc + e]; y += p.bias[pc + 32 + e]; }
+            v[e] = x * gelu_erf_f(y);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        for (int sidx = 0; sidx < splits; ++sidx) {
+            const float* r = ws + ((int64_t)sidx * M + m) * ldw + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = v[e] * p.alpha;
+            if (p.bias && n + e < p.Cout) x += p.bias[n + e];
+            if (p.act == OMGSR_ACT_SILU) x = silu_f(x);
+            else if (p.act == OMGSR_ACT_GELU_TANH) x = gelu_tanh_f(x);
+            v[e] = x;
+        }
+    }
+    const int64_t ldo = p.out_ld > 0 ? p.out_ld : p.Cout;
+    for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
+        float x = v[e];
+        if (p.gate) x *= p.gate[n + e];
+        if (p.residual) x += (float)((const bf16_t*)p.residual)[(int64_t)m * p.Cout + n + e];
+        if (p.out_dtype == OMGSR_OUT_BF16) ((bf16_t*)p.out)[(int64_t)m * ldo + n + e] = (bf16_t)x;
+        else ((float*)p.out)[(int64_t)m * ldo + n + e] = x;
+    }
+}
+
+// Split-K policy: small-M problems whose 256x128 tiles cannot fill the 256 CUs but whose contraction is long.
+int splitk_plan(const omgsr_igemm_args& a, int64_t M64) {
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || logical_cols < 96) return 1;
+    const int nk = a.K_pad / 32;
+    const int64_t tiles = ((M64 + 255) / 256) * ((logical_cols + 127) / 128);
+    if (tiles >= 128 || nk < 48) return 1;
+    int splits = (int)(256 / tiles);
+    if (splits > 8) splits = 8;
+    while (splits > 1 && nk / splits < 16) --splits;
+    return splits < 2 ? 1 : splits;
+}
+
 }  // namespace
+
+extern "C" int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* ap) {
+    if (!ap) return 0;
+    const int64_t M64 = (int64_t)ap->N * ap->Ho * ap->Wo;
+    const int splits = splitk_plan(*ap, M64);
+    if (splits < 2) return 0;
+    const int logical_cols = (ap->act == OMGSR_ACT_GEGLU) ? 2 * ap->Cout : ap->Cout;
+    return (int64_t)splits * M64 * (((logical_cols + 127) / 128) * 128) * 4;
+}
 
 extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     if (!ap || !ap->in || !ap->weight || !ap->out) return OMGSR_E_BADARG;
@@ -210,6 +285,20 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     // Large problems: LDS-DMA kernel (256x128 tile, 3-stage ring). OMGSR_IGEMM_MODE=reg|dma overrides (A/B runs).
     static const char* mode = getenv("OMGSR_IGEMM_MODE");
     const int64_t tiles256 = ((M64 + 255) / 256) * ((logical_cols + 127) / 128) * a.batch;
+    g.splits = 1; g.nk_total = g.nk;
+    if (a.workspace && !(mode && (!strcmp(mode, "reg") || !strcmp(mode, "halo")))) {
+        const int splits = splitk_plan(a, M64);
+        if (splits > 1) {
+            g.splits = splits;
+            const int rc = omgsr::igemm_dma_launch(a, g, st);
+            if (rc != 0) return rc;
+            const int ldw = ((logical_cols + 127) / 128) * 128;
+            const int64_t items = M64 * ((a.Cout + 7) / 8);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a,
+                               (const float*)a.workspace, (int)M64, ldw, splits);
+            return (int)hipGetLastError();
+        }
+    }
     // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
     const bool halo_ok = a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 &&
                          !a.upsample && (a.Cin % 32) == 0 && a.batch == 1 && a.Ho == a.H && a.Wo == a.W && a.W >= 16 &&

@@ -115,27 +115,33 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
             a_img[i] = -1; a_vy0[i] = 0; a_vx0[i] = 0;
         }
     }
+    // split-K: blockIdx.y owns K-steps [ks0, ks0 + nk) and writes an fp32 partial tile to the workspace
+    const int ks0 = blockIdx.y * g.nk;
+    const int nk = (g.nk_total - ks0) < g.nk ? (g.nk_total - ks0) : g.nk;
     const unsigned char* b_ptr[BPW];
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
-        b_ptr[i] = reinterpret_cast<const unsigned char*>(wt + (int64_t)(n0 + 16 * (wave * BPW + i) + lrow) * p.K_pad + kc * 8);
+        b_ptr[i] = reinterpret_cast<const unsigned char*>(wt + (int64_t)(n0 + 16 * (wave * BPW + i) + lrow) * p.K_pad + kc * 8 + (int64_t)ks0 * BK);
     const unsigned char* a_ptr[APW];
     int a_inc[APW];
     const int steps_per_tap = p.Cin / BK;
-    int kin = 0, tap_r = 0, tap_s = 0;       // wave-uniform cursor of the NEXT step to issue
+    int kin = ks0 % steps_per_tap;           // wave-uniform cursor of the NEXT step to issue
+    int tap_r = (ks0 / steps_per_tap) / p.S, tap_s = (ks0 / steps_per_tap) % p.S;
+    bool fresh = true;                       // the first issue of a split may start in the middle of a tap
 
     auto issue = [&](int stage) {
-        if (kin == 0) {
+        if (kin == 0 || fresh) {
 #pragma unroll
             for (int i = 0; i < APW; ++i) {
                 const int vy = a_vy0[i] + tap_r, vx = a_vx0[i] + tap_s;
                 const bool ok = a_img[i] >= 0 && (unsigned)vy < (unsigned)g.Hv && (unsigned)vx < (unsigned)g.Wv;
                 const int iy = vy >> p.upsample, ix = vx >> p.upsample;
                 const int64_t pix = ((int64_t)a_img[i] * p.H + iy) * p.W + ix;
-                a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * p.Cin + kc * 8)
+                a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * p.Cin + kc * 8 + kin * BK)
                               : reinterpret_cast<const unsigned char*>(g_zero_page);
                 a_inc[i] = ok ? BK * 2 : 0;
             }
+            fresh = false;
         }
         const unsigned sa = lds_base + stage * STAGE_BYTES + (16 * wave * APW) * 64;
         const unsigned sb = lds_base + stage * STAGE_BYTES + A_BYTES + (16 * wave * BPW) * 64;
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    if constexpr (ABL != 1) { issue(0); if (g.nk > 1) issue(1); }
+    if constexpr (ABL != 1) { issue(0); if (nk > 1) issue(1); }
 
     // fragment read offsets (swizzled): row = base + (lane & 31); chunk = 2*ks + (lane >> 5)
     const int frow = lane & 31;
@@ -178,13 +184,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
     auto kstep = [&](auto stage_c, const int kt) {
         constexpr int stage = decltype(stage_c)::value;
         if constexpr (ABL != 1) {
-            if (kt + 1 < g.nk) wait_vmcnt<PIECES>();
+            if (kt + 1 < nk) wait_vmcnt<PIECES>();
             else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (ABL != 1) {
-            if (kt + 2 < g.nk) issue((stage + 2) % NSTAGE);
+            if (kt + 2 < nk) issue((stage + 2) % NSTAGE);
         }
         if constexpr (ABL == 3) return;
         bf16x8_t af[2][FM], bf[2][FN];
@@ -215,14 +221,24 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
                     for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);   // transposed tile
         }
     };
-    for (int kt = 0; kt < g.nk; kt += NSTAGE) {
+    for (int kt = 0; kt < nk; kt += NSTAGE) {
         kstep(std::integral_constant<int, 0>{}, kt);
-        if (kt + 1 < g.nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
-        if (kt + 2 < g.nk) kstep(std::integral_constant<int, 2>{}, kt + 2);
+        if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
+        if (kt + 2 < nk) kstep(std::integral_constant<int, 2>{}, kt + 2);
     }
 
     static_assert(NW * 32 * (WTN + 4) * 4 <= LDS_BYTES, "epilogue staging must fit the ring");
     float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
+    if (g.splits > 1) {
+        // raw fp32 partial [split][M][ntn*BN]; bias / activation / residual run in the split-K reduce kernel
+        omgsr_igemm_args q = p;
+        const int ldw = g.ntn * BN;
+        q.out = (float*)p.workspace + (int64_t)blockIdx.y * g.M * ldw;
+        q.out_dtype = OMGSR_OUT_F32; q.out_layout = OMGSR_LAYOUT_NHWC; q.out_ld = ldw; q.Cout = ldw;
+        q.bias = nullptr; q.gate = nullptr; q.residual = nullptr; q.act = OMGSR_ACT_NONE; q.alpha = 1.0f;
+        igemm_epilogue_linear<WTN, FM, FN>(q, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, 0);
+        return;
+    }
     igemm_epilogue_linear<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
 }
 
@@ -237,7 +253,7 @@ int launch_dma(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid(g.ntm * g.ntn, 1, a.batch);
+    dim3 grid(g.ntm * g.ntn, g.splits, a.batch);
     hipLaunchKernelGGL((igemm_dma_kernel<WGM, WGN, ABL>), grid, dim3(WGM * WGN * 64), lds_bytes(WGN), st, a, g);
     return (int)hipGetLastError();
 }
@@ -247,8 +263,14 @@ int launch_dma(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
 namespace omgsr {
 int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
-    g.nk = a.K_pad / BK;
+    g.nk_total = a.K_pad / BK;
     g.ntm = (g.M + BM - 1) / BM;
+    if (g.splits > 1) {                        // split-K always runs the 256 x 128 tile (see igemm_splitk_plan)
+        g.nk = (g.nk_total + g.splits - 1) / g.splits;
+        return launch_dma<2, 2>(a, g, st);
+    }
+    g.splits = 1;
+    g.nk = g.nk_total;
     static const char* shape = getenv("OMGSR_DMA_WAVES");      // A/B runs: "8" = 8 waves of 64x64, "n128" = never use BN 256
     static const char* abl = getenv("OMGSR_DMA_ABLATE");      // timing experiments only: results are garbage
     if (abl && abl[0] == '1') return launch_dma<2, 2, 1>(a, g, st);

@@ -149,6 +149,8 @@ struct IgemmGeo {
     int M;          // N*Ho*Wo rows per batch entry
     int HoWo;
     int Hv, Wv;     // virtual (post-upsample) input extent
-    int nk;         // K steps
+    int nk;         // K steps (per split)
+    int nk_total;   // K steps of the whole contraction
+    int splits;     // split-K factor (1 = none)
     int ntm, ntn;   // tile counts
 };

@@ -42,6 +42,17 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def _igemm(a: "IgemmArgs", device, what: str) -> None:
+    """Launch omgsr_igemm; when the library wants to split K (small-M / long-K problems) hand it an fp32 scratch."""
+    lib = _lib.load()
+    need = lib.omgsr_igemm_workspace_bytes(C.byref(a))
+    ws = None
+    if need > 0:
+        ws = torch.empty(need // 4, device=device, dtype=torch.float32)
+        a.workspace = ws.data_ptr()
+    check(lib.omgsr_igemm(C.byref(a), _stream()), what)
+
+
 # --------------------------------------------------------------------------------------------
 # weight packing (load time)
 
@@ -159,7 +170,7 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     a.t_rows, a.t_ld = 0, 0
     a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
     a.alpha = alpha
-    check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(conv2d)")
+    _igemm(a, x.device, "omgsr_igemm(conv2d)")
     return out
 
 
@@ -199,7 +210,7 @@ def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int,
     a.act, a.out_dtype, a.out_layout = act, OUT_BF16, LAYOUT_NHWC
     a.out_ld = ld
     a.batch, a.alpha = 1, 1.0
-    check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_into)")
+    _igemm(a, x.device, "omgsr_igemm(linear_into)")
 
 
 def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: int) -> None:

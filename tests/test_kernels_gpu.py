@@ -149,6 +149,33 @@ def test_linear_transposed_out():
     assert (yt[:, :, L:] == 0).all()
 
 
+def test_split_k_paths():
+    """Small-M / long-K problems are split over K (fp32 partial tiles + reduce pass with the full epilogue)."""
+    ops = _ops()
+    M, K, Nout = 300, 3072, 384
+    x = rnd(1, M, K, seed=70)
+    w = rnd(Nout, K, seed=71, scale=K ** -0.5)
+    b, gate, res = rnd(Nout, seed=72), rnd(Nout, seed=73), rnd(1, M, Nout, seed=74)
+    pw = ops.pack_linear_weight(w, b, device=DEV)
+    from omgsr_amd import _lib
+    import ctypes
+    y = ops.linear(bf(x).to(DEV), pw, act=ops.ACT_GELU_TANH, gate=gate.to(DEV), residual=bf(res).to(DEV))
+    assert_close(y, res + gate * F.gelu(F.linear(x, w, b), approximate="tanh"), "split-K gelu+gate+residual")
+    y32 = ops.linear(bf(x).to(DEV), pw, out_dtype=ops.OUT_F32, alpha=0.5)
+    assert_close(y32, 0.5 * F.linear(x, w) + b, "split-K f32", rel_l2=1e-5, max_ulps=0.05)
+    inner = 640
+    wg = rnd(2 * inner, 2048, seed=75, scale=2048 ** -0.5)
+    bg = rnd(2 * inner, seed=76, scale=0.1)
+    xg = rnd(1, 200, 2048, seed=77)
+    h = F.linear(xg, wg, bg)
+    a_, g_ = h.chunk(2, dim=-1)
+    assert_close(ops.linear(bf(xg).to(DEV), ops.pack_geglu_weight(wg, bg, device=DEV)), a_ * F.gelu(g_), "split-K geglu")
+    # the policy really splits these shapes
+    a = _lib.IgemmArgs()
+    a.N, a.Ho, a.Wo, a.Cin, a.Cout, a.K_pad, a.batch, a.act, a.out_layout = 1, 1, M, K, Nout, K, 1, 0, 0
+    assert _lib.load().omgsr_igemm_workspace_bytes(ctypes.byref(a)) > 0
+
+
 def test_linear_into_slices():
     """Projections written straight into slices of joint buffers (Flux joint sequence / [attn|mlp] concat)."""
     ops = _ops()
