@@ -29,6 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+WDTYPE = torch.bfloat16          # --weight-dtype (the reference's --weight_dtype): bf16 (default) or fp16, same MFMA rate
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: 2.5 PF, measured 2495 TF)
 
 WORKLOADS = {
@@ -47,6 +48,7 @@ def parse():
     # default = the first "1k out" configuration of BASELINE.json's metric that fits one GPU (configs[2])
     ap.add_argument("--workload", default=os.environ.get("OMGSR_BENCH_WORKLOAD", "s1024"), choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = workload default)")
+    ap.add_argument("--weight-dtype", default="bf16", choices=["bf16", "fp16"], help="the kernels' 16-bit element type")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-tiled-vae", action="store_true", help="s1024 only: run the VAE untiled (the reference's shipped default)")
@@ -63,8 +65,8 @@ def build_s(device, rank, world):
     else:   # peers allocate uninitialised HBM and receive rank 0's weights over RCCL
         with torch.device("meta"):
             vae, unet = AutoencoderKL(), UNet2DConditionModel()
-        vae, unet = vae.to_empty(device=device).to(torch.bfloat16), unet.to_empty(device=device).to(torch.bfloat16)
-    pipe = OMGSR_S_Infer(None, None, 273, device, torch.bfloat16, vae=vae, unet=unet)
+        vae, unet = vae.to_empty(device=device).to(WDTYPE), unet.to_empty(device=device).to(WDTYPE)
+    pipe = OMGSR_S_Infer(None, None, 273, device, WDTYPE, vae=vae, unet=unet)
     moved = D.broadcast_module_(pipe.vae) + D.broadcast_module_(pipe.unet)   # RCCL over xGMI (no-op at N=1)
     if not (D.replicas_identical(pipe.vae) and D.replicas_identical(pipe.unet)):
         raise RuntimeError("weight replicas differ after broadcast")
@@ -79,15 +81,15 @@ def build_f(device, rank, world):
     from omgsr_amd.testing import seeded_init_, seeded_init_device_
     with torch.device("meta"):
         flux = FluxTransformer2DModel()
-    flux = flux.to_empty(device=device).to(torch.bfloat16)
+    flux = flux.to_empty(device=device).to(WDTYPE)
     if rank == 0 or world == 1:
         vae = seeded_init_(AutoencoderKL(**FLUX_VAE_CONFIG), 303)
         seeded_init_device_(flux, 404)
     else:
         with torch.device("meta"):
             vae = AutoencoderKL(**FLUX_VAE_CONFIG)
-        vae = vae.to_empty(device=device).to(torch.bfloat16)
-    pipe = OMGSR_F_Infer(None, None, device, torch.bfloat16, 244, 1.0, vae=vae, flux_transformer=flux)
+        vae = vae.to_empty(device=device).to(WDTYPE)
+    pipe = OMGSR_F_Infer(None, None, device, WDTYPE, 244, 1.0, vae=vae, flux_transformer=flux)
     moved = D.broadcast_module_(pipe.vae) + D.broadcast_module_(pipe.flux_transformer)
     if not (D.replicas_identical(pipe.vae) and D.replicas_identical(pipe.flux_transformer)):
         raise RuntimeError("weight replicas differ after broadcast")
@@ -120,6 +122,8 @@ def collect_roofline(lib_mod):
 
 def main():
     args = parse()
+    global WDTYPE
+    WDTYPE = torch.bfloat16 if args.weight_dtype == "bf16" else torch.float16
     from omgsr_amd import _lib, dist as D
     from omgsr_amd.testing import psnr, rel_l2, synthetic_lq
 
@@ -150,16 +154,16 @@ def main():
     eps_cpu = torch.randn(B, lat_c, side // 8, side // 8, generator=torch.Generator().manual_seed(99 + rank))
     pipe.vae.posterior_noise = eps_cpu.to(device)
     if family == "S":
-        prompt = torch.randn(1, 77, 1024, generator=g).to(torch.bfloat16).to(device)
+        prompt = torch.randn(1, 77, 1024, generator=g).to(WDTYPE).to(device)
 
         def step():
             return pipe.sr_nhwc(lq, prompt, tile, overlap)
     else:
         from omgsr_amd.pipelines.omgsr_f import prepare_latent_image_ids
-        prompt = torch.randn(1, 512, 4096, generator=g).to(torch.bfloat16).to(device)
-        pooled = torch.randn(1, 768, generator=g).to(torch.bfloat16).to(device)
-        text_ids = torch.zeros(512, 3, device=device, dtype=torch.bfloat16)
-        image_ids = prepare_latent_image_ids(tile // 2, tile // 2, device, torch.bfloat16)
+        prompt = torch.randn(1, 512, 4096, generator=g).to(WDTYPE).to(device)
+        pooled = torch.randn(1, 768, generator=g).to(WDTYPE).to(device)
+        text_ids = torch.zeros(512, 3, device=device, dtype=WDTYPE)
+        image_ids = prepare_latent_image_ids(tile // 2, tile // 2, device, WDTYPE)
 
         def step():
             return pipe.sr_nhwc(lq, prompt, pooled, text_ids, image_ids, tile, overlap)
@@ -208,8 +212,8 @@ def main():
         line = {
             "metric": "SR images/sec", "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"OMGSR-{family} {side // 4}->{side}, batch={B}/GPU, bf16, seeded random weights at {'SD2.1-base' if family == 'S' else 'FLUX.1-dev'} shapes"
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if WDTYPE == torch.bfloat16 else "fp16", "data": "synthetic",
+            "config": {"workload": f"OMGSR-{family} {side // 4}->{side}, batch={B}/GPU, {'bf16' if WDTYPE == torch.bfloat16 else 'fp16'}, seeded random weights at {'SD2.1-base' if family == 'S' else 'FLUX.1-dev'} shapes"
                                    + (", tiled VAE (VAEHook enc 256 / dec 64)" if tiled_vae else ""),
                        "global_batch": B * world, "latent_tile": tile, "tile_overlap": overlap, "mid_timestep": 273 if family == "S" else 244,
                        "parallelism": f"dp{world} (images sharded, RCCL weight broadcast {moved >> 20} MiB)"},

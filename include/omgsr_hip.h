@@ -41,6 +41,17 @@ extern "C" {
 #define OMGSR_LAYOUT_NHWC 0   /* out[m][n]                                                        */
 #define OMGSR_LAYOUT_T 1      /* out[(m / t_rows) * Cout + n][m % t_rows] with row stride t_ld     */
 
+#define OMGSR_DT_BF16 0
+#define OMGSR_DT_F16 1
+/*
+ * 16-bit element type of every activation / weight tensor the library touches (fp32 accumulation and
+ * statistics either way). bf16 is the reference's default --weight_dtype; fp16 is its other 16-bit option
+ * (infer/infer_omgsr_s.py:134-149): same MFMA rate, 10-bit mantissa (rel-L2 vs the fp32 oracle ~8x lower),
+ * narrower range. Process-wide: set it before packing weights and keep it for the lifetime of those buffers.
+ */
+int omgsr_set_compute_dtype(int dtype);
+int omgsr_get_compute_dtype(void);
+
 /* ABI version: bump on any struct change. */
 int omgsr_abi_version(void);
 /* 0 when the current device is gfx950, OMGSR_E_ARCH otherwise. */

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class OmgsrError(RuntimeError):
@@ -59,6 +59,8 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "omgsr_abi_version": (C.c_int, []),
     "omgsr_check_device": (C.c_int, []),
+    "omgsr_set_compute_dtype": (C.c_int, [C.c_int]),
+    "omgsr_get_compute_dtype": (C.c_int, []),
     "omgsr_error_string": (C.c_char_p, [C.c_int]),
     "omgsr_igemm": (C.c_int, [C.POINTER(IgemmArgs), _P]),
     "omgsr_igemm_workspace_bytes": (C.c_int64, [C.POINTER(IgemmArgs)]),

@@ -24,7 +24,7 @@
 
 namespace {
 
-template <int D>
+template <typename T, int D>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, const int ntiles) {
     constexpr int KP = 2 * D + 16;
     constexpr int VP = 136;
@@ -41,17 +41,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     const int b = blockIdx.z, h = blockIdx.y;
     const int q0 = blockIdx.x * 128 + wave * 32;
 
-    const bf16_t* __restrict__ qp = (const bf16_t*)p.q + (int64_t)b * p.q_bstride + h * D;
-    const bf16_t* __restrict__ kp = (const bf16_t*)p.k + (int64_t)b * p.k_bstride + h * D;
-    const bf16_t* __restrict__ vp = (const bf16_t*)p.vt + (int64_t)b * p.vt_bstride + (int64_t)h * D * p.vt_ld;
+    const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_bstride + h * D;
+    const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_bstride + h * D;
+    const T* __restrict__ vp = (const T*)p.vt + (int64_t)b * p.vt_bstride + (int64_t)h * D * p.vt_ld;
 
     // Q^T operand fragments live in registers for the whole sweep
-    bf16x8_t qf[NKS];
+    x8_t<T> qf[NKS];
     {
         int qrow = q0 + l31; if (qrow > p.Lq - 1) qrow = p.Lq - 1;
-        const bf16_t* qr = qp + (int64_t)qrow * p.q_ld + 8 * half;
+        const T* qr = qp + (int64_t)qrow * p.q_ld + 8 * half;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qr + 16 * ks);
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const x8_t<T>*>(qr + 16 * ks);
     }
 
     u32x4_t kreg[NKC], vreg[NVC];
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
             const unsigned char* kr = Ks + (32 * sb + l31) * KP + half * 16;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
+                const x8_t<T> kf = *reinterpret_cast<const x8_t<T>*>(kr + ks * 32);
                 s[sb] = mfma32(kf, qf[ks], s[sb]);
             }
         }
@@ -172,13 +172,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
         l_run += rs;
 
         // P^T operand: score registers converted in place (key permutation, see header)
-        bf16x8_t pf[2][2];
+        x8_t<T> pf[2][2];
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[sb][u][j] = (bf16_t)s[sb][8 * u + j];
+                for (int j = 0; j < 8; ++j) pf[sb][u][j] = (T)s[sb][8 * u + j];
 
         // O^T += V^T P^T
 #pragma unroll
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
                     const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(a);
                     const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(a + 16);
                     const u32x4_t both = {lo[0], lo[1], hi[0], hi[1]};
-                    o[db] = mfma32(*reinterpret_cast<const bf16x8_t*>(&both), pf[sb][u], o[db]);
+                    o[db] = mfma32(*reinterpret_cast<const x8_t<T>*>(&both), pf[sb][u], o[db]);
                 }
         }
         if (kt + 1 < ntiles) write_tile(buf ^ 1);
@@ -203,14 +203,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + l31;
     if (qrow < p.Lq) {
-        bf16_t* op = (bf16_t*)p.o + (int64_t)b * p.o_bstride + (int64_t)qrow * p.o_ld + h * D + 4 * half;
+        T* op = (T*)p.o + (int64_t)b * p.o_bstride + (int64_t)qrow * p.o_ld + h * D + 4 * half;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2_t w;
-                w[0] = pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
-                w[1] = pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                w[0] = pack2<T>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+                w[1] = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
                 *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g) = w;
             }
     }
@@ -221,14 +221,16 @@ int launch_attn(const omgsr_attn_args& a, hipStream_t st) {
     constexpr int LDS = 2 * (64 * (2 * D + 16) + D * 136);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<D>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<bf16_t, D>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<f16_t, D>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int ntiles = (a.Lk + 63) / 64;
     dim3 grid((a.Lq + 127) / 128, a.H, a.B);
-    hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), LDS, st, a, ntiles);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL((attn_kernel<T, D>), grid, dim3(256), LDS, st, a, ntiles));
     return (int)hipGetLastError();
 }
 

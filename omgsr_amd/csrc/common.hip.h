@@ -11,6 +11,22 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// The 16-bit element type T of activations / weights is a template parameter of every kernel:
+// bf16 (the reference's default --weight_dtype) or fp16 (its other 16-bit option: same MFMA rate, 10-bit
+// mantissa). The library-wide choice is omgsr_set_compute_dtype(); fp32 accumulation either way.
+typedef _Float16 f16_t;
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <typename T> struct vec8;
+template <> struct vec8<bf16_t> { typedef bf16x8_t type; };
+template <> struct vec8<f16_t> { typedef f16x8_t type; };
+template <typename T> using x8_t = typename vec8<T>::type;
+namespace omgsr { int compute_dtype(); }     // 0 = bf16, 1 = fp16 (elementwise.hip)
+#define OMGSR_DISPATCH_T(...)                                               \
+    do {                                                                    \
+        if (omgsr::compute_dtype() == 1) { using T = f16_t; __VA_ARGS__; }  \
+        else { using T = bf16_t; __VA_ARGS__; }                             \
+    } while (0)
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -22,29 +38,50 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 OMGSR_DEVINL f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+OMGSR_DEVINL f32x16_t mfma32(f16x8_t a, f16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 // row index inside a 32x32 C fragment held by (lane, reg)
 OMGSR_DEVINL int cfrag_row(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 OMGSR_DEVINL float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
 
-OMGSR_DEVINL void unpack8(const u32x4_t v, float (&f)[8]) {
+template <typename T> OMGSR_DEVINL void unpack8(const u32x4_t v, float (&f)[8]);
+template <> OMGSR_DEVINL void unpack8<bf16_t>(const u32x4_t v, float (&f)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         f[2 * i] = __uint_as_float(v[i] << 16);
         f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
     }
 }
+template <> OMGSR_DEVINL void unpack8<f16_t>(const u32x4_t v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned int w = v[i];
+        const f16x2_t h = *reinterpret_cast<const f16x2_t*>(&w);
+        f[2 * i] = (float)h[0];
+        f[2 * i + 1] = (float)h[1];
+    }
+}
 
-OMGSR_DEVINL unsigned int pack2(float lo, float hi) {
+template <typename T> OMGSR_DEVINL unsigned int pack2(float lo, float hi);
+template <> OMGSR_DEVINL unsigned int pack2<bf16_t>(float lo, float hi) {
     bf16x2_t r = __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t);
     return *reinterpret_cast<unsigned int*>(&r);
 }
+template <> OMGSR_DEVINL unsigned int pack2<f16_t>(float lo, float hi) {
+    // saturate instead of overflowing to inf (what diffusers' fp16 paths do with clip(-65504, 65504))
+    lo = __builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f);
+    hi = __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f);
+    f16x2_t r = __builtin_convertvector((f32x2_t){lo, hi}, f16x2_t);
+    return *reinterpret_cast<unsigned int*>(&r);
+}
 
-OMGSR_DEVINL u32x4_t pack8(const float (&f)[8]) {
+template <typename T> OMGSR_DEVINL u32x4_t pack8(const float (&f)[8]) {
     u32x4_t v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = pack2(f[2 * i], f[2 * i + 1]);
+    for (int i = 0; i < 4; ++i) v[i] = pack2<T>(f[2 * i], f[2 * i + 1]);
     return v;
 }
 

@@ -7,15 +7,17 @@
 
 namespace omgsr {
 TimingState& timing_state() { static TimingState s; return s; }
+static int g_compute_dtype = 0;
+int compute_dtype() { return g_compute_dtype; }
 }
 
 namespace {
 
-OMGSR_DEVINL float bf16_round(float x) { return (float)(bf16_t)x; }
+template <typename T> OMGSR_DEVINL float round_to(float x) { return (float)(T)x; }
 
 // NCHW -> NHWC(Cpad) bf16. One thread per output pixel-channel-group of 8.
-template <typename SRC>
-__global__ void nchw_to_nhwc_kernel(const SRC* __restrict__ src, bf16_t* __restrict__ dst, int N, int C, int64_t HW, int Cpad) {
+template <typename SRC, typename T>
+__global__ void nchw_to_nhwc_kernel(const SRC* __restrict__ src, T* __restrict__ dst, int N, int C, int64_t HW, int Cpad) {
     const int ng = Cpad >> 3;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)N * HW * ng;
@@ -30,12 +32,12 @@ __global__ void nchw_to_nhwc_kernel(const SRC* __restrict__ src, bf16_t* __restr
         const int c = g * 8 + e;
         f[e] = (c < C) ? (float)src[((int64_t)n * C + c) * HW + hw] : 0.0f;
     }
-    *reinterpret_cast<u32x4_t*>(dst + pix * Cpad + g * 8) = pack8(f);
+    *reinterpret_cast<u32x4_t*>(dst + pix * Cpad + g * 8) = pack8<T>(f);
 }
 
 // NHWC(ld) bf16 -> NCHW. Thread per (n, c, hw) element; hw fastest => coalesced writes.
-template <typename DST>
-__global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ src, DST* __restrict__ dst, int N, int C, int64_t HW, int ld,
+template <typename DST, typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, DST* __restrict__ dst, int N, int C, int64_t HW, int ld,
                                     int do_clamp, float lo, float hi) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)N * C * HW;
@@ -61,7 +63,8 @@ __global__ void copy_channels_kernel(const bf16_t* __restrict__ src, bf16_t* __r
 }
 
 // z = ((mu + exp(0.5*clamp(logvar,-30,20)) * eps) - shift) * scale, fp32 math, one rounding.
-__global__ void vae_sample_kernel(const bf16_t* __restrict__ mom, const float* __restrict__ eps, bf16_t* __restrict__ z, int64_t rows,
+template <typename T>
+__global__ void vae_sample_kernel(const T* __restrict__ mom, const float* __restrict__ eps, T* __restrict__ z, int64_t rows,
                                   int C, int ld_out, float shift, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * ld_out) return;
@@ -74,10 +77,11 @@ __global__ void vae_sample_kernel(const bf16_t* __restrict__ mom, const float* _
         lv = fminf(fmaxf(lv, -30.0f), 20.0f);
         out = ((mu + __expf(0.5f * lv) * eps[r * C + c]) - shift) * scale;
     }
-    z[i] = (bf16_t)out;
+    z[i] = (T)out;
 }
 
-__global__ void axpby_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, bf16_t* __restrict__ out, int64_t n, float a,
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out, int64_t n, float a,
                              float b, float c, float d, int steps) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -85,19 +89,20 @@ __global__ void axpby_kernel(const bf16_t* __restrict__ x, const bf16_t* __restr
     const float yv = y ? (float)y[i] : 0.0f;
     float v;
     if (steps) {
-        const float t0 = (a == 1.0f) ? xv : bf16_round(xv * a);
-        const float t1 = y ? bf16_round(yv * b) : 0.0f;
-        v = y ? bf16_round(t0 + t1) : t0;
-        if (c != 0.0f) v = bf16_round(v + c);
-        if (d != 1.0f) v = bf16_round(v * d);
+        const float t0 = (a == 1.0f) ? xv : round_to<T>(xv * a);
+        const float t1 = y ? round_to<T>(yv * b) : 0.0f;
+        v = y ? round_to<T>(t0 + t1) : t0;
+        if (c != 0.0f) v = round_to<T>(v + c);
+        if (d != 1.0f) v = round_to<T>(v * d);
     } else {
         v = (xv * a + yv * b + c) * d;
     }
-    out[i] = (bf16_t)v;
+    out[i] = (T)v;
 }
 
 // acc[n, y0+y, x0+x, c] += tile[n,y,x,c] * w[y,x]; wsum[n?]: handled by a second call with tile==NULL
-__global__ void tile_accumulate_kernel(const bf16_t* __restrict__ tile, const float* __restrict__ w, float* __restrict__ acc, int N,
+template <typename T>
+__global__ void tile_accumulate_kernel(const T* __restrict__ tile, const float* __restrict__ w, float* __restrict__ acc, int N,
                                        int C, int th, int tw, int tile_ld, int H, int W, int y0, int x0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)N * th * tw * C;
@@ -112,7 +117,8 @@ __global__ void tile_accumulate_kernel(const bf16_t* __restrict__ tile, const fl
     acc[(((int64_t)n * H + y0 + y) * W + x0 + x) * C + c] += tv * wv;
 }
 
-__global__ void tile_normalise_kernel(const float* __restrict__ acc, const float* __restrict__ wsum, bf16_t* __restrict__ out, int N,
+template <typename T>
+__global__ void tile_normalise_kernel(const float* __restrict__ acc, const float* __restrict__ wsum, T* __restrict__ out, int N,
                                       int64_t HW, int C, int ld) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * HW * ld) return;
@@ -120,7 +126,7 @@ __global__ void tile_normalise_kernel(const float* __restrict__ acc, const float
     const int64_t pix = i / ld;
     float v = 0.0f;
     if (c < C) v = acc[pix * C + c] / wsum[pix % HW];
-    out[i] = (bf16_t)v;
+    out[i] = (T)v;
 }
 
 __global__ void crop_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int H, int W, int C, int y0, int x0, int th,
@@ -169,7 +175,14 @@ inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)((tot
 
 }  // namespace
 
-extern "C" int omgsr_abi_version(void) { return 5; }
+extern "C" int omgsr_abi_version(void) { return 6; }
+
+extern "C" int omgsr_set_compute_dtype(int dtype) {
+    if (dtype != OMGSR_DT_BF16 && dtype != OMGSR_DT_F16) return OMGSR_E_BADARG;
+    omgsr::g_compute_dtype = dtype;
+    return 0;
+}
+extern "C" int omgsr_get_compute_dtype(void) { return omgsr::g_compute_dtype; }
 
 extern "C" int omgsr_check_device(void) {
     int dev = 0;
@@ -196,8 +209,8 @@ extern "C" int omgsr_nchw_to_nhwc(const void* src, void* dst, int32_t N, int32_t
     hipStream_t st = (hipStream_t)stream;
     const int64_t HW = (int64_t)H * W, total = (int64_t)N * HW * (Cpad >> 3);
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 2.0 * N * HW * (C + Cpad), st);
-    if (src_dtype == 1) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid1d(total), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, N, C, HW, Cpad);
-    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, C, HW, Cpad);
+    if (src_dtype == 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, T>), grid1d(total), dim3(256), 0, st, (const float*)src, (T*)dst, N, C, HW, Cpad));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((nchw_to_nhwc_kernel<T, T>), grid1d(total), dim3(256), 0, st, (const T*)src, (T*)dst, N, C, HW, Cpad));
     return (int)hipGetLastError();
 }
 
@@ -207,8 +220,8 @@ extern "C" int omgsr_nhwc_to_nchw(const void* src, void* dst, int32_t N, int32_t
     hipStream_t st = (hipStream_t)stream;
     const int64_t HW = (int64_t)H * W, total = (int64_t)N * C * HW;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 4.0 * total, st);
-    if (dst_dtype == 1) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, N, C, HW, ld, do_clamp, lo, hi);
-    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, C, HW, ld, do_clamp, lo, hi);
+    if (dst_dtype == 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, T>), grid1d(total), dim3(256), 0, st, (const T*)src, (float*)dst, N, C, HW, ld, do_clamp, lo, hi));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((nhwc_to_nchw_kernel<T, T>), grid1d(total), dim3(256), 0, st, (const T*)src, (T*)dst, N, C, HW, ld, do_clamp, lo, hi));
     return (int)hipGetLastError();
 }
 
@@ -227,7 +240,7 @@ extern "C" int omgsr_vae_sample(const void* moments, const float* eps, void* z, 
     if (!moments || !eps || !z || rows <= 0 || C <= 0 || ld_out < C) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 10.0 * rows * C, st);
-    hipLaunchKernelGGL(vae_sample_kernel, grid1d(rows * ld_out), dim3(256), 0, st, (const bf16_t*)moments, eps, (bf16_t*)z, rows, C, ld_out, shift, scale);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL(vae_sample_kernel<T>, grid1d(rows * ld_out), dim3(256), 0, st, (const T*)moments, eps, (T*)z, rows, C, ld_out, shift, scale));
     return (int)hipGetLastError();
 }
 
@@ -236,7 +249,7 @@ extern "C" int omgsr_axpby(const void* x, const void* y, void* out, int64_t n, f
     if (!x || !out || n <= 0) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 6.0 * n, st);
-    hipLaunchKernelGGL(axpby_kernel, grid1d(n), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)out, n, a, b, c, d, bf16_steps);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL(axpby_kernel<T>, grid1d(n), dim3(256), 0, st, (const T*)x, (const T*)y, (T*)out, n, a, b, c, d, bf16_steps));
     return (int)hipGetLastError();
 }
 
@@ -247,7 +260,7 @@ extern "C" int omgsr_tile_accumulate(const void* tile, const float* w, float* ac
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)N * th * tw * C;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 10.0 * total, st);
-    hipLaunchKernelGGL(tile_accumulate_kernel, grid1d(total), dim3(256), 0, st, (const bf16_t*)tile, w, acc, N, C, th, tw, tile_ld, H, W, y0, x0);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL(tile_accumulate_kernel<T>, grid1d(total), dim3(256), 0, st, (const T*)tile, w, acc, N, C, th, tw, tile_ld, H, W, y0, x0));
     return (int)hipGetLastError();
 }
 
@@ -257,7 +270,7 @@ extern "C" int omgsr_tile_normalise(const float* acc, const float* wsum, void* o
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)N * HW * ld;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 6.0 * total, st);
-    hipLaunchKernelGGL(tile_normalise_kernel, grid1d(total), dim3(256), 0, st, acc, wsum, (bf16_t*)out, N, HW, C, ld);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL(tile_normalise_kernel<T>, grid1d(total), dim3(256), 0, st, acc, wsum, (T*)out, N, HW, C, ld));
     return (int)hipGetLastError();
 }
 

@@ -37,7 +37,7 @@ constexpr int NTHREADS = 256;
 
 using Geo = IgemmGeo;
 
-template <int BM, int BN, int WGM, int WGN>
+template <typename T, int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args p, const Geo g) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
     constexpr int FM = WTM / 32, FN = WTN / 32;     // 32x32 fragments per wave
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args 
     const int m0 = tm * BM, n0 = tn * BN;
     const int bz = blockIdx.z;
 
-    const bf16_t* __restrict__ in = (const bf16_t*)p.in + (int64_t)bz * p.in_bstride;
-    const bf16_t* __restrict__ wt = (const bf16_t*)p.weight + (int64_t)bz * p.w_bstride;
+    const T* __restrict__ in = (const T*)p.in + (int64_t)bz * p.in_bstride;
+    const T* __restrict__ wt = (const T*)p.weight + (int64_t)bz * p.w_bstride;
 
     // ---- per-thread staging coordinates -------------------------------------------------
     const int kc = t & 3;      // which 16-byte chunk of the 64-byte K-step row
@@ -148,11 +148,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args 
         const unsigned char* Bs = lds + buf * STAGE_BYTES + BM * ROWB + wn * WTN * ROWB + frag_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t af[FM], bf[FN];
+            x8_t<T> af[FM], bf[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + i * 32 * ROWB + ks * 32);
+            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const x8_t<T>*>(As + i * 32 * ROWB + ks * 32);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 32 * ROWB + ks * 32);
+            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const x8_t<T>*>(Bs + j * 32 * ROWB + ks * 32);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args 
 
     // ---- epilogue: fragments -> LDS (fp32) -> 8 consecutive channels per lane -------------
     float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
-    igemm_epilogue_linear<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
+    igemm_epilogue_linear<T, WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -173,11 +173,12 @@ int launch(const omgsr_igemm_args& a, Geo g, hipStream_t st) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     g.ntn = (logical_cols + BN - 1) / BN;   // Cout_pad (multiple of 128) always covers ntn * BN rows
     dim3 grid(g.ntm * g.ntn, 1, a.batch);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WGM, WGN>), grid, dim3(NTHREADS), 0, st, a, g);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WGM, WGN>), grid, dim3(NTHREADS), 0, st, a, g));
     return (int)hipGetLastError();
 }
 
 // split-K reduce: out[m][n] = epilogue(sum_s partial[s][m][n]); one thread per 8 output channels.
+template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_args p, const float* __restrict__ ws, const int M,
                                                             const int ldw, const int splits) {
     const bool geglu = (p.act == OMGSR_ACT_GEGLU);
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
     for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
         float x = v[e];
         if (p.gate) x *= p.gate[n + e];
-        if (p.residual) x += (float)((const bf16_t*)p.residual)[(int64_t)m * p.Cout + n + e];
-        if (p.out_dtype == OMGSR_OUT_BF16) ((bf16_t*)p.out)[(int64_t)m * ldo + n + e] = (bf16_t)x;
+        if (p.residual) x += (float)((const T*)p.residual)[(int64_t)m * p.Cout + n + e];
+        if (p.out_dtype == OMGSR_OUT_BF16) ((T*)p.out)[(int64_t)m * ldo + n + e] = (T)x;
         else ((float*)p.out)[(int64_t)m * ldo + n + e] = x;
     }
 }
@@ -294,8 +295,8 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
             if (rc != 0) return rc;
             const int ldw = ((logical_cols + 127) / 128) * 128;
             const int64_t items = M64 * ((a.Cout + 7) / 8);
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a,
-                               (const float*)a.workspace, (int)M64, ldw, splits);
+            OMGSR_DISPATCH_T(hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a,
+                                                (const float*)a.workspace, (int)M64, ldw, splits));
             return (int)hipGetLastError();
         }
     }

@@ -63,7 +63,7 @@ OMGSR_DEVINL void wait_vmcnt() {
 }
 
 // ABL (ablation, A/B runs only): 0 = the kernel; 1 = no DMA; 2 = DMA + ds_reads, no MFMA; 3 = DMA only
-template <int WGM, int WGN, int ABL = 0>
+template <typename T, int WGM, int WGN, int ABL = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     constexpr int NW = WGM * WGN;              // waves
     constexpr int BN = WGN * WTN;
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
     const int m0 = tm * BM, n0 = tn * BN;
     const int bz = blockIdx.z;
 
-    const bf16_t* __restrict__ in = (const bf16_t*)p.in + (int64_t)bz * p.in_bstride;
-    const bf16_t* __restrict__ wt = (const bf16_t*)p.weight + (int64_t)bz * p.w_bstride;
+    const T* __restrict__ in = (const T*)p.in + (int64_t)bz * p.in_bstride;
+    const T* __restrict__ wt = (const T*)p.weight + (int64_t)bz * p.w_bstride;
     typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
     const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;            // LDS byte offset of the ring
 
@@ -193,16 +193,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
             if (kt + 2 < nk) issue((stage + 2) % NSTAGE);
         }
         if constexpr (ABL == 3) return;
-        bf16x8_t af[2][FM], bf[2][FN];
+        x8_t<T> af[2][FM], bf[2][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            af[0][i] = *reinterpret_cast<const bf16x8_t*>(fa0 + stage * STAGE_BYTES + i * 32 * 64);
-            af[1][i] = *reinterpret_cast<const bf16x8_t*>(fa1 + stage * STAGE_BYTES + i * 32 * 64);
+            af[0][i] = *reinterpret_cast<const x8_t<T>*>(fa0 + stage * STAGE_BYTES + i * 32 * 64);
+            af[1][i] = *reinterpret_cast<const x8_t<T>*>(fa1 + stage * STAGE_BYTES + i * 32 * 64);
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            bf[0][j] = *reinterpret_cast<const bf16x8_t*>(fb0 + stage * STAGE_BYTES + j * 32 * 64);
-            bf[1][j] = *reinterpret_cast<const bf16x8_t*>(fb1 + stage * STAGE_BYTES + j * 32 * 64);
+            bf[0][j] = *reinterpret_cast<const x8_t<T>*>(fb0 + stage * STAGE_BYTES + j * 32 * 64);
+            bf[1][j] = *reinterpret_cast<const x8_t<T>*>(fb1 + stage * STAGE_BYTES + j * 32 * 64);
         }
         if constexpr (ABL == 2) {
 #pragma unroll
@@ -236,10 +236,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
         q.out = (float*)p.workspace + (int64_t)blockIdx.y * g.M * ldw;
         q.out_dtype = OMGSR_OUT_F32; q.out_layout = OMGSR_LAYOUT_NHWC; q.out_ld = ldw; q.Cout = ldw;
         q.bias = nullptr; q.gate = nullptr; q.residual = nullptr; q.act = OMGSR_ACT_NONE; q.alpha = 1.0f;
-        igemm_epilogue_linear<WTN, FM, FN>(q, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, 0);
+        igemm_epilogue_linear<T, WTN, FM, FN>(q, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, 0);
         return;
     }
-    igemm_epilogue_linear<WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
+    igemm_epilogue_linear<T, WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
 }
 
 template <int WGM, int WGN, int ABL = 0>
@@ -248,13 +248,15 @@ int launch_dma(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     g.ntn = (logical_cols + WGN * WTN - 1) / (WGN * WTN);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<WGM, WGN, ABL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<bf16_t, WGM, WGN, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(WGN));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<f16_t, WGM, WGN, ABL>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(WGN));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(g.ntm * g.ntn, g.splits, a.batch);
-    hipLaunchKernelGGL((igemm_dma_kernel<WGM, WGN, ABL>), grid, dim3(WGM * WGN * 64), lds_bytes(WGN), st, a, g);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_dma_kernel<T, WGM, WGN, ABL>), grid, dim3(WGM * WGN * 64), lds_bytes(WGN), st, a, g));
     return (int)hipGetLastError();
 }
 

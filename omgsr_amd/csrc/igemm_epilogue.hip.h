@@ -18,7 +18,7 @@ OMGSR_DEVINL void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "me
 // epi: this wave's private LDS region of 32 x (WTN + 4) floats. Fragment row-block i covers output rows
 // (pixels) mb[i] .. mb[i] + nvalid[i] - 1; n_base: first PACKED column of the wave tile (GEGLU: packed
 // [32 a | 32 g] per 64). Must be called by every wave of the block.
-template <int WTN, int FM, int FN>
+template <typename T, int WTN, int FM, int FN>
 OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
                                  const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz) {
     constexpr int EPI_LD = WTN + 4;
@@ -29,9 +29,9 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
     const int lanes_per_row = cols_per_row / 8;
     const int rows_per_pass = 64 / lanes_per_row;
     const int lrow = lane / lanes_per_row, lcol = (lane % lanes_per_row) * 8;
-    bf16_t* outb = (bf16_t*)p.out + (int64_t)bz * p.out_bstride;
+    T* outb = (T*)p.out + (int64_t)bz * p.out_bstride;
     float* outf = (float*)p.out + (int64_t)bz * p.out_bstride;
-    const bf16_t* resb = p.residual ? (const bf16_t*)p.residual + (int64_t)bz * p.out_bstride : nullptr;
+    const T* resb = p.residual ? (const T*)p.residual + (int64_t)bz * p.out_bstride : nullptr;
     const int64_t ldo = p.out_ld > 0 ? p.out_ld : p.Cout;
     const bool vec_ok = (p.Cout & 7) == 0 && (ldo & 7) == 0;
 
@@ -101,12 +101,12 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                 if (vec_ok) {
                     if (resb) {
                         float rf[8];
-                        unpack8(*reinterpret_cast<const u32x4_t*>(resb + ro), rf);
+                        unpack8<T>(*reinterpret_cast<const u32x4_t*>(resb + ro), rf);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rf[e];
                     }
                     if (p.out_dtype == OMGSR_OUT_BF16) {
-                        *reinterpret_cast<u32x4_t*>(outb + o) = pack8(v);
+                        *reinterpret_cast<u32x4_t*>(outb + o) = pack8<T>(v);
                     } else {
                         *reinterpret_cast<f32x4_t*>(outf + o) = (f32x4_t){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4_t*>(outf + o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
@@ -115,14 +115,14 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                     for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
                         float x = v[e];
                         if (resb) x += (float)resb[ro + e];
-                        if (p.out_dtype == OMGSR_OUT_BF16) outb[o + e] = (bf16_t)x; else outf[o + e] = x;
+                        if (p.out_dtype == OMGSR_OUT_BF16) outb[o + e] = (T)x; else outf[o + e] = x;
                     }
                 }
             } else {  // OMGSR_LAYOUT_T: out[(m / t_rows) * Cout + n][m % t_rows]
                 const int blk = m / p.t_rows, mr = m - blk * p.t_rows;
                 for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
                     const int64_t o = ((int64_t)blk * p.Cout + n + e) * p.t_ld + mr;
-                    if (p.out_dtype == OMGSR_OUT_BF16) outb[o] = (bf16_t)v[e]; else outf[o] = v[e];
+                    if (p.out_dtype == OMGSR_OUT_BF16) outb[o] = (T)v[e]; else outf[o] = v[e];
                 }
             }
         }
@@ -131,7 +131,7 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
 }
 
 // linear-M helper for the GEMM-shaped kernels: row block i starts at m_base + 32*i
-template <int WTN, int FM, int FN>
+template <typename T, int WTN, int FM, int FN>
 OMGSR_DEVINL void igemm_epilogue_linear(const omgsr_igemm_args& p, const int M, f32x16_t (&acc)[FM][FN], float* epi,
                                         const int lane, const int m_base, const int n_base, const int bz) {
     int mb[FM], nv[FM];
@@ -141,7 +141,7 @@ OMGSR_DEVINL void igemm_epilogue_linear(const omgsr_igemm_args& p, const int M, 
         const int left = M - mb[i];
         nv[i] = left < 0 ? 0 : (left > 32 ? 32 : left);
     }
-    igemm_epilogue<WTN, FM, FN>(p, acc, epi, lane, mb, nv, n_base, bz);
+    igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n_base, bz);
 }
 
 struct IgemmGeo {

@@ -49,7 +49,7 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 
 // PRIO: raise the wave's priority around its MFMA cluster. Measured +6..10 % on K-heavy layers (Cin >= 512)
 // and -3..5 % on the epilogue-heavy 128/256-channel layers, so the dispatcher picks per layer.
-template <int ABL, bool PRIO>
+template <typename T, int ABL, bool PRIO>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     const int ty = trem / g.tiles_x, tx = trem - ty * g.tiles_x;
     const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
 
-    const bf16_t* __restrict__ in = (const bf16_t*)p.in;
-    const bf16_t* __restrict__ wt = (const bf16_t*)p.weight_cm;
+    const T* __restrict__ in = (const T*)p.in;
+    const T* __restrict__ wt = (const T*)p.weight_cm;
     typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
     const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;
 
@@ -167,16 +167,16 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
 
         const unsigned char* As = lds + par * A_BYTES;
         const unsigned char* Bs = lds + B_OFF + (tap % NB) * B_BYTES;
-        bf16x8_t af[2][FM], bf[2][FN];
+        x8_t<T> af[2][FM], bf[2][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            af[0][i] = *reinterpret_cast<const bf16x8_t*>(As + aoff[tap][i]);
-            af[1][i] = *reinterpret_cast<const bf16x8_t*>(As + (aoff[tap][i] ^ 32));
+            af[0][i] = *reinterpret_cast<const x8_t<T>*>(As + aoff[tap][i]);
+            af[1][i] = *reinterpret_cast<const x8_t<T>*>(As + (aoff[tap][i] ^ 32));
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            bf[0][j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 32 * 64 + boff0);
-            bf[1][j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 32 * 64 + boff1);
+            bf[0][j] = *reinterpret_cast<const x8_t<T>*>(Bs + j * 32 * 64 + boff0);
+            bf[1][j] = *reinterpret_cast<const x8_t<T>*>(Bs + j * 32 * 64 + boff1);
         }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
             for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
     } else {
         float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
-        igemm_epilogue<WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0);
+        igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0);
     }
 }
 
@@ -237,20 +237,23 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     g.ntn = (logical_cols + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel<0, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel<0, true>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel<1, false>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipSuccess;
+        const void* fns[] = {reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, true>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 1, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, true>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 1, false>)};
+        for (const void* f : fns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(g.ntm * g.ntn, 1, 1);
     static const char* abl = getenv("OMGSR_HALO_ABLATE");      // timing experiments only
-    if (abl && abl[0] == '1') hipLaunchKernelGGL((igemm_halo_kernel<1, false>), grid, dim3(256), LDS_BYTES, st, a, g);
-    else if (a.Cin >= 384) hipLaunchKernelGGL((igemm_halo_kernel<0, true>), grid, dim3(256), LDS_BYTES, st, a, g);
-    else hipLaunchKernelGGL((igemm_halo_kernel<0, false>), grid, dim3(256), LDS_BYTES, st, a, g);
+    if (abl && abl[0] == '1') OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 1, false>), grid, dim3(256), LDS_BYTES, st, a, g));
+    else if (a.Cin >= 384) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, true>), grid, dim3(256), LDS_BYTES, st, a, g));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false>), grid, dim3(256), LDS_BYTES, st, a, g));
     return (int)hipGetLastError();
 }
 int igemm_halo_tiles(const omgsr_igemm_args& a) {

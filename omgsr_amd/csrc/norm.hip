@@ -11,7 +11,8 @@ constexpr int GN_PPC = 256;   // pixels per statistics chunk (1024 measured 30 %
 // ---------------------------------------------------------------------------------------------
 // GroupNorm statistics, pass 1: per (image, pixel-chunk) partial (sum, sumsq) per group.
 // x [N][HW][C] bf16.  grid = (nchunk, N), 256 threads.  LDS: 2*C floats.
-__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
                                                           int64_t HW, int C, int G, int nchunk) {
     // LDS: csum[P][C], csq[P][C] — one slot per (pixel lane, channel), reduced in a FIXED order
     // afterwards (no atomics: results are bitwise reproducible and independent of the batch size)
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     const int npx = (int)((HW - p0) < GN_PPC ? (HW - p0) : GN_PPC);
     if (t < TP * P) {
         const int pl = t / TP;
-        const bf16_t* base = x + ((int64_t)n * HW + p0) * C;
+        const T* base = x + ((int64_t)n * HW + p0) * C;
         for (int c8 = t % TP; c8 < nch8; c8 += TP) {
             float s[8], q[8];
 #pragma unroll
@@ -41,14 +42,14 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float f[8];
-                    unpack8(r[u], f);
+                    unpack8<T>(r[u], f);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
                 }
             }
             for (; px < npx; px += P) {
                 float f[8];
-                unpack8(*reinterpret_cast<const u32x4_t*>(base + (int64_t)px * C + c8 * 8), f);
+                unpack8<T>(*reinterpret_cast<const u32x4_t*>(base + (int64_t)px * C + c8 * 8), f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
             }
@@ -95,7 +96,8 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __r
 
 // GroupNorm apply (+ optional SiLU). grid = (nblk, N); each block builds the per-channel
 // (scale, shift) table of its image in LDS, then streams its pixel range.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int64_t HW, int C, int G, int act, int64_t px_per_block) {
@@ -116,8 +118,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     const int64_t p0 = (int64_t)blockIdx.x * px_per_block;
     int64_t p1 = p0 + px_per_block; if (p1 > HW) p1 = HW;
     const int total = (int)((p1 - p0) * nch8);   // <= ~4k chunks per block by construction
-    const bf16_t* xb = x + ((int64_t)n * HW + p0) * C;
-    bf16_t* yb = y + ((int64_t)n * HW + p0) * C;
+    const T* xb = x + ((int64_t)n * HW + p0) * C;
+    T* yb = y + ((int64_t)n * HW + p0) * C;
     // two 16-byte chunks in flight per thread; the channel-octet index advances by (256 mod nch8) per step
     const int step8 = 256 % nch8;
     int c8 = t % nch8;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         const u32x4_t r1 = *reinterpret_cast<const u32x4_t*>(xb + (int64_t)(i + 256) * 8);
         int c8b = c8 + step8; if (c8b >= nch8) c8b -= nch8;
         float f[8], h[8];
-        unpack8(r0, f); unpack8(r1, h);
+        unpack8<T>(r0, f); unpack8<T>(r1, h);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = f[e] * sc[c8 * 8 + e] + sh[c8 * 8 + e];
@@ -135,41 +137,41 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
             f[e] = (act == OMGSR_ACT_SILU) ? silu_f(v) : v;
             h[e] = (act == OMGSR_ACT_SILU) ? silu_f(w) : w;
         }
-        *reinterpret_cast<u32x4_t*>(yb + (int64_t)i * 8) = pack8(f);
-        *reinterpret_cast<u32x4_t*>(yb + (int64_t)(i + 256) * 8) = pack8(h);
+        *reinterpret_cast<u32x4_t*>(yb + (int64_t)i * 8) = pack8<T>(f);
+        *reinterpret_cast<u32x4_t*>(yb + (int64_t)(i + 256) * 8) = pack8<T>(h);
         c8 = c8b + step8; if (c8 >= nch8) c8 -= nch8;
     }
     for (; i < total; i += 256) {
         float f[8];
-        unpack8(*reinterpret_cast<const u32x4_t*>(xb + (int64_t)i * 8), f);
+        unpack8<T>(*reinterpret_cast<const u32x4_t*>(xb + (int64_t)i * 8), f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = f[e] * sc[c8 * 8 + e] + sh[c8 * 8 + e];
             f[e] = (act == OMGSR_ACT_SILU) ? silu_f(v) : v;
         }
-        *reinterpret_cast<u32x4_t*>(yb + (int64_t)i * 8) = pack8(f);
+        *reinterpret_cast<u32x4_t*>(yb + (int64_t)i * 8) = pack8<T>(f);
         c8 += step8; if (c8 >= nch8) c8 -= nch8;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, C <= 64*8*MAXCH. y = (x-mu)*rstd*a[c] + b[c].
-template <int MAXCH>
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+template <typename T, int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          const float* __restrict__ a, const float* __restrict__ b,
                                                          int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch8 = C >> 3;
-    const bf16_t* xr = x + row * C;
+    const T* xr = x + row * C;
     float f[MAXCH][8];
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         const int c8 = lane + 64 * i;
         if (c8 < nch8) {
-            unpack8(*reinterpret_cast<const u32x4_t*>(xr + c8 * 8), f[i]);
+            unpack8<T>(*reinterpret_cast<const u32x4_t*>(xr + c8 * 8), f[i]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += f[i][e];
         }
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
         }
     }
     const float r = rsqrtf(wave_sum(q) / (float)C + eps);
-    bf16_t* yr = y + row * C;
+    T* yr = y + row * C;
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         const int c8 = lane + 64 * i;
@@ -199,19 +201,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                 if (b) v += b[c];
                 o[e] = v;
             }
-            *reinterpret_cast<u32x4_t*>(yr + c8 * 8) = pack8(o);
+            *reinterpret_cast<u32x4_t*>(yr + c8 * 8) = pack8<T>(o);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Row softmax fp32 -> bf16, one 256-thread block per row, L <= 256*4*MAXV.
-template <int MAXV>
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, int L, int Lvalid) {
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, T* __restrict__ p, int L, int Lvalid) {
     __shared__ float red[8];
     const int t = threadIdx.x;
     const float* sr = s + (int64_t)blockIdx.x * L;
-    bf16_t* pr = p + (int64_t)blockIdx.x * L;
+    T* pr = p + (int64_t)blockIdx.x * L;
     const int nv = L >> 2;
     f32x4_t v[MAXV];
     float mx = -3.0e38f;
@@ -247,8 +249,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         const int j = t + 256 * i;
         if (j < nv) {
             u32x2_t o;
-            o[0] = pack2(v[i][0] * inv, v[i][1] * inv);
-            o[1] = pack2(v[i][2] * inv, v[i][3] * inv);
+            o[0] = pack2<T>(v[i][0] * inv, v[i][1] * inv);
+            o[1] = pack2<T>(v[i][2] * inv, v[i][3] * inv);
             *reinterpret_cast<u32x2_t*>(pr + 4 * j) = o;
         }
     }
@@ -257,7 +259,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // RMSNorm over head_dim (D = 128) * w, then interleaved-pair RoPE, in place.  16 lanes per head
 // (8 elements each), 4 heads per wave.
-__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ x, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                             int64_t rows, int L, int H, int D, int64_t ld, int col0,
                                                             int pos0, float eps) {
@@ -266,9 +269,9 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
     const int sub = threadIdx.x & 15;
     const int64_t row = gid / H;
     const int h = (int)(gid - row * H);
-    bf16_t* px = x + row * ld + col0 + h * D + sub * 8;
+    T* px = x + row * ld + col0 + h * D + sub * 8;
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4_t*>(px), f);
+    unpack8<T>(*reinterpret_cast<const u32x4_t*>(px), f);
     float q = 0.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) q += f[e] * f[e];
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
             f[e + 1] = b * cp[e + 1] + a * sp[e + 1];
         }
     }
-    *reinterpret_cast<u32x4_t*>(px) = pack8(f);
+    *reinterpret_cast<u32x4_t*>(px) = pack8<T>(f);
 }
 
 }  // namespace
@@ -304,8 +307,8 @@ extern "C" int omgsr_groupnorm_stats(const void* x, float* partial, float* mean,
     omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 2.0 * N * (double)HW * C, st);
     const int tp = (C >> 3) < 256 ? (C >> 3) : 256;
     const size_t lds = 2 * (size_t)(256 / tp) * C * sizeof(float);      // <= 20 KB
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, N), dim3(256), lds, st,
-                       (const bf16_t*)x, partial, HW, C, G, nchunk);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, N), dim3(256), lds, st,
+                                        (const T*)x, partial, HW, C, G, nchunk));
     const int tot = N * G;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(tot), dim3(64), 0, st, partial, mean, rstd, var_out,
                        N, G, nchunk, (double)HW * (C / G), eps);
@@ -324,8 +327,8 @@ extern "C" int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, 
     if (ppb < 1) ppb = 1;
     const int nblk = (int)((HW + ppb - 1) / ppb);
     omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 4.0 * N * (double)HW * C, st);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, N), dim3(256), 2 * C * sizeof(float), st, (const bf16_t*)x,
-                       (bf16_t*)y, mean, rstd, gamma, beta, HW, C, G, act, ppb);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nblk, N), dim3(256), 2 * C * sizeof(float), st, (const T*)x,
+                                        (T*)y, mean, rstd, gamma, beta, HW, C, G, act, ppb));
     return (int)hipGetLastError();
 }
 
@@ -337,10 +340,10 @@ extern "C" int omgsr_layernorm(const void* x, void* y, const float* a, const flo
     const dim3 grid((unsigned)((rows + 3) / 4));
     omgsr::TimingScope ts(OMGSR_TK_LN, 0.0, 4.0 * (double)rows * C, st);
     const int nch = ((C >> 3) + 63) / 64;
-    if (nch <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, a, b, rows, C, eps);
-    else if (nch <= 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, a, b, rows, C, eps);
-    else if (nch <= 6) hipLaunchKernelGGL(layernorm_kernel<6>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, a, b, rows, C, eps);
-    else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, a, b, rows, C, eps);
+    if (nch <= 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
+    else if (nch <= 3) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
+    else if (nch <= 6) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 6>), grid, dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 8>), grid, dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
     return (int)hipGetLastError();
 }
 
@@ -350,9 +353,9 @@ extern "C" int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t
     hipStream_t st = (hipStream_t)stream;
     omgsr::TimingScope ts(OMGSR_TK_SOFTMAX, 0.0, 6.0 * (double)rows * L, st);
     const int nv = (L / 4 + 255) / 256;
-    if (nv <= 1) hipLaunchKernelGGL(softmax_rows_kernel<1>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L, Lvalid);
-    else if (nv <= 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L, Lvalid);
-    else hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3((unsigned)rows), dim3(256), 0, st, s, (bf16_t*)p, L, Lvalid);
+    if (nv <= 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((softmax_rows_kernel<T, 1>), dim3((unsigned)rows), dim3(256), 0, st, s, (T*)p, L, Lvalid));
+    else if (nv <= 4) OMGSR_DISPATCH_T(hipLaunchKernelGGL((softmax_rows_kernel<T, 4>), dim3((unsigned)rows), dim3(256), 0, st, s, (T*)p, L, Lvalid));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((softmax_rows_kernel<T, 16>), dim3((unsigned)rows), dim3(256), 0, st, s, (T*)p, L, Lvalid));
     return (int)hipGetLastError();
 }
 
@@ -364,7 +367,7 @@ extern "C" int omgsr_rmsnorm_rope(void* x, const float* w, const float* cos_t, c
     const int64_t rows = (int64_t)B * L;
     const int64_t groups = rows * H;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 4.0 * (double)groups * D, st);
-    hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, st, (bf16_t*)x, w, cos_t,
-                       sin_t, rows, L, H, D, ld, col0, pos0, eps);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL(rmsnorm_rope_kernel<T>, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, st, (T*)x, w, cos_t,
+                                        sin_t, rows, L, H, D, ld, col0, pos0, eps));
     return (int)hipGetLastError();
 }

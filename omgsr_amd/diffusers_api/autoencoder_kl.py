@@ -101,7 +101,7 @@ class VaeAttention(nn.Module):
         Lp = ops._round_up(L, 128)
         k = self.to_k.nhwc(g)
         if Lp != L:
-            kp = torch.zeros((N, Lp, Cc), device=x.device, dtype=torch.bfloat16)
+            kp = torch.zeros((N, Lp, Cc), device=x.device, dtype=ops.act_dtype())
             kp[:, :L] = k
             k = kp
         vt = ops.linear_t(g, self.to_v.packed(), L, ld=Lp)                    # [N, C, Lp], zero padded keys
@@ -223,7 +223,7 @@ class Decoder(nn.Module):
 
 
 def _io_dtype(x):
-    return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.bfloat16
+    return ops.io_dtype(x)
 
 
 class DiagonalGaussianDistribution:

@@ -257,7 +257,7 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
         return self._cache("rope", lambda: rope_tables(torch.cat([txt_ids, img_ids], 0).float(), self.config.axes_dims_rope), txt_ids, img_ids)
 
     def _context(self, ehs):
-        return self._cache("ctx", lambda: self.context_embedder.nhwc(ehs.to(torch.bfloat16).contiguous()), ehs,
+        return self._cache("ctx", lambda: self.context_embedder.nhwc(ehs.to(ops.act_dtype()).contiguous()), ehs,
                            self.context_embedder.weight)
 
     # ---- token executor --------------------------------------------------------------------
@@ -271,10 +271,10 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
         L = Lc + Li
         dev = x_tok.device
         mlp = self.single_transformer_blocks[0].mlp_hidden if len(self.single_transformer_blocks) else 0
-        ws = dict(qk=torch.empty((L, 2 * D), device=dev, dtype=torch.bfloat16),
-                  vt=torch.empty((D, ops._round_up(L, 8)), device=dev, dtype=torch.bfloat16),
-                  o=torch.empty((L, D), device=dev, dtype=torch.bfloat16),
-                  cat=torch.empty((L, D + mlp), device=dev, dtype=torch.bfloat16))
+        ws = dict(qk=torch.empty((L, 2 * D), device=dev, dtype=ops.act_dtype()),
+                  vt=torch.empty((D, ops._round_up(L, 8)), device=dev, dtype=ops.act_dtype()),
+                  o=torch.empty((L, D), device=dev, dtype=ops.act_dtype()),
+                  cat=torch.empty((L, D + mlp), device=dev, dtype=ops.act_dtype()))
         if ws["vt"].shape[1] != L:
             ws["vt"].zero_()
         outs = []
@@ -293,7 +293,7 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
     # ---- diffusers API ---------------------------------------------------------------------
     def forward(self, hidden_states, timestep, guidance=None, pooled_projections=None, encoder_hidden_states=None,
                 txt_ids=None, img_ids=None, return_dict: bool = True, **_):
-        x = hidden_states.to(torch.bfloat16).contiguous()
+        x = hidden_states.to(ops.act_dtype()).contiguous()
         out = self.tokens(x, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids)
         out = out.to(hidden_states.dtype)
         return SimpleNamespace(sample=out) if return_dict else (out,)

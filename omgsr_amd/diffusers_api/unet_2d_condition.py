@@ -97,7 +97,7 @@ class Attention(nn.Module):
         """K and V^T of a fixed prompt (cached on the tensor's identity)."""
         k = _key(ehs, self.to_k.weight, self.to_v.weight)
         if self._ctx_cache is None or self._ctx_cache[0] != k:
-            e = ehs.to(torch.bfloat16).contiguous()
+            e = ehs.to(ops.act_dtype()).contiguous()
             kk = ops.linear(e, self.to_k.packed())                      # [Bc, 77, inner]
             vt = ops.linear_t(e, self.to_v.packed(), e.shape[1])        # [Bc, inner, 80]
             self._ctx_cache = (k, kk, vt, e.shape[1])
@@ -287,6 +287,6 @@ class UNet2DConditionModel(ModelMixin):
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, return_dict: bool = True):
         x = ops.nchw_to_nhwc(sample.contiguous(), 8)
         y = self.nhwc(x, timestep, encoder_hidden_states)
-        out_dtype = sample.dtype if sample.dtype in (torch.float32, torch.bfloat16) else torch.bfloat16
+        out_dtype = ops.io_dtype(sample)
         out = ops.nhwc_to_nchw(y, channels=self.config.out_channels, dtype=out_dtype)
         return SimpleNamespace(sample=out) if return_dict else (out,)

@@ -19,7 +19,7 @@ from . import ops
 
 
 def _key(*tensors) -> tuple:
-    return tuple((t.data_ptr(), t._version, str(t.device), t.dtype) if t is not None else None for t in tensors)
+    return (ops.act_dtype(),) + tuple((t.data_ptr(), t._version, str(t.device), t.dtype) if t is not None else None for t in tensors)
 
 
 class _Packed:
@@ -49,7 +49,7 @@ class Conv2d(nn.Conv2d, _Packed):
     def forward(self, x):  # NCHW compat
         y = self.nhwc(ops.nchw_to_nhwc(x.contiguous(), ops._round_up(self.in_channels, 8)))
         return ops.nhwc_to_nchw(y, channels=self.out_channels,
-                                dtype=x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.bfloat16)
+                                dtype=ops.io_dtype(x))
 
 
 class Linear(nn.Linear, _Packed):
@@ -60,7 +60,7 @@ class Linear(nn.Linear, _Packed):
         return ops.linear(x, self.packed(), act=act, residual=residual, gate=gate, out_dtype=out_dtype)
 
     def forward(self, x):
-        y = self.nhwc(x.to(torch.bfloat16).contiguous())
+        y = self.nhwc(x.to(ops.act_dtype()).contiguous())
         return y.to(x.dtype)
 
 
@@ -101,7 +101,7 @@ class LayerNorm(nn.LayerNorm, _Packed):
         return ops.layer_norm(x, a, b, self.eps)
 
     def forward(self, x):
-        return self.nhwc(x.to(torch.bfloat16).contiguous()).to(x.dtype)
+        return self.nhwc(x.to(ops.act_dtype()).contiguous()).to(x.dtype)
 
 
 class RMSNormWeight(nn.Module):

@@ -20,6 +20,28 @@ OUT_BF16, OUT_F32 = 0, 1
 LAYOUT_NHWC, LAYOUT_T = 0, 1
 
 
+_ACT = torch.bfloat16
+
+
+def act_dtype() -> torch.dtype:
+    """The 16-bit element type of every activation / packed weight (bf16 default, fp16 optional)."""
+    return _ACT
+
+
+def set_compute_dtype(dtype: torch.dtype) -> None:
+    """Process-wide switch (omgsr_set_compute_dtype): packed-weight caches are keyed on it and rebuild lazily."""
+    global _ACT
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError(f"compute dtype must be act_dtype() or torch.float16, got {dtype}")
+    check(_lib.load().omgsr_set_compute_dtype(0 if dtype == torch.bfloat16 else 1), "set_compute_dtype")
+    _ACT = dtype
+
+
+def io_dtype(x: torch.Tensor) -> torch.dtype:
+    """Boundary dtype the kernels can write directly for a caller holding `x`: f32 stays f32, else the compute dtype."""
+    return torch.float32 if x.dtype == torch.float32 else _ACT
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -96,8 +118,8 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
     w = w.reshape(cout, R * S * cin8)
     k_pad = _round_up(w.shape[1], 32)
     cout_pad = _round_up(cout, 256 if cout >= 256 else 128)   # 256-row padding lets the 256x256 GEMM tile run
-    out = torch.zeros(cout_pad, k_pad, device=dev, dtype=torch.bfloat16)
-    out[:cout, : w.shape[1]] = w.to(torch.bfloat16)
+    out = torch.zeros(cout_pad, k_pad, device=dev, dtype=act_dtype())
+    out[:cout, : w.shape[1]] = w.to(act_dtype())
     b = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
     w_cm = None
     if R == 3 and S == 3 and cin8 % 32 == 0:
@@ -139,7 +161,7 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
            gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_BF16, alpha: float = 1.0,
            out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [N,H,W,Cin] bf16 -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on the (virtual) input."""
-    _req(x, torch.bfloat16, "x")
+    _req(x, act_dtype(), "x")
     N, H, W, Cin = x.shape
     if Cin != pw.cin:
         raise ValueError(f"conv2d: input has {Cin} channels, packed weight expects {pw.cin}")
@@ -153,9 +175,9 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
         act = ACT_GEGLU
     if out is None:
         out = torch.empty((N, Ho, Wo, pw.cout), device=x.device,
-                          dtype=torch.bfloat16 if out_dtype == OUT_BF16 else torch.float32)
+                          dtype=act_dtype() if out_dtype == OUT_BF16 else torch.float32)
     if residual is not None:
-        _req(residual, torch.bfloat16, "residual")
+        _req(residual, act_dtype(), "residual")
         if residual.shape != out.shape:
             raise ValueError(f"residual shape {tuple(residual.shape)} != output {tuple(out.shape)}")
     a = IgemmArgs()
@@ -191,13 +213,13 @@ def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int,
                 residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None) -> None:
     """out[row0:row0+M, col0:col0+Cout] = epilogue(x @ W^T): writes a projection straight into a slice of a
     larger 2-D token buffer `out` [rows, ld] (joint text+image sequences, [attn | mlp] concat)."""
-    _req(x, torch.bfloat16, "x"); _req(out, torch.bfloat16, "out")
+    _req(x, act_dtype(), "x"); _req(out, act_dtype(), "out")
     M, K = x.numel() // x.shape[-1], x.shape[-1]
     ld = out.shape[-1]
     if K != pw.cin or out.dim() != 2 or row0 + M > out.shape[0] or col0 + pw.cout > ld or (col0 & 7):
         raise ValueError("linear_into: slice does not fit")
     if residual is not None:
-        _req(residual, torch.bfloat16, "residual")
+        _req(residual, act_dtype(), "residual")
         if residual.numel() != M * pw.cout:
             raise ValueError("linear_into: residual must be a dense [M, Cout]")
     a = IgemmArgs()
@@ -216,7 +238,7 @@ def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int,
 def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: int) -> None:
     """out_t[n, key0 + l] = (x W^T + b)[l, n] for x [L, K]: transposed projection into a slice of a joint
     V^T buffer [Cout, ld]."""
-    _req(x, torch.bfloat16, "x"); _req(out_t, torch.bfloat16, "out_t")
+    _req(x, act_dtype(), "x"); _req(out_t, act_dtype(), "out_t")
     L, K = x.numel() // x.shape[-1], x.shape[-1]
     if out_t.dim() != 2 or out_t.shape[0] != pw.cout or key0 + L > out_t.shape[1]:
         raise ValueError("linear_t_into: slice does not fit")
@@ -235,13 +257,13 @@ def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: 
 def linear_t(x: torch.Tensor, pw: PackedWeight, rows_per_batch: int, ld: Optional[int] = None) -> torch.Tensor:
     """Transposed-output projection: x [B, L, K] -> out [B, Cout, ld] with out[b, n, l] = (x W^T + bias)[b, l, n].
     This is how V reaches omgsr_attention (key index contiguous). Columns l >= L are zero."""
-    _req(x, torch.bfloat16, "x")
+    _req(x, act_dtype(), "x")
     B, L, K = x.shape
     if L != rows_per_batch:
         raise ValueError("rows_per_batch mismatch")
     ld = ld or _round_up(L, 8)
-    out = torch.zeros((B, pw.cout, ld), device=x.device, dtype=torch.bfloat16) if ld != L else \
-        torch.empty((B, pw.cout, ld), device=x.device, dtype=torch.bfloat16)
+    out = torch.zeros((B, pw.cout, ld), device=x.device, dtype=act_dtype()) if ld != L else \
+        torch.empty((B, pw.cout, ld), device=x.device, dtype=act_dtype())
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate, a.residual, a.out = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), None, None, out.data_ptr()
     a.N, a.H, a.W, a.Cin = 1, 1, B * L, K
@@ -259,17 +281,17 @@ def linear_t(x: torch.Tensor, pw: PackedWeight, rows_per_batch: int, ld: Optiona
 def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_dtype: int = OUT_BF16) -> torch.Tensor:
     """out[b] = alpha * a[b] @ b[b]^T ; a [B, M, K], b [B, Npad, K] bf16 with Npad % 128 == 0, K % 32 == 0.
     Returns [B, M, Npad]. (d=512 VAE attention scores / PV product.)"""
-    _req(a_mat, torch.bfloat16, "a")
-    _req(b_mat, torch.bfloat16, "b")
+    _req(a_mat, act_dtype(), "a")
+    _req(b_mat, act_dtype(), "b")
     B, M, K = a_mat.shape
     Bb, Np, Kb = b_mat.shape
     if Bb != B or Kb != K or K % 32:
         raise ValueError(f"bmm_nt: incompatible shapes {tuple(a_mat.shape)} x {tuple(b_mat.shape)}")
     if Np % 128:    # reduced test configs only (the real VAE has 512 channels / 128-padded key counts)
-        bp = torch.zeros((B, _round_up(Np, 128), K), device=b_mat.device, dtype=torch.bfloat16)
+        bp = torch.zeros((B, _round_up(Np, 128), K), device=b_mat.device, dtype=act_dtype())
         bp[:, :Np] = b_mat
         return bmm_nt(a_mat, bp, alpha=alpha, out_dtype=out_dtype)[:, :, :Np].contiguous()
-    out = torch.empty((B, M, Np), device=a_mat.device, dtype=torch.bfloat16 if out_dtype == OUT_BF16 else torch.float32)
+    out = torch.empty((B, M, Np), device=a_mat.device, dtype=act_dtype() if out_dtype == OUT_BF16 else torch.float32)
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate, a.residual, a.out = a_mat.data_ptr(), b_mat.data_ptr(), None, None, None, out.data_ptr()
     a.N, a.H, a.W, a.Cin = 1, 1, M, K
@@ -289,7 +311,7 @@ def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_
 
 def group_norm_stats(x: torch.Tensor, groups: int, eps: float):
     """x [N, ..., C] bf16 -> (mean [N,G], rstd [N,G], var [N,G]) f32 (biased variance)."""
-    _req(x, torch.bfloat16, "x")
+    _req(x, act_dtype(), "x")
     N, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * Cc)
     lib = _lib.load()
@@ -305,7 +327,7 @@ def group_norm_stats(x: torch.Tensor, groups: int, eps: float):
 
 def group_norm_apply(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: Optional[torch.Tensor],
                      beta: Optional[torch.Tensor], groups: int, act: int = ACT_NONE, inplace: bool = False) -> torch.Tensor:
-    _req(x, torch.bfloat16, "x")
+    _req(x, act_dtype(), "x")
     N, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * Cc)
     y = x if inplace else torch.empty_like(x)
@@ -323,7 +345,7 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, act: int =
 # K9/K10: LayerNorm (affine or AdaLN-modulated)
 
 def layer_norm(x: torch.Tensor, a: Optional[torch.Tensor], b: Optional[torch.Tensor], eps: float) -> torch.Tensor:
-    _req(x, torch.bfloat16, "x")
+    _req(x, act_dtype(), "x")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     y = torch.empty_like(x)
@@ -339,13 +361,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, he
               o_col: int = 0) -> torch.Tensor:
     """q [B, Lq, *] (heads at columns q_col + h*D), k [Bk, Lk, *], vt [Bk, heads*D, ld] -> o [B, Lq, heads*D].
     Bk == 1 broadcasts one K/V over the batch (constant cross-attention context)."""
-    _req(q, torch.bfloat16, "q"); _req(k, torch.bfloat16, "k"); _req(vt, torch.bfloat16, "vt")
+    _req(q, act_dtype(), "q"); _req(k, act_dtype(), "k"); _req(vt, act_dtype(), "vt")
     B, Lq = q.shape[0], q.shape[1]
     Bk = k.shape[0]
     Lk = Lk if Lk is not None else k.shape[1]
     inner = heads * head_dim
     if out is None:
-        out = torch.empty((B, Lq, inner), device=q.device, dtype=torch.bfloat16)
+        out = torch.empty((B, Lq, inner), device=q.device, dtype=act_dtype())
     a = AttnArgs()
     esz = 2
     a.q = q.data_ptr() + q_col * esz
@@ -368,7 +390,7 @@ def softmax_rows(s: torch.Tensor, valid: Optional[int] = None) -> torch.Tensor:
     _req(s, torch.float32, "s")
     L = s.shape[-1]
     rows = s.numel() // L
-    p = torch.empty(s.shape, device=s.device, dtype=torch.bfloat16)
+    p = torch.empty(s.shape, device=s.device, dtype=act_dtype())
     check(_lib.load().omgsr_softmax_rows(s.data_ptr(), p.data_ptr(), rows, L, valid or L, _stream()), "omgsr_softmax_rows")
     return p
 
@@ -377,7 +399,7 @@ def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos: Optional[torch.Tensor],
                   heads: int, head_dim: int, col0: int = 0, pos0: int = 0, eps: float = 1e-6) -> torch.Tensor:
     """In place on x [B, L, ld]: per head RMSNorm(head_dim) * w[h] then RoPE with cos/sin [>= pos0+L, D] (f32).
     w is [heads, D]: one call can cover the q heads and the k heads of a fused [q|k] buffer."""
-    _req(x, torch.bfloat16, "x"); _req(w, torch.float32, "w")
+    _req(x, act_dtype(), "x"); _req(w, torch.float32, "w")
     B, L, ld = x.shape
     if tuple(w.shape) != (heads, head_dim):
         raise ValueError(f"rmsnorm_rope_: w must be [{heads}, {head_dim}], got {tuple(w.shape)}")
@@ -390,20 +412,23 @@ def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos: Optional[torch.Tensor],
 # K14: layout + latent algebra
 
 def nchw_to_nhwc(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
-    if x.dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError("nchw_to_nhwc: f32 or bf16 input")
+    if x.dtype not in (torch.float32, act_dtype()):
+        x = x.to(act_dtype())          # the other 16-bit type / f64: one conversion at the boundary
     _req(x, x.dtype, "x")
     N, Cc, H, W = x.shape
     cpad = cpad or _round_up(Cc, 8)
-    y = torch.empty((N, H, W, cpad), device=x.device, dtype=torch.bfloat16)
+    y = torch.empty((N, H, W, cpad), device=x.device, dtype=act_dtype())
     check(_lib.load().omgsr_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), N, Cc, H, W, cpad, int(x.dtype == torch.float32), _stream()),
           "omgsr_nchw_to_nhwc")
     return y
 
 
-def nhwc_to_nchw(x: torch.Tensor, channels: Optional[int] = None, dtype=torch.bfloat16,
+def nhwc_to_nchw(x: torch.Tensor, channels: Optional[int] = None, dtype=None,
                  clamp: Optional[tuple[float, float]] = None) -> torch.Tensor:
-    _req(x, torch.bfloat16, "x")
+    _req(x, act_dtype(), "x")
+    dtype = dtype or act_dtype()
+    if dtype not in (torch.float32, act_dtype()):
+        raise TypeError(f"nhwc_to_nchw: output dtype must be float32 or {act_dtype()}, got {dtype}")
     N, H, W, ld = x.shape
     Cc = channels or ld
     y = torch.empty((N, Cc, H, W), device=x.device, dtype=dtype)
@@ -415,10 +440,10 @@ def nhwc_to_nchw(x: torch.Tensor, channels: Optional[int] = None, dtype=torch.bf
 
 def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """torch.cat([a, b], dim=channel) for NHWC bf16."""
-    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b")
+    _req(a, act_dtype(), "a"); _req(b, act_dtype(), "b")
     Ca, Cb = a.shape[-1], b.shape[-1]
     rows = a.numel() // Ca
-    out = torch.empty((*a.shape[:-1], Ca + Cb), device=a.device, dtype=torch.bfloat16)
+    out = torch.empty((*a.shape[:-1], Ca + Cb), device=a.device, dtype=act_dtype())
     lib = _lib.load()
     check(lib.omgsr_copy_channels(a.data_ptr(), out.data_ptr(), rows, Ca, Ca, Ca + Cb, 0, _stream()), "omgsr_copy_channels")
     check(lib.omgsr_copy_channels(b.data_ptr(), out.data_ptr(), rows, Cb, Cb, Ca + Cb, Ca, _stream()), "omgsr_copy_channels")
@@ -428,10 +453,10 @@ def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def vae_sample(moments: torch.Tensor, eps: torch.Tensor, latent_channels: int, shift: float, scale: float,
                ld_out: Optional[int] = None) -> torch.Tensor:
     """moments [N,h,w,2C] bf16, eps [N,h,w,C] f32 -> z [N,h,w,ld_out] bf16 (zero padded channels)."""
-    _req(moments, torch.bfloat16, "moments"); _req(eps, torch.float32, "eps")
+    _req(moments, act_dtype(), "moments"); _req(eps, torch.float32, "eps")
     N, h, w, _ = moments.shape
     ld_out = ld_out or _round_up(latent_channels, 8)
-    z = torch.empty((N, h, w, ld_out), device=moments.device, dtype=torch.bfloat16)
+    z = torch.empty((N, h, w, ld_out), device=moments.device, dtype=act_dtype())
     check(_lib.load().omgsr_vae_sample(moments.data_ptr(), eps.data_ptr(), z.data_ptr(), N * h * w, latent_channels, ld_out,
                                        shift, scale, _stream()), "omgsr_vae_sample")
     return z
@@ -439,7 +464,7 @@ def vae_sample(moments: torch.Tensor, eps: torch.Tensor, latent_channels: int, s
 
 def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float, c: float = 0.0, d: float = 1.0,
           bf16_steps: bool = False) -> torch.Tensor:
-    _req(x, torch.bfloat16, "x")
+    _req(x, act_dtype(), "x")
     out = torch.empty_like(x)
     check(_lib.load().omgsr_axpby(x.data_ptr(), _ptr(y), out.data_ptr(), x.numel(), a, b, c, d, int(bf16_steps), _stream()),
           "omgsr_axpby")
@@ -454,7 +479,7 @@ def tile_accumulate(tile: Optional[torch.Tensor], w: torch.Tensor, acc: torch.Te
     th, tw = w.shape
     tile_ld = 0
     if tile is not None:
-        _req(tile, torch.bfloat16, "tile")
+        _req(tile, act_dtype(), "tile")
         tile_ld = tile.shape[-1]
     check(_lib.load().omgsr_tile_accumulate(_ptr(tile), w.data_ptr(), acc.data_ptr(), N, Cc, th, tw, tile_ld, H, W, y0, x0,
                                             _stream()), "omgsr_tile_accumulate")
@@ -463,23 +488,23 @@ def tile_accumulate(tile: Optional[torch.Tensor], w: torch.Tensor, acc: torch.Te
 def tile_normalise(acc: torch.Tensor, wsum: torch.Tensor, ld: Optional[int] = None) -> torch.Tensor:
     N, H, W, Cc = acc.shape
     ld = ld or _round_up(Cc, 8)
-    out = torch.empty((N, H, W, ld), device=acc.device, dtype=torch.bfloat16)
+    out = torch.empty((N, H, W, ld), device=acc.device, dtype=act_dtype())
     check(_lib.load().omgsr_tile_normalise(acc.data_ptr(), wsum.data_ptr(), out.data_ptr(), N, H * W, Cc, ld, _stream()),
           "omgsr_tile_normalise")
     return out
 
 
 def crop_nhwc(x: torch.Tensor, y0: int, x0: int, th: int, tw: int) -> torch.Tensor:
-    _req(x, torch.bfloat16, "x")
+    _req(x, act_dtype(), "x")
     N, H, W, Cc = x.shape
-    out = torch.empty((N, th, tw, Cc), device=x.device, dtype=torch.bfloat16)
+    out = torch.empty((N, th, tw, Cc), device=x.device, dtype=act_dtype())
     check(_lib.load().omgsr_crop_nhwc(x.data_ptr(), out.data_ptr(), N, H, W, Cc, y0, x0, th, tw, _stream()), "omgsr_crop_nhwc")
     return out
 
 
 def paste_nhwc(src: torch.Tensor, dst: torch.Tensor, sy0: int, sx0: int, dy0: int, dx0: int, th: int, tw: int) -> None:
     """dst[:, dy0:dy0+th, dx0:dx0+tw, :] = src[:, sy0:sy0+th, sx0:sx0+tw, :] (bf16 NHWC, same N and C)."""
-    _req(src, torch.bfloat16, "src"); _req(dst, torch.bfloat16, "dst")
+    _req(src, act_dtype(), "src"); _req(dst, act_dtype(), "dst")
     N, sH, sW, Cc = src.shape
     if dst.shape[0] != N or dst.shape[3] != Cc:
         raise ValueError("paste_nhwc: batch/channel mismatch")
@@ -489,19 +514,19 @@ def paste_nhwc(src: torch.Tensor, dst: torch.Tensor, sy0: int, sx0: int, dy0: in
 
 def flux_pack(x: torch.Tensor, channels: int) -> torch.Tensor:
     """NHWC [N,H,W,ld] (first `channels`) -> tokens [N, (H/2)(W/2), 4*channels]."""
-    _req(x, torch.bfloat16, "x")
+    _req(x, act_dtype(), "x")
     N, H, W, ld = x.shape
-    out = torch.empty((N, (H // 2) * (W // 2), 4 * channels), device=x.device, dtype=torch.bfloat16)
+    out = torch.empty((N, (H // 2) * (W // 2), 4 * channels), device=x.device, dtype=act_dtype())
     check(_lib.load().omgsr_flux_pack(x.data_ptr(), out.data_ptr(), N, H, W, channels, ld, 0, _stream()), "omgsr_flux_pack")
     return out
 
 
 def flux_unpack(tok: torch.Tensor, H: int, W: int, ld: Optional[int] = None) -> torch.Tensor:
-    _req(tok, torch.bfloat16, "tok")
+    _req(tok, act_dtype(), "tok")
     N, _, c4 = tok.shape
     Cc = c4 // 4
     ld = ld or _round_up(Cc, 8)
-    out = torch.zeros((N, H, W, ld), device=tok.device, dtype=torch.bfloat16) if ld != Cc else \
-        torch.empty((N, H, W, ld), device=tok.device, dtype=torch.bfloat16)
+    out = torch.zeros((N, H, W, ld), device=tok.device, dtype=act_dtype()) if ld != Cc else \
+        torch.empty((N, H, W, ld), device=tok.device, dtype=act_dtype())
     check(_lib.load().omgsr_flux_pack(tok.data_ptr(), out.data_ptr(), N, H, W, Cc, ld, 1, _stream()), "omgsr_flux_pack")
     return out

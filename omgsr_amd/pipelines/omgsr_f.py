@@ -44,6 +44,8 @@ class OMGSR_F_Infer(torch.nn.Module):
                  mid_timestep: int = 244, guidance_scale: float = 1.0, vae: Optional[AutoencoderKL] = None,
                  flux_transformer: Optional[FluxTransformer2DModel] = None, verbose: bool = False):
         super().__init__()
+        if weight_dtype in (torch.bfloat16, torch.float16):       # --weight_dtype picks the kernels' 16-bit type
+            ops.set_compute_dtype(weight_dtype)
         if vae is None:
             vae = AutoencoderKL.from_pretrained(flux_path, subfolder="vae")
         if flux_transformer is None:
@@ -92,7 +94,7 @@ class OMGSR_F_Infer(torch.nn.Module):
         C = self.vae.config.latent_channels
         dt = self.t_prev - self.t_curr
         moments = self.vae.encode_moments_nhwc(lq_nhwc8)
-        post = DiagonalGaussianDistribution(moments, C, self.vae.posterior_noise, torch.bfloat16)
+        post = DiagonalGaussianDistribution(moments, C, self.vae.posterior_noise, ops.act_dtype())
         z = post.sample_nhwc(shift=sh, scale=sf)                                  # [B,h,w,16]
         _, h, w, _ = z.shape
         if h * w <= tile_size * tile_size:
@@ -113,7 +115,7 @@ class OMGSR_F_Infer(torch.nn.Module):
         start_time = time.time()
         x = ops.nchw_to_nhwc(lq_img.contiguous(), 8)
         img = self.sr_nhwc(x, prompt_embeds, pooled_prompt_embeds, text_ids, latent_image_ids, tile_size, tile_overlap)
-        out_dtype = lq_img.dtype if lq_img.dtype in (torch.float32, torch.bfloat16) else torch.bfloat16
+        out_dtype = ops.io_dtype(lq_img)
         pred_img = ops.nhwc_to_nchw(img, channels=3, dtype=out_dtype)
         torch.cuda.synchronize()
         t = time.time() - start_time

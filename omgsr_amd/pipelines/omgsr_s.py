@@ -29,6 +29,8 @@ class OMGSR_S_Infer(torch.nn.Module):
         (infer/omgsr_s_infer_model.py:11-25); `vae=` / `unet=` inject already-built modules instead
         (synthetic-weight benchmarks and tests — there are no checkpoints on the GPU box)."""
         super().__init__()
+        if weight_dtype in (torch.bfloat16, torch.float16):       # --weight_dtype picks the kernels' 16-bit type
+            ops.set_compute_dtype(weight_dtype)
         self.mid_timestep = mid_timestep
         self.verbose = verbose
         if vae is None:
@@ -80,7 +82,7 @@ class OMGSR_S_Infer(torch.nn.Module):
 
     def vae_posterior(self, moments):
         from ..diffusers_api.autoencoder_kl import DiagonalGaussianDistribution
-        return DiagonalGaussianDistribution(moments, self.vae.config.latent_channels, self.vae.posterior_noise, torch.bfloat16)
+        return DiagonalGaussianDistribution(moments, self.vae.config.latent_channels, self.vae.posterior_noise, ops.act_dtype())
 
     # ---- reference API ---------------------------------------------------------------------
     @torch.no_grad()
@@ -89,7 +91,7 @@ class OMGSR_S_Infer(torch.nn.Module):
         start_time = time.time()
         x = ops.nchw_to_nhwc(lq_img.contiguous(), 8)
         img = self.sr_nhwc(x, prompt_embeds, tile_size, tile_overlap)
-        out_dtype = lq_img.dtype if lq_img.dtype in (torch.float32, torch.bfloat16) else torch.bfloat16
+        out_dtype = ops.io_dtype(lq_img)
         pred_img = ops.nhwc_to_nchw(img, channels=3, dtype=out_dtype, clamp=(-1.0, 1.0))
         torch.cuda.synchronize()
         t = time.time() - start_time

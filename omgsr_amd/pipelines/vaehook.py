@@ -170,7 +170,7 @@ class VAEHook:
         groups = self._run(seq, groups, counts, N, fixed=fixed)
         Ho, Wo = (H * 8, W * 8) if self.is_decoder else (H // 8, W // 8)
         Cout = next(iter(groups.values())).shape[-1]
-        result = torch.zeros((N, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16)
+        result = torch.zeros((N, Ho, Wo, Cout), device=x.device, dtype=ops.act_dtype())
         for k, idx in order.items():
             t = groups[k]
             for j, i in enumerate(idx):
@@ -193,7 +193,7 @@ class VAEHook:
         std_n, mean_n = torch.std_mean(small, dim=[0, 2, 3], keepdim=True)
         std_n = torch.where(std_n == 0, torch.ones_like(std_n), std_n)      # zero-padded channels
         small = ((small - mean_n) / std_n * std_o + mean_o).clamp_(min=float(xc.min()), max=float(xc.max()))
-        small = small.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+        small = small.permute(0, 2, 3, 1).to(ops.act_dtype()).contiguous()
         record: list = []
         self._run(seq, {(small.shape[1], small.shape[2]): small}, {(small.shape[1], small.shape[2]): 1}, N, record=record)
         return record

@@ -18,8 +18,18 @@ def _ops():
     return ops
 
 
+@pytest.fixture(autouse=True, params=["bf16", "fp16"])
+def compute_dtype(request):
+    """Every kernel test runs in both 16-bit modes (omgsr_set_compute_dtype); inputs are bf16-representable
+    values, which fp16 holds exactly in the normal range, so one fp32 reference serves both."""
+    ops = _ops()
+    ops.set_compute_dtype(torch.bfloat16 if request.param == "bf16" else torch.float16)
+    yield request.param
+    ops.set_compute_dtype(torch.bfloat16)
+
+
 def bf(x):
-    return x.to(torch.bfloat16)
+    return x.to(_ops().act_dtype())
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -183,14 +193,14 @@ def test_linear_into_slices():
     xc, xi = rnd(Lc, K, seed=60), rnd(Li, K, seed=61)
     wc, wi = rnd(Nout, K, seed=62, scale=K ** -0.5), rnd(Nout, K, seed=63, scale=K ** -0.5)
     bc, bi = rnd(Nout, seed=64), rnd(Nout, seed=65)
-    joint = torch.full((Lc + Li, 2 * Nout + 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    joint = torch.full((Lc + Li, 2 * Nout + 64), 7.0, dtype=_ops().act_dtype(), device=DEV)
     ops.linear_into(bf(xc).to(DEV), ops.pack_linear_weight(wc, bc, device=DEV), joint, 0, Nout)
     ops.linear_into(bf(xi).to(DEV), ops.pack_linear_weight(wi, bi, device=DEV), joint, Lc, Nout, act=ops.ACT_GELU_TANH)
     j = joint.float().cpu()
     assert_close(j[:Lc, Nout:2 * Nout], F.linear(xc, wc, bc), "linear_into ctx")
     assert_close(j[Lc:, Nout:2 * Nout], F.gelu(F.linear(xi, wi, bi), approximate="tanh"), "linear_into img")
     assert (j[:, :Nout] == 7).all() and (j[:, 2 * Nout:] == 7).all()          # nothing outside the slice is touched
-    vt = torch.zeros((Nout, Lc + Li), dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros((Nout, Lc + Li), dtype=_ops().act_dtype(), device=DEV)
     ops.linear_t_into(bf(xc).to(DEV), ops.pack_linear_weight(wc, bc, device=DEV), vt, 0)
     ops.linear_t_into(bf(xi).to(DEV), ops.pack_linear_weight(wi, bi, device=DEV), vt, Lc)
     ref = torch.cat([F.linear(xc, wc, bc), F.linear(xi, wi, bi)], 0).t()

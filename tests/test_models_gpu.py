@@ -14,12 +14,27 @@ SMALL_VAE = dict(block_out_channels=[32, 64, 128, 128], layers_per_block=1, norm
 SMALL_UNET = dict(block_out_channels=[64, 128, 256, 256], attention_head_dim=[1, 2, 4, 4], cross_attention_dim=128, layers_per_block=2)
 
 
+WD = torch.bfloat16
+
+
+@pytest.fixture(autouse=True, params=["bf16", "fp16"])
+def compute_dtype(request):
+    """Both --weight_dtype options of the reference's drivers (infer/infer_omgsr_s.py:134-149)."""
+    global WD
+    from omgsr_amd import ops
+    WD = torch.bfloat16 if request.param == "bf16" else torch.float16
+    ops.set_compute_dtype(WD)
+    yield request.param
+    WD = torch.bfloat16
+    ops.set_compute_dtype(WD)
+
+
 def _pair(product_cls, oracle_cls, cfg, seed):
     from omgsr_amd.testing import seeded_init_
     o = seeded_init_(oracle_cls(**cfg), seed).eval()
     p = product_cls(**cfg)
     p.load_state_dict(o.state_dict())
-    return p.to(DEV, torch.bfloat16).eval(), o
+    return p.to(DEV, WD).eval(), o
 
 
 def _report(name, got, ref, tol):
@@ -98,7 +113,7 @@ def test_omgsr_s_pipeline(h, w, tile, overlap):
     ov.posterior_noise = eps
     pv.posterior_noise = eps
     ref_pipe = OmgsrSRef(ov, ou, R.DDPMScheduler().alphas_cumprod[273], 273)
-    pipe = OMGSR_S_Infer(None, None, 273, DEV, torch.bfloat16, vae=pv, unet=pu)
+    pipe = OMGSR_S_Infer(None, None, 273, DEV, WD, vae=pv, unet=pu)
     with torch.no_grad():
         ref = ref_pipe(x, ehs, tile, overlap)
         got, secs = pipe(x.to(DEV), ehs.to(DEV), tile, overlap)
@@ -131,10 +146,10 @@ def test_flux_transformer_forward():
     with torch.no_grad():
         ref = o(hidden_states=x, timestep=t, guidance=gd, pooled_projections=pooled, encoder_hidden_states=pe,
                 txt_ids=tids, img_ids=iids, return_dict=False)[0]
-        got = p(hidden_states=x.to(DEV).to(torch.bfloat16), timestep=t.to(DEV), guidance=gd.to(DEV).to(torch.bfloat16),
-                pooled_projections=pooled.to(DEV).to(torch.bfloat16), encoder_hidden_states=pe.to(DEV).to(torch.bfloat16),
-                txt_ids=tids.to(DEV).to(torch.bfloat16), img_ids=iids.to(DEV).to(torch.bfloat16), return_dict=False)[0]
-    assert got.dtype == torch.bfloat16 and got.shape == ref.shape
+        got = p(hidden_states=x.to(DEV).to(WD), timestep=t.to(DEV), guidance=gd.to(DEV).to(WD),
+                pooled_projections=pooled.to(DEV).to(WD), encoder_hidden_states=pe.to(DEV).to(WD),
+                txt_ids=tids.to(DEV).to(WD), img_ids=iids.to(DEV).to(WD), return_dict=False)[0]
+    assert got.dtype == WD and got.shape == ref.shape
     _report("flux velocity", got, ref, 2e-2)
 
 
@@ -154,7 +169,7 @@ def test_omgsr_f_pipeline(h, w, tile, overlap):
     ov.posterior_noise = eps
     pv.posterior_noise = eps
     ref_pipe = OmgsrFRef(ov, of, 244, 1.0)
-    pipe = OMGSR_F_Infer(None, None, DEV, torch.bfloat16, 244, 1.0, vae=pv, flux_transformer=pf)
+    pipe = OMGSR_F_Infer(None, None, DEV, WD, 244, 1.0, vae=pv, flux_transformer=pf)
     assert pipe.t_curr == ref_pipe.t_curr and pipe.t_prev == 0.0
     with torch.no_grad():
         ref = ref_pipe(x, pe, pooled, tids, iids, tile, overlap)
@@ -222,7 +237,7 @@ def test_omgsr_s_with_tiled_vae():
             return type("D", (), {"sample": V.tiled_forward(ov.decoder, ov.post_quant_conv(zz), 8, True)})()
 
     ref_pipe = OmgsrSRef(HookedVae(), ou, R.DDPMScheduler().alphas_cumprod[273], 273)
-    pipe = OMGSR_S_Infer(None, None, 273, DEV, torch.bfloat16, vae=pv, unet=pu)
+    pipe = OMGSR_S_Infer(None, None, 273, DEV, WD, vae=pv, unet=pu)
     pipe._init_tiled_vae(encoder_tile_size=96, decoder_tile_size=8)
     with torch.no_grad():
         ref = ref_pipe(x, ehs, 16, 8)
