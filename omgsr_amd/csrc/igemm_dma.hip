@@ -227,6 +227,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
         if (kt + 2 < nk) kstep(std::integral_constant<int, 2>{}, kt + 2);
     }
 
+    if constexpr (ABL == 4) { if (p.alpha != 12345.0f) return; }      // no epilogue (never true at run time)
     static_assert(NW * 32 * (WTN + 4) * 4 <= LDS_BYTES, "epilogue staging must fit the ring");
     float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
     if (g.splits > 1) {
@@ -278,6 +279,7 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     if (abl && abl[0] == '1') return launch_dma<2, 2, 1>(a, g, st);
     if (abl && abl[0] == '2') return launch_dma<2, 2, 2>(a, g, st);
     if (abl && abl[0] == '3') return launch_dma<2, 2, 3>(a, g, st);
+    if (abl && abl[0] == '4') return launch_dma<2, 2, 4>(a, g, st);
     if (shape && shape[0] == '8') return launch_dma<4, 2>(a, g, st);
     // 256 x 256 tile (8 waves of 128x64): a third fewer operand bytes per FLOP; needs 256-row weight padding and
     // enough tiles to fill the chip

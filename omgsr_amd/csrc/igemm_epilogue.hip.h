@@ -50,6 +50,98 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
             gate8[e] = (p.gate && nlog + e < p.Cout) ? p.gate[nlog + e] : 1.0f;
         }
     }
+    // fast path (NHWC, 16-byte rows): every residual load of the tile is issued up front, before the barrier and
+    // the LDS staging, so the wave pays ONE global-load latency instead of one per row pass (the serial
+    // load -> add -> store chain made short-K GEMMs epilogue-bound: ~25 us per 256x128 tile,
+    // profiles/r01_pmc_igemm.md §7)
+    constexpr int EPI_CPR = WTN;                       // staged columns per row
+    const bool fast = vec_ok && p.out_layout == OMGSR_LAYOUT_NHWC;
+    const int n_out = geglu ? (n_base >> 1) + lcol : n_base + lcol;      // first logical output column of this lane
+    const bool col_ok = n_out < p.Cout;
+    if (fast) {
+        {
+            constexpr int NPASS_MAX = 32 / (64 / (EPI_CPR / 8));           // non-GEGLU passes per row block
+            const int npass = 32 / rows_per_pass;                          // GEGLU: half as many lanes per row -> 2x rows per pass
+            // two row blocks of residual in flight (32 VGPRs): block i + 2 is requested as soon as block i is stored
+            u32x4_t res[2][NPASS_MAX];
+            auto load_res = [&](const int i, u32x4_t (&dst)[NPASS_MAX]) {
+#pragma unroll
+                for (int ps = 0; ps < NPASS_MAX; ++ps) {
+                    const int row = ps * rows_per_pass + lrow;
+                    dst[ps] = (u32x4_t){0u, 0u, 0u, 0u};
+                    if (ps < npass && row < nvalid[i] && col_ok)
+                        dst[ps] = *reinterpret_cast<const u32x4_t*>(resb + (int64_t)(mb[i] + row) * p.Cout + n_out);
+                }
+            };
+            if (resb) {
+                load_res(0, res[0]);
+                if constexpr (FM > 1) load_res(1, res[1]);
+            }
+            __syncthreads();            // every wave is done reading the operand ring the staging region overlaps
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                float* wr = epi + px * EPI_LD + 4 * half;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4_t*>(wr + j * 32 + 8 * q) =
+                            (f32x4_t){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                wave_lds_fence();
+#pragma unroll
+                for (int ps = 0; ps < NPASS_MAX; ++ps) {
+                    if (ps >= npass) break;
+                    const int row = ps * rows_per_pass + lrow;
+                    float v[8];
+                    if (geglu) {
+                        const int grp = lcol >> 5, within = lcol & 31;
+                        const float* pa = epi + row * EPI_LD + grp * 64 + within;
+                        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(pa), a1 = *reinterpret_cast<const f32x4_t*>(pa + 4);
+                        const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(pa + 32), g1 = *reinterpret_cast<const f32x4_t*>(pa + 36);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (a0[e] * p.alpha + bias_a[e]) * gelu_erf_f(g0[e] * p.alpha + bias_g[e]);
+                            v[4 + e] = (a1[e] * p.alpha + bias_a[4 + e]) * gelu_erf_f(g1[e] * p.alpha + bias_g[4 + e]);
+                        }
+                    } else {
+                        const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(epi + row * EPI_LD + lcol);
+                        const f32x4_t x1 = *reinterpret_cast<const f32x4_t*>(epi + row * EPI_LD + lcol + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = x0[e] * p.alpha + bias_a[e]; v[4 + e] = x1[e] * p.alpha + bias_a[4 + e]; }
+                        if (p.act == OMGSR_ACT_SILU) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                        } else if (p.act == OMGSR_ACT_GELU_TANH) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                        }
+                    }
+                    if (p.gate) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= gate8[e];
+                    }
+                    if (resb) {
+                        float rf[8];
+                        unpack8<T>(res[i & 1][ps], rf);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+                    }
+                    if (row < nvalid[i] && col_ok) {
+                        const int64_t o = (int64_t)(mb[i] + row) * ldo + n_out;
+                        if (p.out_dtype == OMGSR_OUT_BF16) {
+                            *reinterpret_cast<u32x4_t*>(outb + o) = pack8<T>(v);
+                        } else {
+                            *reinterpret_cast<f32x4_t*>(outf + o) = (f32x4_t){v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4_t*>(outf + o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+                        }
+                    }
+                }
+                if (resb && i + 2 < FM) load_res(i + 2, res[i & 1]);
+                wave_lds_fence();       // this wave's reads are done before the next row block overwrites the region
+            }
+            return;
+        }
+    }
     __syncthreads();            // every wave is done reading the operand ring the staging region overlaps
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
