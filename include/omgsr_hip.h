@@ -89,11 +89,19 @@ typedef struct omgsr_igemm_args {
     const void* weight_cm; /* optional second packing of a 3x3 weight, chunk-major K order
                               k = ((c/32)*9 + r*3+s)*32 + c%32 (Cin % 32 == 0): enables the halo-tile kernel | NULL */
     void* workspace;       /* split-K scratch (f32), omgsr_igemm_workspace_bytes() bytes | NULL = never split */
+    float* gn_partial;     /* optional fused GroupNorm statistics of `out`: f32 [N][gn_slots][gn_groups][2] (sum, sum of
+                              squares per slot), to be folded by omgsr_groupnorm_finalize | NULL. Only when
+                              omgsr_igemm_gn_slots() > 0 for these arguments. */
+    int32_t gn_groups;
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
 /* Bytes of `workspace` that would let omgsr_igemm split the contraction of a small-M / large-K problem over
  * several workgroups (fp32 partial tiles + a reduce pass that applies the epilogue); 0 = no split for this shape. */
 int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* a);
+/* Slots per image of `gn_partial` if omgsr_igemm can emit the GroupNorm statistics of its output for these
+ * arguments (with gn_groups set; 3x3 halo-tile path, NHWC 16-byte rows, Cout/gn_groups in {4, 8, 16, 32, 64}),
+ * else 0: the caller then runs omgsr_groupnorm_stats on the output instead. */
+int32_t omgsr_igemm_gn_slots(const omgsr_igemm_args* a);
 
 /*
  * K4 — GroupNorm statistics and apply (replaces F.group_norm; the externally supplied
@@ -104,6 +112,10 @@ int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* a);
 int omgsr_groupnorm_nchunk(int64_t HW);
 int omgsr_groupnorm_stats(const void* x, float* partial, float* mean, float* rstd, float* var_out,
                           int32_t N, int64_t HW, int32_t C, int32_t G, float eps, void* stream);
+/* Second half of omgsr_groupnorm_stats alone: fold partial [N][nslot][G][2] (from omgsr_igemm's gn_partial) into
+ * mean / rstd (/ biased variance); count = elements per (image, group) = HW * C / G. */
+int omgsr_groupnorm_finalize(const float* partial, float* mean, float* rstd, float* var_out, int32_t N,
+                             int32_t nslot, int32_t G, double count, float eps, void* stream);
 /* y = act((x - mean[n,g]) * rstd[n,g] * gamma[c] + beta[c]);  act in {NONE, SILU}. x and y may alias. */
 int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int32_t N, int64_t HW, int32_t C,

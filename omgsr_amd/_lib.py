@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class OmgsrError(RuntimeError):
@@ -35,6 +35,7 @@ class IgemmArgs(C.Structure):
         ("batch", C.c_int32),
         ("in_bstride", C.c_int64), ("w_bstride", C.c_int64), ("out_bstride", C.c_int64),
         ("alpha", C.c_float), ("weight_cm", C.c_void_p), ("workspace", C.c_void_p),
+        ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
     ]
 
 
@@ -64,6 +65,8 @@ SIGNATURES = {
     "omgsr_error_string": (C.c_char_p, [C.c_int]),
     "omgsr_igemm": (C.c_int, [C.POINTER(IgemmArgs), _P]),
     "omgsr_igemm_workspace_bytes": (C.c_int64, [C.POINTER(IgemmArgs)]),
+    "omgsr_igemm_gn_slots": (C.c_int32, [C.POINTER(IgemmArgs)]),
+    "omgsr_groupnorm_finalize": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, C.c_double, _F, _P]),
     "omgsr_groupnorm_nchunk": (C.c_int, [_L]),
     "omgsr_groupnorm_stats": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _P]),
     "omgsr_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P]),

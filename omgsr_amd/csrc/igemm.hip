@@ -27,6 +27,7 @@ namespace omgsr {
 int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 int igemm_halo_tiles(const omgsr_igemm_args& a);
+int igemm_halo_gn_slots(const omgsr_igemm_args& a);
 }
 
 namespace {
@@ -244,7 +245,30 @@ int splitk_plan(const omgsr_igemm_args& a, int64_t M64) {
     return splits < 2 ? 1 : splits;
 }
 
+// the halo-tile kernel's preconditions + the "enough tiles to fill the chip" policy
+bool use_halo(const omgsr_igemm_args& a) {
+    static const char* mode = getenv("OMGSR_IGEMM_MODE");
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    const bool halo_ok = a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 &&
+                         !a.upsample && (a.Cin % 32) == 0 && a.batch == 1 && a.Ho == a.H && a.Wo == a.W && a.W >= 16 &&
+                         logical_cols >= 96 && a.out_layout == OMGSR_LAYOUT_NHWC;
+    if (!halo_ok || (mode && (!strcmp(mode, "reg") || !strcmp(mode, "dma")))) return false;
+    return (mode && !strcmp(mode, "halo")) || omgsr::igemm_halo_tiles(a) >= 192;
+}
+
 }  // namespace
+
+extern "C" int32_t omgsr_igemm_gn_slots(const omgsr_igemm_args* ap) {
+    if (!ap || ap->gn_groups <= 0 || ap->Cout <= 0 || (ap->Cout % ap->gn_groups)) return 0;
+    const int gsz = ap->Cout / ap->gn_groups;
+    if (!(gsz == 4 || gsz == 8 || gsz == 16 || gsz == 32 || gsz == 64)) return 0;
+    const int64_t ldo = ap->out_ld > 0 ? ap->out_ld : ap->Cout;
+    if ((ap->Cout & 7) || (ldo & 7) || ap->act == OMGSR_ACT_GEGLU) return 0;     // the epilogue's 16-byte-row fast path
+    if (!use_halo(*ap)) return 0;
+    const int64_t M64 = (int64_t)ap->N * ap->Ho * ap->Wo;
+    if (ap->workspace && splitk_plan(*ap, M64) > 1) return 0;
+    return omgsr::igemm_halo_gn_slots(*ap);
+}
 
 extern "C" int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* ap) {
     if (!ap) return 0;
@@ -301,12 +325,8 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         }
     }
     // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
-    const bool halo_ok = a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 &&
-                         !a.upsample && (a.Cin % 32) == 0 && a.batch == 1 && a.Ho == a.H && a.Wo == a.W && a.W >= 16 &&
-                         logical_cols >= 96 && a.out_layout == OMGSR_LAYOUT_NHWC;
-    if (halo_ok && !(mode && (!strcmp(mode, "reg") || !strcmp(mode, "dma"))) &&
-        ((mode && !strcmp(mode, "halo")) || omgsr::igemm_halo_tiles(a) >= 192))
-        return omgsr::igemm_halo_launch(a, g, st);
+    if (use_halo(a)) return omgsr::igemm_halo_launch(a, g, st);
+    if (a.gn_partial) return OMGSR_E_BADARG;      // fused GroupNorm statistics exist on the halo path only (omgsr_igemm_gn_slots)
     const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0;   // the DMA kernel's K-steps never straddle taps
     if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192)))
         return omgsr::igemm_dma_launch(a, g, st);

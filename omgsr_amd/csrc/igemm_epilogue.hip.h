@@ -20,7 +20,8 @@ OMGSR_DEVINL void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "me
 // [32 a | 32 g] per 64). Must be called by every wave of the block.
 template <typename T, int WTN, int FM, int FN>
 OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
-                                 const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz) {
+                                 const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
+                                 float* gn_dst = nullptr) {
     constexpr int EPI_LD = WTN + 4;
     static_assert(WTN == FN * 32, "wave tile width");
     const int half = lane >> 5, px = lane & 31;
@@ -77,6 +78,9 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                 load_res(0, res[0]);
                 if constexpr (FM > 1) load_res(1, res[1]);
             }
+            // fused GroupNorm statistics (gn_dst != NULL): this wave's (sum, sum of squares) of the values it
+            // stores, per group, for the two 4-channel halves of the lane's 8 channels
+            float gs[2] = {0.0f, 0.0f}, gq[2] = {0.0f, 0.0f};
             __syncthreads();            // every wave is done reading the operand ring the staging region overlaps
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
@@ -128,6 +132,13 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                     }
                     if (row < nvalid[i] && col_ok) {
                         const int64_t o = (int64_t)(mb[i] + row) * ldo + n_out;
+                        if (gn_dst) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                gs[0] += v[e]; gq[0] += v[e] * v[e];
+                                gs[1] += v[4 + e]; gq[1] += v[4 + e] * v[4 + e];
+                            }
+                        }
                         if (p.out_dtype == OMGSR_OUT_BF16) {
                             *reinterpret_cast<u32x4_t*>(outb + o) = pack8<T>(v);
                         } else {
@@ -138,6 +149,25 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                 }
                 if (resb && i + 2 < FM) load_res(i + 2, res[i & 1]);
                 wave_lds_fence();       // this wave's reads are done before the next row block overwrites the region
+            }
+            if (gn_dst) {
+                // lanes of one column chunk differ in lrow only: fold rows with a fixed butterfly (deterministic)
+                for (int o = lanes_per_row; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { gs[h] += __shfl_xor(gs[h], o); gq[h] += __shfl_xor(gq[h], o); }
+                }
+                const int gsz = p.Cout / p.gn_groups;          // channels per group: 4 or a multiple of 8 (<= WTN)
+                if (gsz == 4) {
+                    if (lrow == 0 && col_ok) {
+                        float* d = gn_dst + (n_out >> 2) * 2;
+                        *reinterpret_cast<f32x4_t*>(d) = (f32x4_t){gs[0], gq[0], gs[1], gq[1]};
+                    }
+                } else {
+                    float s1 = gs[0] + gs[1], q1 = gq[0] + gq[1];
+                    for (int o = 1; o * 8 < gsz; o <<= 1) { s1 += __shfl_xor(s1, o); q1 += __shfl_xor(q1, o); }
+                    if (lrow == 0 && col_ok && (n_out % gsz) == 0)
+                        *reinterpret_cast<f32x2_t*>(gn_dst + (n_out / gsz) * 2) = (f32x2_t){s1, q1};
+                }
             }
             return;
         }

@@ -219,7 +219,9 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
             for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
     } else {
         float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
-        igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0);
+        // fused GroupNorm statistics: slot = (spatial tile, upper / lower 4 tile rows), [N][2*tiles][G][2]
+        float* gn_dst = p.gn_partial ? p.gn_partial + ((int64_t)(img * per_img + trem) * 2 + wm) * p.gn_groups * 2 : nullptr;
+        igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0, gn_dst);
     }
 }
 
@@ -255,6 +257,9 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     else if (a.Cin >= 384) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, true>), grid, dim3(256), LDS_BYTES, st, a, g));
     else OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false>), grid, dim3(256), LDS_BYTES, st, a, g));
     return (int)hipGetLastError();
+}
+int igemm_halo_gn_slots(const omgsr_igemm_args& a) {
+    return 2 * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
 }
 int igemm_halo_tiles(const omgsr_igemm_args& a) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;

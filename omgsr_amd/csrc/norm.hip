@@ -315,6 +315,14 @@ extern "C" int omgsr_groupnorm_stats(const void* x, float* partial, float* mean,
     return (int)hipGetLastError();
 }
 
+extern "C" int omgsr_groupnorm_finalize(const float* partial, float* mean, float* rstd, float* var_out, int32_t N,
+                                        int32_t nslot, int32_t G, double count, float eps, void* stream) {
+    if (!partial || !mean || !rstd || N <= 0 || nslot <= 0 || G <= 0 || count <= 0.0) return OMGSR_E_BADARG;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(64), 0, (hipStream_t)stream, partial, mean, rstd, var_out,
+                       N, G, nslot, count, eps);
+    return (int)hipGetLastError();
+}
+
 extern "C" int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                                      const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act,
                                      void* stream) {

@@ -46,10 +46,10 @@ class ResnetBlock2D(nn.Module):
     def nhwc(self, x, conv1_bias=None):
         """conv1_bias: conv1.bias + time_emb_proj(silu(temb)) folded by the UNet (constant at fixed t*)."""
         h = self.norm1.nhwc(x, ops.ACT_SILU)
-        h = self.conv1.nhwc(h, bias_override=conv1_bias)
+        h = self.conv1.nhwc(h, bias_override=conv1_bias, gn_groups=self.norm2.num_groups)     # norm2's statistics ride the epilogue
         h = self.norm2.nhwc(h, ops.ACT_SILU)
         sc = self.conv_shortcut.nhwc(x, pad=0) if self.conv_shortcut is not None else x
-        return self.conv2.nhwc(h, residual=sc)
+        return self.conv2.nhwc(h, residual=sc, gn_groups=self.norm1.num_groups)             # ... and the next block's norm1
 
 
 class Downsample2D(nn.Module):

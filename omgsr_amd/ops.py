@@ -159,8 +159,10 @@ def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device
 def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, int, int] | int = 1,
            upsample: bool = False, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
            gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_BF16, alpha: float = 1.0,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [N,H,W,Cin] bf16 -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on the (virtual) input."""
+           out: Optional[torch.Tensor] = None, gn_groups: int = 0) -> torch.Tensor:
+    """x [N,H,W,Cin] bf16 -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on the (virtual) input.
+    gn_groups > 0: the caller will GroupNorm the result with that many groups; when the kernel can, it emits the
+    (sum, sum of squares) partials from its epilogue and group_norm_stats() skips its read pass over the tensor."""
     _req(x, act_dtype(), "x")
     N, H, W, Cin = x.shape
     if Cin != pw.cin:
@@ -192,7 +194,16 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     a.t_rows, a.t_ld = 0, 0
     a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
     a.alpha = alpha
+    partial = None
+    if gn_groups > 0:
+        a.gn_groups = gn_groups
+        nslot = _lib.load().omgsr_igemm_gn_slots(C.byref(a))
+        if nslot > 0:
+            partial = torch.empty((N, nslot, gn_groups, 2), device=x.device, dtype=torch.float32)
+            a.gn_partial = partial.data_ptr()
     _igemm(a, x.device, "omgsr_igemm(conv2d)")
+    if partial is not None:
+        out._omgsr_gn = (partial, gn_groups, out.data_ptr(), out._version)      # consumed by group_norm_stats(out)
     return out
 
 
@@ -315,11 +326,19 @@ def group_norm_stats(x: torch.Tensor, groups: int, eps: float):
     N, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * Cc)
     lib = _lib.load()
-    nchunk = lib.omgsr_groupnorm_nchunk(HW)
-    partial = torch.empty((N, nchunk, groups, 2), device=x.device, dtype=torch.float32)
     mean = torch.empty((N, groups), device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     var = torch.empty_like(mean)
+    fused = getattr(x, "_omgsr_gn", None)
+    if fused is not None and fused[1] == groups and fused[2] == x.data_ptr() and fused[3] == x._version \
+            and fused[0].shape[0] == N:
+        # the producing conv already reduced this tensor (omgsr_igemm gn_partial): fold its partials only
+        check(lib.omgsr_groupnorm_finalize(fused[0].data_ptr(), mean.data_ptr(), rstd.data_ptr(), var.data_ptr(), N,
+                                           fused[0].shape[1], groups, float(HW) * (Cc // groups), eps, _stream()),
+              "omgsr_groupnorm_finalize")
+        return mean, rstd, var
+    nchunk = lib.omgsr_groupnorm_nchunk(HW)
+    partial = torch.empty((N, nchunk, groups, 2), device=x.device, dtype=torch.float32)
     check(lib.omgsr_groupnorm_stats(x.data_ptr(), partial.data_ptr(), mean.data_ptr(), rstd.data_ptr(), var.data_ptr(),
                                     N, HW, Cc, groups, eps, _stream()), "omgsr_groupnorm_stats")
     return mean, rstd, var

@@ -71,9 +71,9 @@ class VAEHook:
         def resblock(b):
             seq.append(("res_push", (lambda x, b=b: b.conv_shortcut.nhwc(x, pad=0)) if b.conv_shortcut is not None else None))
             seq.append(("gn", b.norm1, ops.ACT_SILU))
-            seq.append(("f", lambda x, b=b: b.conv1.nhwc(x)))
+            seq.append(("f", lambda x, b=b: b.conv1.nhwc(x, gn_groups=b.norm2.num_groups)))
             seq.append(("gn", b.norm2, ops.ACT_SILU))
-            seq.append(("conv_res", b.conv2))                      # conv2 + residual in the GEMM epilogue
+            seq.append(("conv_res", b.conv2, b.norm1.num_groups))  # conv2 + residual in the GEMM epilogue (+ next GN statistics)
 
         def attn(a):
             seq.append(("res_push", None))
@@ -147,7 +147,7 @@ class VAEHook:
                     res[k].append(op[1](groups[k]) if op[1] is not None else groups[k])
             elif kind == "conv_res":
                 for k in groups:
-                    groups[k] = op[1].nhwc(groups[k], residual=res[k].pop())
+                    groups[k] = op[1].nhwc(groups[k], residual=res[k].pop(), gn_groups=op[2])
             elif kind == "attn_res":
                 for k in groups:
                     groups[k] = op[1].attend(groups[k], residual=res[k].pop())

@@ -402,3 +402,32 @@ def test_tile_stitch_ops():
     wsum.clamp_(min=1e-3)
     out = ops.tile_normalise(acc, wsum)
     assert_close(out[..., :Cc], ref_acc / ref_w[None, :, :, None], "tile_normalise")
+
+
+@pytest.mark.parametrize("N,C,Cout,H,W,res", [(2, 128, 128, 128, 192, False), (2, 256, 256, 80, 160, True), (2, 512, 512, 64, 96, True),
+                                               (2, 128, 256, 86, 150, False)])      # >= 192 halo tiles each
+def test_conv_fused_groupnorm_statistics(N, C, Cout, H, W, res):
+    """omgsr_igemm's gn_partial: the conv epilogue emits the (sum, sum of squares) of what it stores; GroupNorm of
+    the result must equal F.group_norm of the conv output, and must not launch the statistics read pass."""
+    ops = _ops()
+    x = rnd(N, C, H, W, seed=90)
+    w = rnd(Cout, C, 3, 3, seed=91, scale=(9 * C) ** -0.5)
+    b = rnd(Cout, seed=92)
+    r = rnd(N, Cout, H, W, seed=93) if res else None
+    ref_conv = F.conv2d(x, w, b, padding=1) + (r if res else 0)
+    gamma, beta = rnd(Cout, seed=94) + 1.0, rnd(Cout, seed=95)
+    ref = F.silu(F.group_norm(ref_conv, 32, gamma, beta, eps=1e-6))
+    pw = ops.pack_conv_weight(w, b, device=DEV)
+    y = ops.conv2d(nhwc(x), pw, pad=1, residual=None if r is None else nhwc(r), gn_groups=32)
+    assert getattr(y, "_omgsr_gn", None) is not None, "the halo path should have emitted statistics for this shape"
+    assert_close(to_nchw(y), ref_conv, "conv out")
+    mean, rstd, var = ops.group_norm_stats(y, 32, 1e-6)
+    g = ref_conv.view(N, 32, -1)
+    assert torch.allclose(mean.cpu(), g.mean(-1), atol=2e-3, rtol=2e-3)
+    assert torch.allclose(var.cpu(), g.var(-1, unbiased=False), atol=2e-3, rtol=4e-3)
+    out = ops.group_norm_apply(y, mean, rstd, gamma.to(DEV), beta.to(DEV), 32, ops.ACT_SILU)
+    assert_close(to_nchw(out), ref, "fused-stat groupnorm", rel_l2=6e-3, max_ulps=6.0)
+    # same tensor without the handle: the classic two-kernel path agrees to fp32 rounding of the statistics
+    y2 = y.clone()
+    m2, r2, v2 = ops.group_norm_stats(y2, 32, 1e-6)
+    assert torch.allclose(mean, m2, atol=2e-3, rtol=2e-3) and torch.allclose(var, v2, atol=2e-3, rtol=4e-3)
