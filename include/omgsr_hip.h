@@ -86,8 +86,8 @@ typedef struct omgsr_igemm_args {
     int32_t batch;         /* grid.z; strides below are in elements                    */
     int64_t in_bstride, w_bstride, out_bstride;
     float alpha;
-    const void* weight_cm; /* optional second packing of a 3x3 weight, chunk-major K order
-                              k = ((c/32)*9 + r*3+s)*32 + c%32 (Cin % 32 == 0): enables the halo-tile kernel | NULL */
+    const void* weight_cm; /* optional second packing of a 3x3 weight, slice-major [Cin/32][9 taps][Cout_pad][32]
+                              (Cin % 32 == 0; tap = r*3+s): enables the halo-tile kernel | NULL */
     void* workspace;       /* split-K scratch (f32), omgsr_igemm_workspace_bytes() bytes | NULL = never split */
     float* gn_partial;     /* optional fused GroupNorm statistics of `out`: f32 [N][gn_slots][gn_groups][2] (sum, sum of
                               squares per slot), to be folded by omgsr_groupnorm_finalize | NULL. Only when

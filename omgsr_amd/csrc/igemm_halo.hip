@@ -8,8 +8,9 @@
 //    the (8+2) x (32+2) input patch is DMA'd into LDS ONCE (21.3 KB) and all 9 taps read their MFMA A
 //    fragments from it at shifted rows (fragment = 32 consecutive pixels of one tile row, so the swizzled
 //    linear image stays conflict-free at any shift)      -> A traffic 144 KB -> 24 KB per chunk
-//  * K order is chunk-major: k = (cc*9 + tap)*32 + c, the weights are packed that way (`weight_cm`);
-//    a K-step = (chunk, tap) streams only its 8 KB weight slice through a 3-deep ring
+//  * K order is chunk-major: k = (cc*9 + tap)*32 + c, and the weights are packed SLICE-major (`weight_cm` =
+//    [Cin/32][9][Cout_pad][32]): a K-step = (chunk, tap) streams its 8 KB weight slice, one contiguous run of
+//    full 128-B lines, through a 3-deep ring (row-major weights made every DMA instruction touch 16 half lines)
 //  * per 18.9 MFLOP chunk: 24 KB (A, double-buffered, prefetched one chunk ahead) + 72 KB (B) = 5.1 KB/MFLOP
 //    vs 12 KB/MFLOP for the GEMM-shaped kernel
 //  * 4 waves, 128 x 64 per wave (4 tile rows x 64 couts), one raw s_barrier per K-step, counted vmcnt
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     const unsigned char* b_ptr[BPW];
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
-        b_ptr[i] = reinterpret_cast<const unsigned char*>(wt + (int64_t)(n0 + 16 * (wave * BPW + i) + lrow) * p.K_pad + kc * 8);
+        b_ptr[i] = reinterpret_cast<const unsigned char*>(wt + (int64_t)(n0 + 16 * (wave * BPW + i) + lrow) * 32 + kc * 8);
+    const int64_t b_step = (int64_t)p.Cout_pad * 64;       // bytes between consecutive (chunk, tap) slices
 
     auto issue_a = [&](int buf) {
 #pragma unroll
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
             glds16(b_ptr[i], __builtin_amdgcn_readfirstlane(dst + i * 1024));
-            b_ptr[i] += 64;
+            b_ptr[i] += b_step;
         }
     };
 
@@ -143,15 +145,18 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
             aoff[tp][i] = row * 64 + ((half ^ ((row >> 2) & 3)) << 4);
         }
 
-    issue_a(0);
-    issue_b(0);
-    issue_b(1);
+    if constexpr (ABL != 2) {
+        issue_a(0);
+        issue_b(0);
+        issue_b(1);
+    }
 
     // one K-step with compile-time tap and patch parity
     auto step = [&](auto tap_c, auto par_c, const int cc, const int s) {
         constexpr int tap = decltype(tap_c)::value, par = decltype(par_c)::value;
         // wait for slice s: only what the PREVIOUS step issued may still be in flight
-        if constexpr (tap == 1) {
+        if constexpr (ABL == 2) {
+        } else if constexpr (tap == 1) {
             if (cc + 1 < ncc) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else if constexpr (tap == 8) {
@@ -162,8 +167,11 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (tap == 0) { if (cc + 1 < ncc) issue_a(par ^ 1); }
-        if (s + 2 < nsteps) issue_b((tap + 2) % NB);
+        if constexpr (ABL != 2) {
+            if constexpr (tap == 0) { if (cc + 1 < ncc) issue_a(par ^ 1); }
+            if (s + 2 < nsteps) issue_b((tap + 2) % NB);
+        }
+        if constexpr (ABL == 3) return;
 
         const unsigned char* As = lds + par * A_BYTES;
         const unsigned char* Bs = lds + B_OFF + (tap % NB) * B_BYTES;
@@ -243,6 +251,8 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
         const void* fns[] = {reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, false>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, true>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 1, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 2, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 3, false>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, true>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 1, false>)};
@@ -254,6 +264,8 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     dim3 grid(g.ntm * g.ntn, 1, 1);
     static const char* abl = getenv("OMGSR_HALO_ABLATE");      // timing experiments only
     if (abl && abl[0] == '1') OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 1, false>), grid, dim3(256), LDS_BYTES, st, a, g));
+    else if (abl && abl[0] == '2') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 2, false>), grid, dim3(256), LDS_BYTES, st, a, g);
+    else if (abl && abl[0] == '3') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 3, false>), grid, dim3(256), LDS_BYTES, st, a, g);
     else if (a.Cin >= 384) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, true>), grid, dim3(256), LDS_BYTES, st, a, g));
     else OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false>), grid, dim3(256), LDS_BYTES, st, a, g));
     return (int)hipGetLastError();

@@ -123,9 +123,9 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
     b = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
     w_cm = None
     if R == 3 and S == 3 and cin8 % 32 == 0:
-        # k = ((c // 32) * 9 + tap) * 32 + c % 32
-        w_cm = torch.zeros_like(out)
-        w_cm[:cout] = out[:cout].view(cout, 9, cin8 // 32, 32).permute(0, 2, 1, 3).reshape(cout, 9 * cin8)
+        # slice-major: [Cin/32][9 taps][Cout_pad][32] - the 128 x 32 weight slice of one (chunk, tap) K-step is one
+        # contiguous 8 KB run, so every LDS-DMA wave instruction reads 8 full 128-B lines
+        w_cm = out.view(cout_pad, 9, cin8 // 32, 32).permute(2, 1, 0, 3).contiguous()
     return PackedWeight(out, b, cout, cin8, R, S, w_cm=w_cm)
 
 
