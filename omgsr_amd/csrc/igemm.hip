@@ -250,7 +250,7 @@ bool use_halo(const omgsr_igemm_args& a) {
     static const char* mode = getenv("OMGSR_IGEMM_MODE");
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     const bool halo_ok = a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 &&
-                         !a.upsample && (a.Cin % 32) == 0 && a.batch == 1 && a.Ho == a.H && a.Wo == a.W && a.W >= 16 &&
+                         (a.Cin % 32) == 0 && a.batch == 1 && a.Ho == (a.H << a.upsample) && a.Wo == (a.W << a.upsample) && a.Wo >= 16 &&
                          logical_cols >= 96 && a.out_layout == OMGSR_LAYOUT_NHWC;
     if (!halo_ok || (mode && (!strcmp(mode, "reg") || !strcmp(mode, "dma")))) return false;
     return (mode && !strcmp(mode, "halo")) || omgsr::igemm_halo_tiles(a) >= 192;

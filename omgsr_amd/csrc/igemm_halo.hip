@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     for (int i = 0; i < APW; ++i) {
         const int pr = 16 * (wave * APW + i) + lrow;
         const int py = pr / PW, px = pr - py * PW;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-        const bool ok = (wave * APW + i) < APIECES && pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        // (vy, vx): coordinates in the virtual (optionally nearest-2x upsampled) input = output coordinates
+        const int vy = y0 - 1 + py, vx = x0 - 1 + px;
+        const bool ok = (wave * APW + i) < APIECES && pr < PROWS && (unsigned)vy < (unsigned)p.Ho && (unsigned)vx < (unsigned)p.Wo;
+        const int iy = vy >> p.upsample, ix = vx >> p.upsample;
         const int64_t pix = ((int64_t)img * p.H + iy) * p.W + ix;
         a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * p.Cin + kc * 8)
                       : reinterpret_cast<const unsigned char*>(g_zero_page_h);
@@ -213,12 +215,12 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     }
 
     int mb[FM], nv[FM];
-    int colsv = p.W - x0; colsv = colsv > TW ? TW : colsv;
+    int colsv = p.Wo - x0; colsv = colsv > TW ? TW : colsv;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int y = y0 + 4 * wm + i;
-        mb[i] = (img * p.H + y) * p.W + x0;
-        nv[i] = (y < p.H) ? colsv : 0;
+        mb[i] = (img * p.Ho + y) * p.Wo + x0;
+        nv[i] = (y < p.Ho) ? colsv : 0;
     }
     if constexpr (ABL == 1) {      // timing experiment: keep the accumulators alive, skip the epilogue
 #pragma unroll
@@ -236,13 +238,13 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
 }  // namespace
 
 namespace omgsr {
-// Preconditions (checked by the dispatcher): R = S = 3, stride 1, pad 1, no upsample, Cin % 32 == 0,
+// Preconditions (checked by the dispatcher): R = S = 3, stride 1, pad 1 (on the virtual, optionally 2x-upsampled input), Cin % 32 == 0,
 // weight_cm != NULL, batch == 1, W >= 16.
 int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     g.nk = a.Cin / 32;
-    g.tiles_x = (a.W + TW - 1) / TW;
-    g.tiles_y = (a.H + TH - 1) / TH;
+    g.tiles_x = (a.Wo + TW - 1) / TW;
+    g.tiles_y = (a.Ho + TH - 1) / TH;
     g.ntm = a.N * g.tiles_x * g.tiles_y;
     g.ntn = (logical_cols + BN - 1) / BN;
     static bool attr_set = false;
@@ -271,10 +273,10 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 int igemm_halo_gn_slots(const omgsr_igemm_args& a) {
-    return 2 * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    return 2 * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
 }
 int igemm_halo_tiles(const omgsr_igemm_args& a) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
-    return a.N * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * ((logical_cols + BN - 1) / BN);
+    return a.N * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH) * ((logical_cols + BN - 1) / BN);
 }
 }  // namespace omgsr

@@ -69,8 +69,9 @@ class Upsample2D(nn.Module):
         super().__init__()
         self.conv = Conv2d(channels, channels, 3, padding=1)
 
-    def nhwc(self, x):
-        return self.conv.nhwc(x, upsample=True)
+    def nhwc(self, x, gn_groups: int = 0):
+        """gn_groups: groups of the GroupNorm that consumes the result directly (VAE decoder: the next block's norm1)."""
+        return self.conv.nhwc(x, upsample=True, gn_groups=gn_groups)
 
 
 class VaeAttention(nn.Module):
@@ -149,7 +150,7 @@ class UpDecoderBlock2D(nn.Module):
         for r in self.resnets:
             h = r.nhwc(h)
         if self.upsamplers is not None:
-            h = self.upsamplers[0].nhwc(h)
+            h = self.upsamplers[0].nhwc(h, gn_groups=self.resnets[0].norm1.num_groups)
         return h
 
 

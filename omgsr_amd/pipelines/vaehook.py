@@ -93,7 +93,7 @@ class VAEHook:
                 resblock(r)
             if i != len(blocks) - 1:
                 samp = blk.upsamplers[0] if dec else blk.downsamplers[0]
-                seq.append(("f", lambda x, s=samp: s.nhwc(x)))
+                seq.append(("f", (lambda x, s=samp, g=blk.resnets[0].norm1.num_groups: s.nhwc(x, gn_groups=g)) if dec else (lambda x, s=samp: s.nhwc(x))))
         if not dec:
             mid()
         seq.append(("gn", net.conv_norm_out, ops.ACT_SILU))

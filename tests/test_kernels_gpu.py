@@ -76,6 +76,8 @@ CONV_CASES = [
     (2, 128, 256, 20, 50, 1, (1, 1, 1, 1), False, True, True, 1),
     (1, 32, 128, 9, 33, 1, (1, 1, 1, 1), False, False, False, 0),
     (2, 256, 128, 64, 64, 1, (1, 1, 1, 1), False, True, True, 0),
+    (2, 128, 128, 64, 96, 1, (1, 1, 1, 1), True, True, False, 0),       # 2x upsample on the halo-tile path (>= 192 tiles)
+    (1, 64, 128, 43, 150, 1, (1, 1, 1, 1), True, False, False, 0),     # ... ragged
 ]
 
 
