@@ -116,10 +116,34 @@ int omgsr_groupnorm_stats(const void* x, float* partial, float* mean, float* rst
  * mean / rstd (/ biased variance); count = elements per (image, group) = HW * C / G. */
 int omgsr_groupnorm_finalize(const float* partial, float* mean, float* rstd, float* var_out, int32_t N,
                              int32_t nslot, int32_t G, double count, float eps, void* stream);
+/* First half of omgsr_groupnorm_stats alone: partial [N][omgsr_groupnorm_nchunk(HW)][G][2]. */
+int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N, int64_t HW, int32_t C, int32_t G, void* stream);
+/*
+ * Tiled-VAE statistics (infer/vaehook.py:459-534 GroupNormParam.summary + :384-413 custom_group_norm): the tiles of
+ * one image come in up to OMGSR_GN_MAX_GROUPS shape groups; group k holds tiles[k] x N rows (tile-major) of partials
+ * [rows][nslot[k]][G][2] with count[k] elements per (row, group channel set). Per image:
+ *   mean[n,g] = sum_k weight[k] * sum_t mean_{k,t,n,g},  var likewise,  rstd = rsqrt(var + eps)
+ * (weight[k] = pixels of one tile of group k / pixels of all tiles: the reference's pixel-weighted merge).
+ */
+#define OMGSR_GN_MAX_GROUPS 8
+typedef struct omgsr_gn_merge_args {
+    const float* partial[OMGSR_GN_MAX_GROUPS];
+    double count[OMGSR_GN_MAX_GROUPS];
+    float weight[OMGSR_GN_MAX_GROUPS];
+    int32_t tiles[OMGSR_GN_MAX_GROUPS];
+    int32_t nslot[OMGSR_GN_MAX_GROUPS];
+    int32_t ngroups;
+} omgsr_gn_merge_args;
+int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, float* mean, float* rstd, float* var_out,
+                                    int32_t N, int32_t G, float eps, void* stream);
 /* y = act((x - mean[n,g]) * rstd[n,g] * gamma[c] + beta[c]);  act in {NONE, SILU}. x and y may alias. */
 int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int32_t N, int64_t HW, int32_t C,
                           int32_t G, int32_t act, void* stream);
+/* Same with `rows` rows of x sharing `stat_rows` rows of statistics: row r uses mean[r % stat_rows] (tile-major tiles). */
+int omgsr_groupnorm_apply_shared(const void* x, void* y, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, int32_t rows, int64_t HW, int32_t C,
+                                 int32_t G, int32_t act, int32_t stat_rows, void* stream);
 
 /*
  * K9/K10 — LayerNorm over the last dim (replaces F.layer_norm and the AdaLN-Zero modulate chain of

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class OmgsrError(RuntimeError):
@@ -37,6 +37,15 @@ class IgemmArgs(C.Structure):
         ("alpha", C.c_float), ("weight_cm", C.c_void_p), ("workspace", C.c_void_p),
         ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
     ]
+
+
+GN_MAX_GROUPS = 8
+
+
+class GnMergeArgs(C.Structure):
+    _fields_ = [("partial", C.c_void_p * GN_MAX_GROUPS), ("count", C.c_double * GN_MAX_GROUPS),
+                ("weight", C.c_float * GN_MAX_GROUPS), ("tiles", C.c_int32 * GN_MAX_GROUPS),
+                ("nslot", C.c_int32 * GN_MAX_GROUPS), ("ngroups", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -67,6 +76,9 @@ SIGNATURES = {
     "omgsr_igemm_workspace_bytes": (C.c_int64, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_slots": (C.c_int32, [C.POINTER(IgemmArgs)]),
     "omgsr_groupnorm_finalize": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, C.c_double, _F, _P]),
+    "omgsr_groupnorm_partial": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
+    "omgsr_groupnorm_finalize_merged": (C.c_int, [C.POINTER(GnMergeArgs), _P, _P, _P, _I, _I, _F, _P]),
+    "omgsr_groupnorm_apply_shared": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "omgsr_groupnorm_nchunk": (C.c_int, [_L]),
     "omgsr_groupnorm_stats": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _P]),
     "omgsr_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P]),

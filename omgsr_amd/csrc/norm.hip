@@ -100,15 +100,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        int64_t HW, int C, int G, int act, int64_t px_per_block) {
+                                                        int64_t HW, int C, int G, int act, int64_t px_per_block, int stat_rows) {
     extern __shared__ __attribute__((aligned(16))) float gn_lds[];
     float* sc = gn_lds;
     float* sh = gn_lds + C;
     const int t = threadIdx.x, n = blockIdx.y;
+    const int ns = n % stat_rows;          // tiled VAE: rows are (tile, image) tile-major and share the image's statistics
     const int cpg = C / G;
     for (int c = t; c < C; c += 256) {
         const int g = c / cpg;
-        const float r = rstd[n * G + g], m = mean[n * G + g];
+        const float r = rstd[ns * G + g], m = mean[ns * G + g];
         const float a = r * (gamma ? gamma[c] : 1.0f);
         sc[c] = a;
         sh[c] = (beta ? beta[c] : 0.0f) - m * a;
@@ -323,9 +324,83 @@ extern "C" int omgsr_groupnorm_finalize(const float* partial, float* mean, float
     return (int)hipGetLastError();
 }
 
+namespace {
+// pass 2 for the tiled VAE: per-tile (mean, var) of every shape group, folded per image with pixel-count weights
+// (infer/vaehook.py GroupNormParam.summary: mean = sum_t w_t mean_t, var = sum_t w_t var_t). One wave per (n, g).
+__global__ void gn_finalize_merged_kernel(const omgsr_gn_merge_args a, float* __restrict__ mean, float* __restrict__ rstd,
+                                          float* __restrict__ var_out, int N, int G, float eps) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int n = i / G, g = i - n * G;
+    double m_acc = 0.0, v_acc = 0.0;
+    for (int k = 0; k < a.ngroups; ++k) {
+        const float* partial = a.partial[k];
+        const int nslot = a.nslot[k];
+        for (int t = 0; t < a.tiles[k]; ++t) {
+            const int row = t * N + n;
+            double s = 0.0, q = 0.0;
+            for (int c = lane; c < nslot; c += 64) {
+                const float* p = partial + (((int64_t)row * nslot + c) * G + g) * 2;
+                s += (double)p[0]; q += (double)p[1];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+            const double m = s / a.count[k];
+            double v = q / a.count[k] - m * m;
+            if (v < 0.0) v = 0.0;
+            m_acc += (double)a.weight[k] * m;
+            v_acc += (double)a.weight[k] * v;
+        }
+    }
+    if (lane != 0) return;
+    mean[i] = (float)m_acc;
+    rstd[i] = (float)(1.0 / sqrt(v_acc + (double)eps));
+    if (var_out) var_out[i] = (float)v_acc;
+}
+
+}  // namespace
+namespace {
+int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, void* stream);
+}
+
+extern "C" int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N, int64_t HW, int32_t C, int32_t G, void* stream) {
+    if (!x || !partial || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
+    if ((C & 7) || (C % G) || G > 256 || C > 8192) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = omgsr_groupnorm_nchunk(HW);
+    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 2.0 * N * (double)HW * C, st);
+    const int tp = (C >> 3) < 256 ? (C >> 3) : 256;
+    const size_t lds = 2 * (size_t)(256 / tp) * C * sizeof(float);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, N), dim3(256), lds, st,
+                                        (const T*)x, partial, HW, C, G, nchunk));
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, float* mean, float* rstd, float* var_out,
+                                               int32_t N, int32_t G, float eps, void* stream) {
+    if (!a || !mean || !rstd || N <= 0 || G <= 0 || a->ngroups <= 0 || a->ngroups > OMGSR_GN_MAX_GROUPS) return OMGSR_E_BADARG;
+    for (int k = 0; k < a->ngroups; ++k)
+        if (!a->partial[k] || a->tiles[k] <= 0 || a->nslot[k] <= 0 || a->count[k] <= 0.0) return OMGSR_E_BADARG;
+    hipLaunchKernelGGL(gn_finalize_merged_kernel, dim3(N * G), dim3(64), 0, (hipStream_t)stream, *a, mean, rstd, var_out, N, G, eps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_groupnorm_apply_shared(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
+                                            const float* beta, int32_t rows, int64_t HW, int32_t C, int32_t G, int32_t act,
+                                            int32_t stat_rows, void* stream) {
+    if (stat_rows <= 0 || rows % stat_rows) return OMGSR_E_BADARG;
+    return gn_apply_launch(x, y, mean, rstd, gamma, beta, rows, HW, C, G, act, stat_rows, stream);
+}
+
 extern "C" int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                                      const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act,
                                      void* stream) {
+    return gn_apply_launch(x, y, mean, rstd, gamma, beta, N, HW, C, G, act, N, stream);
+}
+
+namespace {
+int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, void* stream) {
     if (!x || !y || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
     if ((C & 7) || (C % G) || C > 8192) return OMGSR_E_SHAPE;
     if (act != OMGSR_ACT_NONE && act != OMGSR_ACT_SILU) return OMGSR_E_BADARG;
@@ -336,9 +411,10 @@ extern "C" int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, 
     const int nblk = (int)((HW + ppb - 1) / ppb);
     omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 4.0 * N * (double)HW * C, st);
     OMGSR_DISPATCH_T(hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nblk, N), dim3(256), 2 * C * sizeof(float), st, (const T*)x,
-                                        (T*)y, mean, rstd, gamma, beta, HW, C, G, act, ppb));
+                                        (T*)y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows));
     return (int)hipGetLastError();
 }
+}  // namespace
 
 extern "C" int omgsr_layernorm(const void* x, void* y, const float* a, const float* b, int64_t rows, int32_t C,
                                float eps, void* stream) {

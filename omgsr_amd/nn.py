@@ -80,6 +80,8 @@ class GroupNorm(nn.GroupNorm, _Packed):
     def apply_stats(self, x, mean, rstd, act=ops.ACT_NONE):
         """Normalise with externally supplied per-(n, group) statistics (tiled VAE)."""
         g, b = self._affine()
+        if mean.shape[0] != x.shape[0]:       # tile-major rows sharing their image's statistics
+            return ops.group_norm_apply_shared(x, mean, rstd, g, b, self.num_groups, act)
         return ops.group_norm_apply(x, mean, rstd, g, b, self.num_groups, act)
 
     def forward(self, x):  # NCHW (or [B, C, L]) compat

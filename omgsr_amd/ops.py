@@ -344,6 +344,60 @@ def group_norm_stats(x: torch.Tensor, groups: int, eps: float):
     return mean, rstd, var
 
 
+def group_norm_partial(x: torch.Tensor, groups: int) -> torch.Tensor:
+    """(sum, sum of squares) partials [N, nslot, G, 2] of x: the producing conv's fused ones when it left them
+    (conv2d gn_groups), else one read pass over x."""
+    _req(x, act_dtype(), "x")
+    N, Cc = x.shape[0], x.shape[-1]
+    fused = getattr(x, "_omgsr_gn", None)
+    if fused is not None and fused[1] == groups and fused[2] == x.data_ptr() and fused[3] == x._version and fused[0].shape[0] == N:
+        return fused[0]
+    HW = x.numel() // (N * Cc)
+    lib = _lib.load()
+    partial = torch.empty((N, lib.omgsr_groupnorm_nchunk(HW), groups, 2), device=x.device, dtype=torch.float32)
+    check(lib.omgsr_groupnorm_partial(x.data_ptr(), partial.data_ptr(), N, HW, Cc, groups, _stream()), "omgsr_groupnorm_partial")
+    return partial
+
+
+def group_norm_stats_merged(tensors, tiles, N: int, groups: int, eps: float):
+    """Tiled-VAE GroupNorm statistics in ONE launch: tensors[k] is [tiles[k]*N, h_k, w_k, C] (tile-major); returns
+    per-image (mean, rstd, var) [N, G] merged with pixel-count weights (the reference's GroupNormParam.summary)."""
+    if len(tensors) > _lib.GN_MAX_GROUPS:
+        raise ValueError(f"at most {_lib.GN_MAX_GROUPS} tile shape groups")
+    a = _lib.GnMergeArgs()
+    keep = []
+    tot = float(sum(t.shape[1] * t.shape[2] * tiles[k] for k, t in enumerate(tensors)))
+    for k, t in enumerate(tensors):
+        part = group_norm_partial(t, groups)
+        keep.append(part)
+        a.partial[k] = part.data_ptr()
+        a.nslot[k] = part.shape[1]
+        a.tiles[k] = tiles[k]
+        a.count[k] = float(t.shape[1] * t.shape[2] * (t.shape[3] // groups))
+        a.weight[k] = t.shape[1] * t.shape[2] / tot
+    a.ngroups = len(tensors)
+    dev = tensors[0].device
+    mean = torch.empty((N, groups), device=dev, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    var = torch.empty_like(mean)
+    check(_lib.load().omgsr_groupnorm_finalize_merged(C.byref(a), mean.data_ptr(), rstd.data_ptr(), var.data_ptr(), N, groups,
+                                                      eps, _stream()), "omgsr_groupnorm_finalize_merged")
+    return mean, rstd, var
+
+
+def group_norm_apply_shared(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma, beta, groups: int,
+                            act: int = ACT_NONE) -> torch.Tensor:
+    """x [T*N, ..., C] tile-major; mean / rstd [N, G]: row r is normalised with the statistics of image r % N."""
+    _req(x, act_dtype(), "x")
+    rows, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (rows * Cc)
+    y = torch.empty_like(x)
+    check(_lib.load().omgsr_groupnorm_apply_shared(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
+                                                   _ptr(beta), rows, HW, Cc, groups, act, mean.shape[0], _stream()),
+          "omgsr_groupnorm_apply_shared")
+    return y
+
+
 def group_norm_apply(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: Optional[torch.Tensor],
                      beta: Optional[torch.Tensor], groups: int, act: int = ACT_NONE, inplace: bool = False) -> torch.Tensor:
     _req(x, act_dtype(), "x")

@@ -119,26 +119,17 @@ class VAEHook:
                 G = norm.num_groups
                 if fixed is not None:
                     mean, var = fixed[gi]
+                    rstd = torch.rsqrt(var + 1e-6)                 # custom_group_norm: eps 1e-6
                 else:
-                    # per-tile statistics, merged per image with pixel-count weights (GroupNormParam.summary)
-                    tot_w, mean, var = 0.0, None, None
-                    stats = {}
-                    for k, t in groups.items():
-                        m, _, v = ops.group_norm_stats(t, G, norm.eps)
-                        stats[k] = (m.view(counts[k], N, G), v.view(counts[k], N, G))
-                        tot_w += counts[k] * t.shape[1] * t.shape[2]
-                    for k, (m, v) in stats.items():
-                        wgt = groups[k].shape[1] * groups[k].shape[2] / tot_w
-                        mean = m.sum(0) * wgt if mean is None else mean + m.sum(0) * wgt
-                        var = v.sum(0) * wgt if var is None else var + v.sum(0) * wgt
+                    # per-tile statistics merged per image with pixel-count weights (GroupNormParam.summary), one launch:
+                    # the partials come from the producing conv's epilogue where it left them
+                    keys = list(groups)
+                    mean, rstd, var = ops.group_norm_stats_merged([groups[k] for k in keys], [counts[k] for k in keys], N, G, 1e-6)
                 if record is not None:
                     record.append((mean, var))
                 gi += 1
-                rstd = torch.rsqrt(var + 1e-6)                     # custom_group_norm: eps 1e-6
                 for k in groups:
-                    mm = mean[None].expand(counts[k], N, G).reshape(-1, G).contiguous()
-                    rr = rstd[None].expand(counts[k], N, G).reshape(-1, G).contiguous()
-                    groups[k] = norm.apply_stats(groups[k], mm, rr, act)
+                    groups[k] = norm.apply_stats(groups[k], mean, rstd, act)   # rows (tile, image) share the image's statistics
             elif kind == "f":
                 for k in groups:
                     groups[k] = op[1](groups[k])

@@ -433,3 +433,34 @@ def test_conv_fused_groupnorm_statistics(N, C, Cout, H, W, res):
     y2 = y.clone()
     m2, r2, v2 = ops.group_norm_stats(y2, 32, 1e-6)
     assert torch.allclose(mean, m2, atol=2e-3, rtol=2e-3) and torch.allclose(var, v2, atol=2e-3, rtol=4e-3)
+
+
+def test_groupnorm_merged_tile_statistics():
+    """omgsr_groupnorm_finalize_merged + apply_shared: the tiled VAE's pixel-weighted merge of per-tile (mean, var)
+    (infer/vaehook.py GroupNormParam.summary) in one launch, rows (tile, image) tile-major."""
+    ops = _ops()
+    N, C, G = 2, 64, 32
+    shapes = {(20, 24): 3, (20, 9): 2, (7, 9): 1}           # (h, w) -> tiles
+    tens, tiles = [], []
+    for i, ((h, w), tcount) in enumerate(shapes.items()):
+        tens.append((rnd(tcount * N, C, h, w, seed=100 + i) * (1.0 + i) + 0.25 * i).to(torch.bfloat16).float())
+        tiles.append(tcount)
+    tot = sum(t.shape[2] * t.shape[3] * tiles[k] for k, t in enumerate(tens))
+    mean_ref = torch.zeros(N, G); var_ref = torch.zeros(N, G)
+    for k, t in enumerate(tens):
+        g = t.view(tiles[k], N, G, -1)
+        wgt = t.shape[2] * t.shape[3] / tot
+        mean_ref += g.mean(-1).sum(0) * wgt
+        var_ref += g.var(-1, unbiased=False).sum(0) * wgt
+    dev = [nhwc(t) for t in tens]
+    mean, rstd, var = ops.group_norm_stats_merged(dev, tiles, N, G, 1e-6)
+    assert torch.allclose(mean.cpu(), mean_ref, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(var.cpu(), var_ref, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(rstd.cpu(), torch.rsqrt(var_ref + 1e-6), rtol=1e-4)
+    gamma, beta = rnd(C, seed=110) + 1.0, rnd(C, seed=111)
+    for k, t in enumerate(tens):
+        y = ops.group_norm_apply_shared(dev[k], mean, rstd, gamma.to(DEV), beta.to(DEV), G, ops.ACT_SILU)
+        m = mean_ref.repeat(tiles[k], 1)[:, :, None, None].repeat_interleave(C // G, 1)
+        r = torch.rsqrt(var_ref + 1e-6).repeat(tiles[k], 1)[:, :, None, None].repeat_interleave(C // G, 1)
+        ref = F.silu((t - m) * r * gamma[None, :, None, None] + beta[None, :, None, None])
+        assert_close(to_nchw(y), ref, f"shared-stat apply group {k}")
