@@ -199,7 +199,16 @@ def main():
                         "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
                         "launches": ig["launches"], "kernel_ms": round(ig["ms"], 3),
-                        "algorithmic_tflop": round(ig["flops"] / 1e12, 3)}
+                        "algorithmic_tflop": round(ig["flops"] / 1e12, 3),
+                        "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"])}
+            # HBM bytes per launch of the same kernel family, from the committed rocprofv3 PMC passes of THIS workload
+            # (FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction; tools/traffic_summary.py)
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if args.workload == "s1024" and tiled_vae and WDTYPE == torch.bfloat16 and B == 4 and os.path.isfile(tpath):
+                fam = json.load(open(tpath))["families"].get("igemm")
+                if fam:
+                    roofline["traffic"] = round(fam["hbm_bytes_per_launch"])
+                    roofline["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
         names = {1: "igemm", 2: "attention", 3: "groupnorm", 4: "layernorm", 5: "elementwise", 6: "softmax"}
         extra["kernel_ms_by_family"] = {names.get(k, str(k)): round(v["ms"], 3) for k, v in sorted(kinds.items())}
         extra["pipeline_frac_of_mfma_peak"] = round(tflop_per_img * B * args.steps / elapsed / PEAK_BF16_DENSE_TFLOPS, 4) if world == 1 else None
