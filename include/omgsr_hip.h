@@ -225,6 +225,27 @@ int omgsr_paste_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t s
 int omgsr_flux_pack(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ld,
                     int32_t dir, void* stream);
 
+/*
+ * SURVEY §8(f) f1 — the driver's post-process on the device (replaces infer/infer_omgsr_s.py:96-103 and
+ * infer/wavelet_color_fix.py:12-125, which run on the CPU through PIL per image):
+ *   target = ToPILImage(clip(sr * 0.5 + 0.5, 0, 1))   (the "+ 0.5" rounds to the model dtype, the byte conversion truncates)
+ *   out    = uint8( colour_fix(target / 255, source / 255).clamp(0, 1) * 255 )
+ * sr_nhwc: model output, 16-bit compute dtype, [N,H,W,sr_ld] (channels 0..2 used), values in [-1, 1] unclamped;
+ * src_hwc3 / out_hwc3: uint8 [N,H,W,3] (the upscaled LQ image the model was fed / the result, PIL memory order).
+ * method: NONE (plain conversion, src and workspace may be NULL), ADAIN (per-image per-channel mean / unbiased-std
+ * match, statistics integer-exact), WAVELET (5-level a-trous low-frequency swap). workspace: device scratch of
+ * omgsr_colorfix_workspace_bytes() bytes.
+ */
+/* uint8 [N,H,W,3] -> model input [N,H,W,8] (compute dtype, channels 3..7 zero): to_tensor(img).to(dtype) * 2 - 1
+ * (infer/infer_omgsr_s.py:92), rounded to the dtype after each torch op. */
+int omgsr_image_to_model_input(const uint8_t* img_hwc3, void* out_nhwc8, int32_t N, int32_t H, int32_t W, void* stream);
+#define OMGSR_COLORFIX_NONE 0
+#define OMGSR_COLORFIX_ADAIN 1
+#define OMGSR_COLORFIX_WAVELET 2
+int64_t omgsr_colorfix_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t method);
+int omgsr_colorfix(const void* sr_nhwc, int32_t sr_ld, const uint8_t* src_hwc3, uint8_t* out_hwc3, void* workspace,
+                   int32_t N, int32_t H, int32_t W, int32_t method, void* stream);
+
 /* Optional per-launch timing (HIP events on the launch stream) for bench.py's roofline leg. */
 int omgsr_timing_enable(int on);
 int omgsr_timing_reset(void);
