@@ -43,13 +43,22 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
         const int grp = lcol >> 5, within = lcol & 31;
         const int nb = geglu ? n_base + grp * 64 + within : n_base + lcol;     // packed index
         const int nlog = geglu ? (n_base >> 1) + lcol : n_base + lcol;         // logical output column
+        // 8 consecutive floats per lane: two 16-byte loads each when the row of channels is whole (eight scalar
+        // loads per vector made even a LayerNorm kernel 5x slower, tools/bench_gn.py)
+        const bool whole = (p.Cout & 7) == 0 && (geglu || nb + 8 <= p.Cout);
+        auto load8 = [&](const float* v, const int c, const float dflt, const bool on, float (&o)[8]) {
+            if (on && whole) {
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(v + c), hi = *reinterpret_cast<const f32x4_t*>(v + c + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool in = geglu ? true : (nb + e < p.Cout);
-            bias_a[e] = (p.bias && in) ? p.bias[nb + e] : 0.0f;
-            bias_g[e] = (p.bias && geglu) ? p.bias[nb + 32 + e] : 0.0f;
-            gate8[e] = (p.gate && nlog + e < p.Cout) ? p.gate[nlog + e] : 1.0f;
-        }
+                for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (on && (geglu || c + e < p.Cout)) ? v[c + e] : dflt;
+            }
+        };
+        load8(p.bias, nb, 0.0f, p.bias != nullptr, bias_a);
+        load8(p.bias, nb + 32, 0.0f, p.bias != nullptr && geglu, bias_g);
+        load8(p.gate, nlog, 1.0f, p.gate != nullptr, gate8);
     }
     // fast path (NHWC, 16-byte rows): every residual load of the tile is issued up front, before the barrier and
     // the LDS staging, so the wave pays ONE global-load latency instead of one per row pass (the serial

@@ -3,6 +3,7 @@
 #include "common.hip.h"
 #include "../../include/omgsr_hip.h"
 #include "timing.hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -131,10 +132,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         int c8b = c8 + step8; if (c8b >= nch8) c8b -= nch8;
         float f[8], h[8];
         unpack8<T>(r0, f); unpack8<T>(r1, h);
+        // the (scale, shift) octets as four ds_read_b128 each (the compiler leaves them as 32 scalar LDS reads)
+        const f32x4_t* sa = reinterpret_cast<const f32x4_t*>(sc + c8 * 8);
+        const f32x4_t* ha = reinterpret_cast<const f32x4_t*>(sh + c8 * 8);
+        const f32x4_t* sb = reinterpret_cast<const f32x4_t*>(sc + c8b * 8);
+        const f32x4_t* hb = reinterpret_cast<const f32x4_t*>(sh + c8b * 8);
+        const f32x4_t sa0 = sa[0], sa1 = sa[1], ha0 = ha[0], ha1 = ha[1], sb0 = sb[0], sb1 = sb[1], hb0 = hb[0], hb1 = hb[1];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = f[e] * sc[c8 * 8 + e] + sh[c8 * 8 + e];
-            const float w = h[e] * sc[c8b * 8 + e] + sh[c8b * 8 + e];
+            const float v = f[e] * (e < 4 ? sa0[e & 3] : sa1[e & 3]) + (e < 4 ? ha0[e & 3] : ha1[e & 3]);
+            const float w = h[e] * (e < 4 ? sb0[e & 3] : sb1[e & 3]) + (e < 4 ? hb0[e & 3] : hb1[e & 3]);
             f[e] = (act == OMGSR_ACT_SILU) ? silu_f(v) : v;
             h[e] = (act == OMGSR_ACT_SILU) ? silu_f(w) : w;
         }
@@ -156,53 +163,145 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, C <= 64*8*MAXCH. y = (x-mu)*rstd*a[c] + b[c].
-template <typename T, int MAXCH>
+OMGSR_DEVINL void load_affine8(const float* __restrict__ v, const int c, const float dflt, float (&o)[8]) {
+    if (v) {
+        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(v + c), hi = *reinterpret_cast<const f32x4_t*>(v + c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = dflt;
+    }
+}
+
+// LayerNorm: a wave owns RPW consecutive rows, C <= 64*8*MAXCH. y = (x-mu)*rstd*a[c] + b[c].
+// All RPW*MAXCH 16-byte loads of a wave are issued before the first reduction (one row per wave kept a single load
+// in flight: 1.05 TB/s on the UNet's [147456, 320] token matrices), the RPW butterfly chains interleave, and the
+// affine vectors are fetched once per wave.
+template <typename T, int MAXCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          const float* __restrict__ a, const float* __restrict__ b,
                                                          int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     const int nch8 = C >> 3;
-    const T* xr = x + row * C;
-    float f[MAXCH][8];
-    float s = 0.0f;
+    float f[RPW][MAXCH][8];
+    float s[RPW];
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        const int c8 = lane + 64 * i;
-        if (c8 < nch8) {
-            unpack8<T>(*reinterpret_cast<const u32x4_t*>(xr + c8 * 8), f[i]);
+    for (int r = 0; r < RPW; ++r) {
+        s[r] = 0.0f;
+        const bool live = row0 + r < rows;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += f[i][e];
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c8 = lane + 64 * i;
+            u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+            if (live && c8 < nch8) v = *reinterpret_cast<const u32x4_t*>(x + (row0 + r) * C + c8 * 8);
+            unpack8<T>(v, f[r][i]);
         }
     }
-    const float mu = wave_sum(s) / (float)C;
+    constexpr bool PRE = MAXCH <= 3;          // wide rows: the affine vectors would cost 16*MAXCH registers, fetch them at use
+    float av[PRE ? MAXCH : 1][8], bv[PRE ? MAXCH : 1][8];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c8 = lane + 64 * i;
+            load_affine8(c8 < nch8 ? a : nullptr, c8 * 8, 1.0f, av[i]);
+            load_affine8(c8 < nch8 ? b : nullptr, c8 * 8, 0.0f, bv[i]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[r] += f[r][i][e];         // lanes past the row hold zeros
+    float mu[RPW], q[RPW];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) s[r] += __shfl_xor(s[r], o);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        mu[r] = s[r] / (float)C;
+        q[r] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            if (lane + 64 * i < nch8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[r][i][e] - mu[r]; q[r] += d * d; }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) q[r] += __shfl_xor(q[r], o);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        if (row0 + r >= rows) break;
+        const float rs = rsqrtf(q[r] / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c8 = lane + 64 * i;
+            if (c8 < nch8) {
+                float o8[8], ga[8], be[8];
+                if constexpr (!PRE) { load_affine8(a, c8 * 8, 1.0f, ga); load_affine8(b, c8 * 8, 0.0f, be); }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    o8[e] = (f[r][i][e] - mu[r]) * rs * (PRE ? av[PRE ? i : 0][e] : ga[e]) + (PRE ? bv[PRE ? i : 0][e] : be[e]);
+                *reinterpret_cast<u32x4_t*>(y + (row0 + r) * C + c8 * 8) = pack8<T>(o8);
+            }
+        }
+    }
+}
+
+// Wide rows (C >= 1024: UNet level 2, every Flux LayerNorm): one 256-thread block per row, <= MAXV 16-byte chunks per
+// thread all in flight at once, block reductions through LDS.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_block_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                               const float* __restrict__ a, const float* __restrict__ b,
+                                                               int C, float eps) {
+    __shared__ float red[2][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t row = blockIdx.x;
+    const int nch8 = C >> 3;
+    float f[MAXV][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c8 = t + 256 * i;
+        u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+        if (c8 < nch8) v = *reinterpret_cast<const u32x4_t*>(x + row * C + c8 * 8);
+        unpack8<T>(v, f[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[i][e];
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    const float mu = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)C;
     float q = 0.0f;
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        const int c8 = lane + 64 * i;
-        if (c8 < nch8) {
+    for (int i = 0; i < MAXV; ++i) {
+        if (t + 256 * i < nch8) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mu; q += d * d; }
         }
     }
-    const float r = rsqrtf(wave_sum(q) / (float)C + eps);
-    T* yr = y + row * C;
+    q = wave_sum(q);
+    if (lane == 0) red[1][wave] = q;
+    __syncthreads();
+    const float rs = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)C + eps);
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        const int c8 = lane + 64 * i;
+    for (int i = 0; i < MAXV; ++i) {
+        const int c8 = t + 256 * i;
         if (c8 < nch8) {
-            float o[8];
+            float o8[8], ga[8], be[8];
+            load_affine8(a, c8 * 8, 1.0f, ga); load_affine8(b, c8 * 8, 0.0f, be);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = c8 * 8 + e;
-                float v = (f[i][e] - mu) * r;
-                if (a) v *= a[c];
-                if (b) v += b[c];
-                o[e] = v;
-            }
-            *reinterpret_cast<u32x4_t*>(yr + c8 * 8) = pack8<T>(o);
+            for (int e = 0; e < 8; ++e) o8[e] = (f[i][e] - mu) * rs * ga[e] + be[e];
+            *reinterpret_cast<u32x4_t*>(y + row * C + c8 * 8) = pack8<T>(o8);
         }
     }
 }
@@ -421,13 +520,14 @@ extern "C" int omgsr_layernorm(const void* x, void* y, const float* a, const flo
     if (!x || !y || rows <= 0 || C <= 0) return OMGSR_E_BADARG;
     if ((C & 7) || C > 64 * 8 * 8) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((rows + 3) / 4));
     omgsr::TimingScope ts(OMGSR_TK_LN, 0.0, 4.0 * (double)rows * C, st);
     const int nch = ((C >> 3) + 63) / 64;
-    if (nch <= 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
-    else if (nch <= 3) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
-    else if (nch <= 6) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 6>), grid, dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
-    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 8>), grid, dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
+    auto grid = [&](int rpw) { return dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))); };
+    if (nch <= 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 1, 4>), grid(4), dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
+    else if (nch <= 2) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 2, 4>), grid(4), dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
+    else if (nch <= 3) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 3, 2>), grid(2), dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
+    else if (rows >= (1ll << 31)) return OMGSR_E_SHAPE;
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_block_kernel<T, 2>), dim3((unsigned)rows), dim3(256), 0, st, (const T*)x, (T*)y, a, b, C, eps));
     return (int)hipGetLastError();
 }
 

@@ -18,3 +18,15 @@ for name, N, H, W, C in [("vae 128ch 512^2 b8", 8, 512, 512, 128), ("vae 256ch 2
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / 10
         print(f"{name:26s} {label:6s} {dt*1e3:7.3f} ms  {x.numel()*2*mult/dt/1e12:6.2f} TB/s", flush=True)
+
+print("LayerNorm")
+for name, rows, C in [("unet L0 [147456, 320]", 147456, 320), ("unet L1 [36864, 640]", 36864, 640), ("unet L2 [9216, 1280]", 9216, 1280),
+                      ("flux [4608, 3072]", 4608, 3072)]:
+    x = torch.randn(1, rows, C, device=dev).to(torch.bfloat16)
+    a = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
+    ops.layer_norm(x, a, b, 1e-5); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(20): ops.layer_norm(x, a, b, 1e-5)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 20
+    print(f"{name:26s} {dt*1e6:8.1f} us  {x.numel()*4/dt/1e12:6.2f} TB/s", flush=True)
