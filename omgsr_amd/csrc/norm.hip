@@ -426,19 +426,24 @@ extern "C" int omgsr_groupnorm_finalize(const float* partial, float* mean, float
 namespace {
 // pass 2 for the tiled VAE: per-tile (mean, var) of every shape group, folded per image with pixel-count weights
 // (infer/vaehook.py GroupNormParam.summary: mean = sum_t w_t mean_t, var = sum_t w_t var_t). One wave per (n, g).
-__global__ void gn_finalize_merged_kernel(const omgsr_gn_merge_args a, float* __restrict__ mean, float* __restrict__ rstd,
-                                          float* __restrict__ var_out, int N, int G, float eps) {
-    const int i = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void gn_finalize_merged_kernel(const omgsr_gn_merge_args a, float* __restrict__ mean, float* __restrict__ rstd,
+                                                                  float* __restrict__ var_out, int N, int G, float eps) {
+    // one 256-thread block per (n, g); the (group, tile) pairs go round-robin to the four waves, each wave folds its
+    // tile's slots with 64 lanes; the four weighted partial results are combined in wave order (deterministic)
+    __shared__ double red[4][2];
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = i / G, g = i - n * G;
     double m_acc = 0.0, v_acc = 0.0;
+    int pair = 0;
     for (int k = 0; k < a.ngroups; ++k) {
         const float* partial = a.partial[k];
         const int nslot = a.nslot[k];
-        for (int t = 0; t < a.tiles[k]; ++t) {
+        for (int t = 0; t < a.tiles[k]; ++t, ++pair) {
+            if ((pair & 3) != wave) continue;
             const int row = t * N + n;
             double s = 0.0, q = 0.0;
             for (int c = lane; c < nslot; c += 64) {
-                const float* p = partial + (((int64_t)row * nslot + c) * G + g) * 2;
+                const f32x2_t p = *reinterpret_cast<const f32x2_t*>(partial + (((int64_t)row * nslot + c) * G + g) * 2);
                 s += (double)p[0]; q += (double)p[1];
             }
 #pragma unroll
@@ -450,10 +455,14 @@ __global__ void gn_finalize_merged_kernel(const omgsr_gn_merge_args a, float* __
             v_acc += (double)a.weight[k] * v;
         }
     }
-    if (lane != 0) return;
-    mean[i] = (float)m_acc;
-    rstd[i] = (float)(1.0 / sqrt(v_acc + (double)eps));
-    if (var_out) var_out[i] = (float)v_acc;
+    if (lane == 0) { red[wave][0] = m_acc; red[wave][1] = v_acc; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double mm = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+    const double vv = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    mean[i] = (float)mm;
+    rstd[i] = (float)(1.0 / sqrt(vv + (double)eps));
+    if (var_out) var_out[i] = (float)vv;
 }
 
 }  // namespace
@@ -480,7 +489,7 @@ extern "C" int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, flo
     if (!a || !mean || !rstd || N <= 0 || G <= 0 || a->ngroups <= 0 || a->ngroups > OMGSR_GN_MAX_GROUPS) return OMGSR_E_BADARG;
     for (int k = 0; k < a->ngroups; ++k)
         if (!a->partial[k] || a->tiles[k] <= 0 || a->nslot[k] <= 0 || a->count[k] <= 0.0) return OMGSR_E_BADARG;
-    hipLaunchKernelGGL(gn_finalize_merged_kernel, dim3(N * G), dim3(64), 0, (hipStream_t)stream, *a, mean, rstd, var_out, N, G, eps);
+    hipLaunchKernelGGL(gn_finalize_merged_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, *a, mean, rstd, var_out, N, G, eps);
     return (int)hipGetLastError();
 }
 
