@@ -93,14 +93,6 @@ typedef struct omgsr_igemm_args {
                               squares per slot), to be folded by omgsr_groupnorm_finalize | NULL. Only when
                               omgsr_igemm_gn_slots() > 0 for these arguments. */
     int32_t gn_groups;
-    /* optional fused GroupNorm-apply (+SiLU) on the INPUT: the kernel reads the raw tensor `in` and convolves
-       act(in * in_scale[n % in_affine_rows, c] + in_shift[...]) (rounded to the 16-bit type, zero padding applied AFTER the
-       normalisation, exactly as omgsr_groupnorm_apply followed by the plain conv). f32 [in_affine_rows][Cin] each, from
-       omgsr_groupnorm_affine. Only when omgsr_igemm_in_norm_ok() != 0 for these arguments. */
-    const float* in_scale;
-    const float* in_shift;
-    int32_t in_affine_rows;
-    int32_t in_act;          /* OMGSR_ACT_NONE | OMGSR_ACT_SILU */
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
 /* Bytes of `workspace` that would let omgsr_igemm split the contraction of a small-M / large-K problem over
@@ -110,9 +102,6 @@ int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* a);
  * arguments (with gn_groups set; 3x3 halo-tile path, NHWC 16-byte rows, Cout/gn_groups in {4, 8, 16, 32, 64}),
  * else 0: the caller then runs omgsr_groupnorm_stats on the output instead. */
 int32_t omgsr_igemm_gn_slots(const omgsr_igemm_args* a);
-/* 1 if omgsr_igemm can take in_scale / in_shift for these arguments (3x3 halo-tile path, Cin <= 1280), else 0: the caller
- * then runs omgsr_groupnorm_apply first. */
-int32_t omgsr_igemm_in_norm_ok(const omgsr_igemm_args* a);
 
 /*
  * K4 — GroupNorm statistics and apply (replaces F.group_norm; the externally supplied
@@ -147,10 +136,6 @@ typedef struct omgsr_gn_merge_args {
 } omgsr_gn_merge_args;
 int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, float* mean, float* rstd, float* var_out,
                                     int32_t N, int32_t G, float eps, void* stream);
-/* The affine form of a GroupNorm for omgsr_igemm's fused input norm: scale[r,c] = rstd[r,g(c)] * gamma[c],
- * shift[r,c] = beta[c] - mean[r,g(c)] * scale[r,c]; f32 [rows][C]. */
-int omgsr_groupnorm_affine(const float* mean, const float* rstd, const float* gamma, const float* beta,
-                           float* scale, float* shift, int32_t rows, int32_t C, int32_t G, void* stream);
 /* y = act((x - mean[n,g]) * rstd[n,g] * gamma[c] + beta[c]);  act in {NONE, SILU}. x and y may alias. */
 int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int32_t N, int64_t HW, int32_t C,

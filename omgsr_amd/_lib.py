@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 10
+ABI_VERSION = 9
 
 
 class OmgsrError(RuntimeError):
@@ -36,7 +36,6 @@ class IgemmArgs(C.Structure):
         ("in_bstride", C.c_int64), ("w_bstride", C.c_int64), ("out_bstride", C.c_int64),
         ("alpha", C.c_float), ("weight_cm", C.c_void_p), ("workspace", C.c_void_p),
         ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
-        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_affine_rows", C.c_int32), ("in_act", C.c_int32),
     ]
 
 
@@ -76,8 +75,6 @@ SIGNATURES = {
     "omgsr_igemm": (C.c_int, [C.POINTER(IgemmArgs), _P]),
     "omgsr_igemm_workspace_bytes": (C.c_int64, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_slots": (C.c_int32, [C.POINTER(IgemmArgs)]),
-    "omgsr_igemm_in_norm_ok": (C.c_int32, [C.POINTER(IgemmArgs)]),
-    "omgsr_groupnorm_affine": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "omgsr_groupnorm_finalize": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, C.c_double, _F, _P]),
     "omgsr_groupnorm_partial": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
     "omgsr_groupnorm_finalize_merged": (C.c_int, [C.POINTER(GnMergeArgs), _P, _P, _P, _I, _I, _F, _P]),

@@ -270,12 +270,6 @@ extern "C" int32_t omgsr_igemm_gn_slots(const omgsr_igemm_args* ap) {
     return omgsr::igemm_halo_gn_slots(*ap);
 }
 
-extern "C" int32_t omgsr_igemm_in_norm_ok(const omgsr_igemm_args* ap) {
-    if (!ap || ap->Cin > 1280 || !use_halo(*ap)) return 0;
-    const int64_t M64 = (int64_t)ap->N * ap->Ho * ap->Wo;
-    return (ap->workspace && splitk_plan(*ap, M64) > 1) ? 0 : 1;
-}
-
 extern "C" int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* ap) {
     if (!ap) return 0;
     const int64_t M64 = (int64_t)ap->N * ap->Ho * ap->Wo;
@@ -331,9 +325,8 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         }
     }
     // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
-    if (a.in_scale && (!a.in_shift || a.in_affine_rows <= 0 || a.Cin > 1280)) return OMGSR_E_BADARG;
     if (use_halo(a)) return omgsr::igemm_halo_launch(a, g, st);
-    if (a.gn_partial || a.in_scale) return OMGSR_E_BADARG;      // fused GroupNorm statistics / input norm exist on the halo path only
+    if (a.gn_partial) return OMGSR_E_BADARG;      // fused GroupNorm statistics exist on the halo path only (omgsr_igemm_gn_slots)
     const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0;   // the DMA kernel's K-steps never straddle taps
     if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192)))
         return omgsr::igemm_dma_launch(a, g, st);

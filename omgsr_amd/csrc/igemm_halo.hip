@@ -116,38 +116,6 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
         }
     };
 
-    // Fused GroupNorm apply (+SiLU) on the INPUT (p.in_scale != NULL): the conv reads the raw tensor and every lane
-    // normalises, in place in LDS, exactly the 16 bytes it DMA'd (8 channels of one patch pixel) before any wave
-    // reads fragments from that patch: y = act(x * scale[n, c] + shift[n, c]), rounded to the 16-bit type like the
-    // stand-alone gn_apply kernel's output. Pixels outside the image stay exact zeros (conv padding pads the
-    // NORMALISED tensor). The per-image (scale, shift) rows live in LDS behind the weight ring.
-    const bool in_norm = p.in_scale != nullptr;
-    float* aff = reinterpret_cast<float*>(lds + LDS_BYTES);             // [Cin] scale, [Cin] shift
-    if (in_norm) {
-        const int row = img % p.in_affine_rows;
-        for (int c = t; c < p.Cin; c += 256) {
-            aff[c] = p.in_scale[(int64_t)row * p.Cin + c];
-            aff[p.Cin + c] = p.in_shift[(int64_t)row * p.Cin + c];
-        }
-        __syncthreads();
-    }
-    auto norm_piece = [&](const int buf, auto i_c, const int chunk) {
-        constexpr int i = decltype(i_c)::value;
-        if (a_inc[i] == 0) return;                                       // outside the image / dummy piece: stays zero
-        unsigned char* px = lds + buf * A_BYTES + (wave * APW + i) * 1024 + lane * 16;
-        const float* sc = aff + chunk * 32 + kc * 8;
-        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(sc), s1 = *reinterpret_cast<const f32x4_t*>(sc + 4);
-        const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(sc + p.Cin), h1 = *reinterpret_cast<const f32x4_t*>(sc + p.Cin + 4);
-        float f[8];
-        unpack8<T>(*reinterpret_cast<const u32x4_t*>(px), f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float y = f[e] * (e < 4 ? s0[e & 3] : s1[e & 3]) + (e < 4 ? h0[e & 3] : h1[e & 3]);
-            f[e] = (p.in_act == OMGSR_ACT_SILU) ? silu_f(y) : y;
-        }
-        *reinterpret_cast<u32x4_t*>(px) = pack8<T>(f);
-    };
-
     f32x16_t acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -183,16 +151,6 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
         issue_a(0);
         issue_b(0);
         issue_b(1);
-    }
-    if (in_norm) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  // this wave's 6 patch pieces landed (the 2+2 weight pieces may fly)
-        norm_piece(0, std::integral_constant<int, 0>{}, 0);
-        norm_piece(0, std::integral_constant<int, 1>{}, 0);
-        norm_piece(0, std::integral_constant<int, 2>{}, 0);
-        norm_piece(0, std::integral_constant<int, 3>{}, 0);
-        norm_piece(0, std::integral_constant<int, 4>{}, 0);
-        norm_piece(0, std::integral_constant<int, 5>{}, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // written back before step 0's barrier publishes the patch
     }
 
     // one K-step with compile-time tap and patch parity
@@ -238,12 +196,6 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);   // transposed tile
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        // next chunk's patch: this wave's pieces landed at tap 2's wait; normalise one per step behind the MFMAs
-        // (LDS operations of a wave complete in order, so the write is back before the fragment reads of the next
-        // step retire, two barriers ahead of the patch's first reader)
-        if constexpr (tap >= 2 && tap <= 7) {
-            if (in_norm && cc + 1 < ncc) norm_piece(par ^ 1, std::integral_constant<int, tap - 2>{}, cc + 1);
-        }
     };
     auto chunk = [&](auto par_c, const int cc) {
         const int s0 = cc * 9;
@@ -307,19 +259,17 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
                              reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, true>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 1, false>)};
         for (const void* f : fns)
-            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(g.ntm * g.ntn, 1, 1);
     static const char* abl = getenv("OMGSR_HALO_ABLATE");      // timing experiments only
-    const size_t lds_bytes = LDS_BYTES + (a.in_scale ? (size_t)8 * a.Cin : 0);      // + the (scale, shift) rows of a fused input norm
-    if (lds_bytes > 81920) return OMGSR_E_SHAPE;
-    if (abl && abl[0] == '1') OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 1, false>), grid, dim3(256), lds_bytes, st, a, g));
-    else if (abl && abl[0] == '2') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 2, false>), grid, dim3(256), lds_bytes, st, a, g);
-    else if (abl && abl[0] == '3') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 3, false>), grid, dim3(256), lds_bytes, st, a, g);
-    else if (a.Cin >= 384) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, true>), grid, dim3(256), lds_bytes, st, a, g));
-    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false>), grid, dim3(256), lds_bytes, st, a, g));
+    if (abl && abl[0] == '1') OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 1, false>), grid, dim3(256), LDS_BYTES, st, a, g));
+    else if (abl && abl[0] == '2') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 2, false>), grid, dim3(256), LDS_BYTES, st, a, g);
+    else if (abl && abl[0] == '3') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 3, false>), grid, dim3(256), LDS_BYTES, st, a, g);
+    else if (a.Cin >= 384) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, true>), grid, dim3(256), LDS_BYTES, st, a, g));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false>), grid, dim3(256), LDS_BYTES, st, a, g));
     return (int)hipGetLastError();
 }
 int igemm_halo_gn_slots(const omgsr_igemm_args& a) {

@@ -471,26 +471,6 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
                     const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, void* stream);
 }
 
-namespace {
-__global__ void gn_affine_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift, int rows, int C, int G) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * C) return;
-    const int r = i / C, c = i - r * C, g = c / (C / G);
-    const float sc = rstd[r * G + g] * (gamma ? gamma[c] : 1.0f);
-    scale[i] = sc;
-    shift[i] = (beta ? beta[c] : 0.0f) - mean[r * G + g] * sc;          // same expression as gn_apply's LDS table
-}
-}  // namespace
-
-extern "C" int omgsr_groupnorm_affine(const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                      float* scale, float* shift, int32_t rows, int32_t C, int32_t G, void* stream) {
-    if (!mean || !rstd || !scale || !shift || rows <= 0 || C <= 0 || G <= 0 || (C % G)) return OMGSR_E_BADARG;
-    hipLaunchKernelGGL(gn_affine_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, rstd, gamma, beta,
-                       scale, shift, rows, C, G);
-    return (int)hipGetLastError();
-}
-
 extern "C" int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N, int64_t HW, int32_t C, int32_t G, void* stream) {
     if (!x || !partial || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
     if ((C & 7) || (C % G) || G > 256 || C > 8192) return OMGSR_E_SHAPE;

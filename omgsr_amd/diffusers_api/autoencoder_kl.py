@@ -45,13 +45,11 @@ class ResnetBlock2D(nn.Module):
 
     def nhwc(self, x, conv1_bias=None):
         """conv1_bias: conv1.bias + time_emb_proj(silu(temb)) folded by the UNet (constant at fixed t*)."""
-        # GroupNorm statistics come from the producing conv's epilogue where it left them; GroupNorm apply + SiLU ride
-        # the consuming conv's input path: no normalised tensor is written to HBM
-        m1, r1, _ = self.norm1.stats(x)
-        h = self.conv1.nhwc_normed(x, self.norm1, m1, r1, ops.ACT_SILU, bias_override=conv1_bias, gn_groups=self.norm2.num_groups)
-        m2, r2, _ = self.norm2.stats(h)
+        h = self.norm1.nhwc(x, ops.ACT_SILU)
+        h = self.conv1.nhwc(h, bias_override=conv1_bias, gn_groups=self.norm2.num_groups)     # norm2's statistics ride the epilogue
+        h = self.norm2.nhwc(h, ops.ACT_SILU)
         sc = self.conv_shortcut.nhwc(x, pad=0) if self.conv_shortcut is not None else x
-        return self.conv2.nhwc_normed(h, self.norm2, m2, r2, ops.ACT_SILU, residual=sc, gn_groups=self.norm1.num_groups)
+        return self.conv2.nhwc(h, residual=sc, gn_groups=self.norm1.num_groups)             # ... and the next block's norm1
 
 
 class Downsample2D(nn.Module):

@@ -38,25 +38,14 @@ class Conv2d(nn.Conv2d, _Packed):
         # logical Cout widened to a multiple of 8 (zero rows): 3/4-channel heads write 16-byte NHWC rows
         return self._packed(lambda: ops.pack_conv_weight(self.weight, self.bias, cout_multiple=8), self.weight, self.bias)
 
-    def nhwc(self, x, *, pad=None, upsample=False, act=ops.ACT_NONE, residual=None, bias_override=None, stride=None, gn_groups=0,
-             in_norm=None):
+    def nhwc(self, x, *, pad=None, upsample=False, act=ops.ACT_NONE, residual=None, bias_override=None, stride=None, gn_groups=0):
         """x [N,H,W,Cin8] -> [N,Ho,Wo,Cout8]; channels beyond out_channels are exact zeros."""
         pw = self.packed()
         if bias_override is not None:
             pw = ops.PackedWeight(pw.w, bias_override, pw.cout, pw.cin, pw.R, pw.S, w_cm=pw.w_cm)
         p = self.padding[0] if pad is None else pad
         return ops.conv2d(x, pw, stride=stride or self.stride[0], pad=p, upsample=upsample, act=act, residual=residual,
-                          gn_groups=gn_groups, in_norm=in_norm)
-
-    def nhwc_normed(self, x, norm, mean, rstd, act, **kw):
-        """conv(act(GroupNorm(x))) with externally supplied statistics [R,G] (R divides the rows of x): the normalisation
-        rides the conv's input path when the kernel can (omgsr_igemm in_scale / in_shift), else one apply pass first."""
-        if ops.conv_in_norm_ok(x, self.packed(), stride=kw.get("stride") or self.stride[0],
-                               pad=self.padding[0] if kw.get("pad") is None else kw["pad"], upsample=kw.get("upsample", False)):
-            g, b = norm._affine()
-            sc, sh = ops.group_norm_affine(mean, rstd, g, b, x.shape[-1])
-            return self.nhwc(x, in_norm=(sc, sh, act), **kw)
-        return self.nhwc(norm.apply_stats(x, mean, rstd, act), **kw)
+                          gn_groups=gn_groups)
 
     def forward(self, x):  # NCHW compat
         y = self.nhwc(ops.nchw_to_nhwc(x.contiguous(), ops._round_up(self.in_channels, 8)))

@@ -159,13 +159,10 @@ def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device
 def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, int, int] | int = 1,
            upsample: bool = False, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
            gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_BF16, alpha: float = 1.0,
-           out: Optional[torch.Tensor] = None, gn_groups: int = 0, in_norm=None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, gn_groups: int = 0) -> torch.Tensor:
     """x [N,H,W,Cin] bf16 -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on the (virtual) input.
     gn_groups > 0: the caller will GroupNorm the result with that many groups; when the kernel can, it emits the
-    (sum, sum of squares) partials from its epilogue and group_norm_stats() skips its read pass over the tensor.
-    in_norm = (scale [R,Cin], shift [R,Cin], act): x is the RAW input of a GroupNorm whose affine form is (scale, shift)
-    (group_norm_affine); the kernel normalises (+SiLU) its input patches in LDS, no normalised tensor in HBM. When the
-    kernel cannot (conv_in_norm_ok false) the caller must apply the norm itself; passing in_norm then raises."""
+    (sum, sum of squares) partials from its epilogue and group_norm_stats() skips its read pass over the tensor."""
     _req(x, act_dtype(), "x")
     N, H, W, Cin = x.shape
     if Cin != pw.cin:
@@ -197,12 +194,6 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     a.t_rows, a.t_ld = 0, 0
     a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
     a.alpha = alpha
-    if in_norm is not None:
-        sc, sh, nact = in_norm
-        _req(sc, torch.float32, "in_norm scale"); _req(sh, torch.float32, "in_norm shift")
-        if sc.shape != sh.shape or sc.shape[-1] != Cin or N % sc.shape[0]:
-            raise ValueError(f"in_norm tables {tuple(sc.shape)} do not fit an input of {N} rows x {Cin} channels")
-        a.in_scale, a.in_shift, a.in_affine_rows, a.in_act = sc.data_ptr(), sh.data_ptr(), sc.shape[0], nact
     partial = None
     if gn_groups > 0:
         a.gn_groups = gn_groups
@@ -351,33 +342,6 @@ def group_norm_stats(x: torch.Tensor, groups: int, eps: float):
     check(lib.omgsr_groupnorm_stats(x.data_ptr(), partial.data_ptr(), mean.data_ptr(), rstd.data_ptr(), var.data_ptr(),
                                     N, HW, Cc, groups, eps, _stream()), "omgsr_groupnorm_stats")
     return mean, rstd, var
-
-
-def group_norm_affine(mean: torch.Tensor, rstd: torch.Tensor, gamma, beta, channels: int):
-    """(mean, rstd) [R,G] + affine -> per-channel (scale, shift) f32 [R,C]: GroupNorm as y = x*scale + shift."""
-    R, G = mean.shape
-    scale = torch.empty((R, channels), device=mean.device, dtype=torch.float32)
-    shift = torch.empty_like(scale)
-    check(_lib.load().omgsr_groupnorm_affine(mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), _ptr(beta), scale.data_ptr(),
-                                             shift.data_ptr(), R, channels, G, _stream()), "omgsr_groupnorm_affine")
-    return scale, shift
-
-
-def conv_in_norm_ok(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=0, upsample: bool = False) -> bool:
-    """Whether conv2d(x, pw, ..., in_norm=...) can fuse the input GroupNorm for this problem (omgsr_igemm_in_norm_ok)."""
-    N, H, W, Cin = x.shape
-    if isinstance(pad, int):
-        pad = (pad, pad, pad, pad)
-    pt, pb, pl, pr = pad
-    Hv, Wv = (H * 2, W * 2) if upsample else (H, W)
-    a = IgemmArgs()
-    a.weight_cm = _ptr(pw.w_cm)
-    a.N, a.H, a.W, a.Cin = N, H, W, Cin
-    a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
-    a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = pw.R, pw.S, stride, pt, pl, int(upsample)
-    a.Ho, a.Wo = (Hv + pt + pb - pw.R) // stride + 1, (Wv + pl + pr - pw.S) // stride + 1
-    a.act, a.out_layout, a.batch = (ACT_GEGLU if pw.geglu else ACT_NONE), LAYOUT_NHWC, 1
-    return bool(_lib.load().omgsr_igemm_in_norm_ok(C.byref(a)))
 
 
 def group_norm_partial(x: torch.Tensor, groups: int) -> torch.Tensor:

@@ -70,10 +70,10 @@ class VAEHook:
 
         def resblock(b):
             seq.append(("res_push", (lambda x, b=b: b.conv_shortcut.nhwc(x, pad=0)) if b.conv_shortcut is not None else None))
-            # GroupNorm -> conv pairs: merged statistics, then the conv normalises its own input patches (no apply pass);
-            # (norm, act, conv, takes the pushed residual, groups of the GroupNorm that consumes the conv's output)
-            seq.append(("gn_conv", b.norm1, ops.ACT_SILU, b.conv1, False, b.norm2.num_groups))
-            seq.append(("gn_conv", b.norm2, ops.ACT_SILU, b.conv2, True, b.norm1.num_groups))
+            seq.append(("gn", b.norm1, ops.ACT_SILU))
+            seq.append(("f", lambda x, b=b: b.conv1.nhwc(x, gn_groups=b.norm2.num_groups)))
+            seq.append(("gn", b.norm2, ops.ACT_SILU))
+            seq.append(("conv_res", b.conv2, b.norm1.num_groups))  # conv2 + residual in the GEMM epilogue (+ next GN statistics)
 
         def attn(a):
             seq.append(("res_push", None))
@@ -114,7 +114,7 @@ class VAEHook:
         gi = 0
         for op in seq:
             kind = op[0]
-            if kind in ("gn", "gn_conv"):
+            if kind == "gn":
                 norm, act = op[1], op[2]
                 G = norm.num_groups
                 if fixed is not None:
@@ -129,11 +129,7 @@ class VAEHook:
                     record.append((mean, var))
                 gi += 1
                 for k in groups:
-                    if kind == "gn":
-                        groups[k] = norm.apply_stats(groups[k], mean, rstd, act)   # rows (tile, image) share the image's statistics
-                    else:
-                        groups[k] = op[3].nhwc_normed(groups[k], norm, mean, rstd, act, residual=res[k].pop() if op[4] else None,
-                                                      gn_groups=op[5])
+                    groups[k] = norm.apply_stats(groups[k], mean, rstd, act)   # rows (tile, image) share the image's statistics
             elif kind == "f":
                 for k in groups:
                     groups[k] = op[1](groups[k])

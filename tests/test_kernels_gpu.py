@@ -464,35 +464,3 @@ def test_groupnorm_merged_tile_statistics():
         r = torch.rsqrt(var_ref + 1e-6).repeat(tiles[k], 1)[:, :, None, None].repeat_interleave(C // G, 1)
         ref = F.silu((t - m) * r * gamma[None, :, None, None] + beta[None, :, None, None])
         assert_close(to_nchw(y), ref, f"shared-stat apply group {k}")
-
-
-@pytest.mark.parametrize("N,C,Cout,H,W,silu", [(2, 128, 128, 128, 192, True), (4, 256, 128, 86, 150, True), (4, 512, 256, 64, 96, False),
-                                                (4, 320, 320, 64, 64, True)])        # >= 192 halo tiles each
-def test_conv_fused_input_groupnorm(N, C, Cout, H, W, silu):
-    """omgsr_igemm in_scale / in_shift: conv(act(GroupNorm(x))) with the normalisation done on the input patches in LDS
-    must equal the two-kernel sequence (gn_apply -> conv) BIT FOR BIT, zero padding included, and match torch."""
-    ops = _ops()
-    x = rnd(N, C, H, W, seed=120) * 1.7 + 0.3
-    x = x.to(torch.bfloat16).float()
-    w = rnd(Cout, C, 3, 3, seed=121, scale=(9 * C) ** -0.5)
-    b = rnd(Cout, seed=122)
-    gamma, beta = rnd(C, seed=123) + 1.0, rnd(C, seed=124)
-    xd = nhwc(x)
-    pw = ops.pack_conv_weight(w, b, device=DEV)
-    assert ops.conv_in_norm_ok(xd, pw, pad=1)
-    act = ops.ACT_SILU if silu else ops.ACT_NONE
-    mean, rstd, _ = ops.group_norm_stats(xd, 32, 1e-6)
-    two = ops.conv2d(ops.group_norm_apply(xd, mean, rstd, gamma.to(DEV), beta.to(DEV), 32, act), pw, pad=1)
-    sc, sh = ops.group_norm_affine(mean, rstd, gamma.to(DEV), beta.to(DEV), C)
-    one = ops.conv2d(xd, pw, pad=1, in_norm=(sc, sh, act))
-    assert torch.equal(one, two), f"fused != unfused: {(one.float() - two.float()).abs().max().item()}"
-    h = F.group_norm(x, 32, gamma, beta, eps=1e-6)
-    ref = F.conv2d(F.silu(h) if silu else h, w, b, padding=1)
-    assert_close(to_nchw(one), ref, "fused-norm conv", rel_l2=8e-3, max_ulps=8.0)
-    # tile-major rows sharing one image's statistics (tiled VAE): rows r use table row r % R
-    if N % 2 == 0:
-        m2, r2 = mean[: N // 2].contiguous(), rstd[: N // 2].contiguous()
-        sc2, sh2 = ops.group_norm_affine(m2, r2, gamma.to(DEV), beta.to(DEV), C)
-        a2 = ops.conv2d(ops.group_norm_apply_shared(xd, m2, r2, gamma.to(DEV), beta.to(DEV), 32, act), pw, pad=1)
-        b2 = ops.conv2d(xd, pw, pad=1, in_norm=(sc2, sh2, act))
-        assert torch.equal(a2, b2)
