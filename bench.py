@@ -215,7 +215,11 @@ def main():
 
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and family == "S":
-        cpu_baseline, parity = cpu_leg(lq_cpu[:1], eps_cpu[:1], prompt.float().cpu(), out[:1], tile, overlap, side, tiled_vae)
+        cpu_baseline, parity, oracle_img = cpu_leg(lq_cpu[:1], eps_cpu[:1], prompt.float().cpu(), out[:1], tile, overlap, side, tiled_vae)
+        if WDTYPE == torch.bfloat16:
+            # the same workload in the reference's other 16-bit --weight_dtype: same kernels (templates on the element type),
+            # 8x finer mantissa; a short timed leg + parity of image 0 against the same oracle output
+            extra["fp16_mode"] = fp16_leg(device, rank, world, tiled_vae, lq_cpu, eps_cpu, prompt, tile, overlap, oracle_img, B)
 
     if rank == 0:
         line = {
@@ -259,7 +263,37 @@ def cpu_leg(lq1, eps1, prompt, hip_out_nhwc, tile, overlap, side, tiled_vae=Fals
               "psnr_db": round(psnr(got, img), 2)}
     base = {"value": round(1.0 / secs, 5), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"1 image {side // 4}->{side}, fp32 eager PyTorch oracle, {secs:.1f} s, torch threads={torch.get_num_threads()}"}
-    return base, parity
+    return base, parity, img
+
+
+def fp16_leg(device, rank, world, tiled_vae, lq_cpu, eps_cpu, prompt, tile, overlap, oracle_img, B):
+    global WDTYPE
+    from omgsr_amd import ops
+    from omgsr_amd.testing import psnr, rel_l2
+    keep = WDTYPE
+    try:
+        WDTYPE = torch.float16
+        ops.set_compute_dtype(torch.float16)
+        pipe, _ = build_s(device, rank, world)
+        if tiled_vae:
+            pipe._init_tiled_vae(encoder_tile_size=256, decoder_tile_size=64)
+        pipe.vae.posterior_noise = eps_cpu.to(device)
+        lq = ops_nhwc(lq_cpu.to(device))
+        pr = prompt.to(torch.float16)
+        with torch.no_grad():
+            out = pipe.sr_nhwc(lq, pr, tile, overlap)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(2):
+                out = pipe.sr_nhwc(lq, pr, tile, overlap)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / 2
+        got = ops.nhwc_to_nchw(out[:1].contiguous(), channels=3, dtype=torch.float32, clamp=(-1.0, 1.0)).cpu()
+        return {"images_per_s": round(B / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": 2,
+                "rel_l2": round(rel_l2(got, oracle_img), 5), "psnr_db": round(psnr(got, oracle_img), 2)}
+    finally:
+        WDTYPE = keep
+        ops.set_compute_dtype(keep)
 
 
 if __name__ == "__main__":
