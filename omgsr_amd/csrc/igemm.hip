@@ -253,7 +253,12 @@ bool use_halo(const omgsr_igemm_args& a) {
                          (a.Cin % 32) == 0 && a.batch == 1 && a.Ho == (a.H << a.upsample) && a.Wo == (a.W << a.upsample) && a.Wo >= 16 &&
                          logical_cols >= 96 && a.out_layout == OMGSR_LAYOUT_NHWC;
     if (!halo_ok || (mode && (!strcmp(mode, "reg") || !strcmp(mode, "dma")))) return false;
-    return (mode && !strcmp(mode, "halo")) || omgsr::igemm_halo_tiles(a) >= 192;
+    if (mode && !strcmp(mode, "halo")) return true;
+    // the halo tile is 32 pixels wide: on narrow maps (the UNet's 16 x 16 level) half of every tile would be padding
+    static const char* narrow = getenv("OMGSR_HALO_NARROW");           // A/B runs: "1" = old behaviour
+    const int padded_w = ((a.Wo + 31) / 32) * 32;
+    if (!(narrow && narrow[0] == '1') && padded_w * 3 > a.Wo * 4) return false;      // > 1/3 of the columns wasted
+    return omgsr::igemm_halo_tiles(a) >= 192;
 }
 
 }  // namespace

@@ -30,12 +30,11 @@
 namespace {
 
 constexpr int BK = 32;
-constexpr int BM = 256;
 constexpr int WTN = 64, FN = 2;
-constexpr int A_BYTES = BM * BK * 2;          // 16 KB
 constexpr int NSTAGE = 3;
-// BN = 64 * WGN: 128 (24 KB / stage, 12 KB of operands per MFLOP) or 256 (32 KB / stage, 8 KB per MFLOP)
-constexpr int lds_bytes(int wgn) { return NSTAGE * (A_BYTES + wgn * 64 * BK * 2); }
+// BM = 256 (default) or 192 (tile-count quantisation: M = 9216 rows x 1280 columns is 360 tiles of 256 x 128 on 512
+// workgroup slots, 480 of 192 x 128). BN = 64 * WGN: 128 (24 KB / stage, 12 KB of operands per MFLOP) or 256 (32 KB, 8 KB).
+constexpr int lds_bytes(int bm, int wgn) { return NSTAGE * (bm * BK * 2 + wgn * 64 * BK * 2); }
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
 
@@ -58,18 +57,21 @@ OMGSR_DEVINL void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else static_assert(N == 0, "unsupported count");
 }
 
 // ABL (ablation, A/B runs only): 0 = the kernel; 1 = no DMA; 2 = DMA + ds_reads, no MFMA; 3 = DMA only
-template <typename T, int WGM, int WGN, int ABL = 0>
+template <typename T, int WGM, int WGN, int ABL = 0, int BM = 256>
 __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
+    constexpr int A_BYTES = BM * BK * 2;       // 16 KB at BM 256
     constexpr int NW = WGM * WGN;              // waves
     constexpr int BN = WGN * WTN;
-    constexpr int B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = NSTAGE * STAGE_BYTES;
+    constexpr int B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int WTM = BM / WGM, FM = WTM / 32;
-    constexpr int APW = 16 / NW, BPW = (BN / 16) / NW; // 1-KiB DMA pieces per wave per K-step (A: 16, B: BN/16 in total)
+    constexpr int APW = (BM / 16) / NW, BPW = (BN / 16) / NW; // 1-KiB DMA pieces per wave per K-step (A: BM/16, B: BN/16 in total)
+    static_assert(APW * NW * 16 == BM && (BM / WGM) % 32 == 0, "tile / wave split");
     constexpr int PIECES = APW + BPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // LDS_BYTES, dynamic
 
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
     }
 
     if constexpr (ABL == 4) { if (p.alpha != 12345.0f) return; }      // no epilogue (never true at run time)
-    static_assert(NW * 32 * (WTN + 4) * 4 <= LDS_BYTES, "epilogue staging must fit the ring");
+    static_assert(NW * 32 * (WTN + 4) * 4 <= lds_bytes(BM, WGN), "epilogue staging must fit the allocation");
     float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
     if (g.splits > 1) {
         // raw fp32 partial [split][M][ntn*BN]; bias / activation / residual run in the split-K reduce kernel
@@ -243,21 +245,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
     igemm_epilogue_linear<T, WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
 }
 
-template <int WGM, int WGN, int ABL = 0>
+template <int WGM, int WGN, int ABL = 0, int BM = 256>
 int launch_dma(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
+    g.ntm = (g.M + BM - 1) / BM;
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     g.ntn = (logical_cols + WGN * WTN - 1) / (WGN * WTN);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<bf16_t, WGM, WGN, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(WGN));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<f16_t, WGM, WGN, ABL>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(WGN));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<bf16_t, WGM, WGN, ABL, BM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(BM, WGN));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<f16_t, WGM, WGN, ABL, BM>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(BM, WGN));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(g.ntm * g.ntn, g.splits, a.batch);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_dma_kernel<T, WGM, WGN, ABL>), grid, dim3(WGM * WGN * 64), lds_bytes(WGN), st, a, g));
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_dma_kernel<T, WGM, WGN, ABL, BM>), grid, dim3(WGM * WGN * 64), lds_bytes(BM, WGN), st, a, g));
     return (int)hipGetLastError();
 }
 
@@ -267,7 +270,6 @@ namespace omgsr {
 int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     g.nk_total = a.K_pad / BK;
-    g.ntm = (g.M + BM - 1) / BM;
     if (g.splits > 1) {                        // split-K always runs the 256 x 128 tile (see igemm_splitk_plan)
         g.nk = (g.nk_total + g.splits - 1) / g.splits;
         return launch_dma<2, 2>(a, g, st);
@@ -286,6 +288,17 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     const int64_t t256 = (int64_t)g.ntm * ((logical_cols + 255) / 256) * a.batch;
     if (!(shape && shape[0] == 'n') && (a.Cout_pad % 256) == 0 && logical_cols >= 256 && t256 >= 200)
         return launch_dma<2, 4>(a, g, st);
+    // tile-count quantisation on the 512 slots (2 workgroups per CU): when the 256-row grid leaves the last round under
+    // ~3/4 full and the 192-row grid fills it better, take 192 x 128
+    {
+        const int64_t nt = (logical_cols + 127) / 128;
+        const int64_t t256b = (int64_t)((g.M + 255) / 256) * nt * a.batch, t192 = (int64_t)((g.M + 191) / 192) * nt * a.batch;
+        auto eff = [](int64_t tiles) { const int64_t rounds = (tiles + 511) / 512; return (double)tiles / (double)(rounds * 512); };
+        static const char* bm = getenv("OMGSR_DMA_BM");              // A/B runs: "256" | "192"
+        const bool force192 = bm && bm[0] == '1', force256 = bm && bm[0] == '2';
+        if (!force256 && (g.M % 192) == 0 && (force192 || (eff(t256b) < 0.78 && eff(t192) > eff(t256b) + 0.1)))
+            return launch_dma<2, 2, 0, 192>(a, g, st);
+    }
     return launch_dma<2, 2>(a, g, st);
 }
 }  // namespace omgsr
