@@ -286,7 +286,11 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     // 256 x 256 tile (8 waves of 128x64): a third fewer operand bytes per FLOP; needs 256-row weight padding and
     // enough tiles to fill the chip
     const int64_t t256 = (int64_t)g.ntm * ((logical_cols + 255) / 256) * a.batch;
-    if (!(shape && shape[0] == 'n') && (a.Cout_pad % 256) == 0 && logical_cols >= 256 && t256 >= 200)
+    // ... and no more padded columns than the 128-wide grid would compute (N = 320 is 512 columns of 256-wide tiles but 384
+    // of 128-wide ones: q/k/v/out of the UNet's first level 108 -> 89 us)
+    const int cols256 = ((logical_cols + 255) / 256) * 256, cols128 = ((logical_cols + 127) / 128) * 128;
+    if (!(shape && shape[0] == 'n') && (a.Cout_pad % 256) == 0 && logical_cols >= 256 && t256 >= 200 &&
+        (cols256 * 16 <= cols128 * 17 || getenv("OMGSR_DMA_PAD256")))
         return launch_dma<2, 4>(a, g, st);
     // tile-count quantisation on the 512 slots (2 workgroups per CU): when the 256-row grid leaves the last round under
     // ~3/4 full and the 192-row grid fills it better, take 192 x 128
