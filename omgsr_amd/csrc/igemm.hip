@@ -238,8 +238,10 @@ int splitk_plan(const omgsr_igemm_args& a, int64_t M64) {
     if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || logical_cols < 96) return 1;
     const int nk = a.K_pad / 32;
     const int64_t tiles = ((M64 + 255) / 256) * ((logical_cols + 127) / 128);
-    if (tiles >= 128 || nk < 48) return 1;
-    int splits = (int)(256 / tiles);
+    static const char* old = getenv("OMGSR_SPLITK_OLD");              // A/B runs
+    const int slots = old ? 256 : 512;                                 // two 256 x 128 workgroups per CU
+    if (tiles >= slots / 2 || nk < 48) return 1;
+    int splits = (int)(slots / tiles);
     if (splits > 8) splits = 8;
     while (splits > 1 && nk / splits < 16) --splits;
     return splits < 2 ? 1 : splits;
