@@ -232,10 +232,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
     }
 }
 
+bool use_halo(const omgsr_igemm_args& a);
+
 // Split-K policy: small-M problems whose 256x128 tiles cannot fill the 256 CUs but whose contraction is long.
 int splitk_plan(const omgsr_igemm_args& a, int64_t M64) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || logical_cols < 96) return 1;
+    if (use_halo(a)) return 1;                  // the halo-tile kernel takes the problem (and owns the fused GroupNorm statistics)
     const int nk = a.K_pad / 32;
     const int64_t tiles = ((M64 + 255) / 256) * ((logical_cols + 127) / 128);
     static const char* old = getenv("OMGSR_SPLITK_OLD");              // A/B runs
@@ -321,6 +324,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     if (a.workspace && !(mode && (!strcmp(mode, "reg") || !strcmp(mode, "halo")))) {
         const int splits = splitk_plan(a, M64);
         if (splits > 1) {
+            if (a.gn_partial) return OMGSR_E_BADARG;        // the reduce pass does not emit GroupNorm statistics (omgsr_igemm_gn_slots says so)
             g.splits = splits;
             const int rc = omgsr::igemm_dma_launch(a, g, st);
             if (rc != 0) return rc;
