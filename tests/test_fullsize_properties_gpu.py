@@ -1,0 +1,121 @@
+"""Size-independent properties at BASELINE.json's FULL sizes (SD2.1-base shapes, 512 / 1024 px), where the fp32 CPU oracle
+takes minutes (bench.py's cpu_baseline leg does that comparison once per run: PSNR 46 dB bf16 / 64 dB fp16):
+batch invariance, scaling linearity of the conv kernels, identity of the Gaussian latent stitch, tiled == untiled VAE
+when one tile covers the image, and agreement of the two 16-bit modes with each other."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def full_s():
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api import AutoencoderKL, UNet2DConditionModel
+    from omgsr_amd.pipelines.omgsr_s import OMGSR_S_Infer
+    from omgsr_amd.testing import seeded_init_
+    ops.set_compute_dtype(torch.bfloat16)
+    vae, unet = seeded_init_(AutoencoderKL(), 101), seeded_init_(UNet2DConditionModel(), 202)
+    pipe = OMGSR_S_Infer(None, None, 273, DEV, torch.bfloat16, vae=vae, unet=unet)
+    g = torch.Generator().manual_seed(7)
+    prompt = torch.randn(1, 77, 1024, generator=g).to(torch.bfloat16).to(DEV)
+    return pipe, prompt
+
+
+def _lq(B, side, seed):
+    from omgsr_amd import ops
+    from omgsr_amd.testing import synthetic_lq
+    return ops.nchw_to_nhwc(synthetic_lq(B, side, side, seed=seed).to(DEV), 8)
+
+
+def test_determinism_and_batch_invariance_full_size(full_s):
+    """OMGSR-S 128->512 at SD2.1 shapes: the same batch twice is BIT-identical (fixed-order reductions, no atomics); a
+    batch of 3 equals three batch-1 runs up to summation order (the dispatcher picks tile shapes / split-K by problem
+    size, so fp32 partial sums associate differently and bf16 roundings flip; through ~100 layers the two runs are two
+    independent draws of the bf16 rounding noise around the fp32 result: measured 2.5e-2 = sqrt(2) x the 1.8e-2 of either
+    run against the fp32 oracle). Cross-image leakage would be O(1)."""
+    from omgsr_amd.testing import rel_l2
+    pipe, prompt = full_s
+    x = _lq(3, 512, 11)
+    eps = torch.randn(3, 4, 64, 64, generator=torch.Generator().manual_seed(12)).to(DEV)
+    with torch.no_grad():
+        pipe.vae.posterior_noise = eps
+        full = pipe.sr_nhwc(x, prompt, 64, 32)
+        again = pipe.sr_nhwc(x, prompt, 64, 32)
+        singles = []
+        for i in range(3):
+            pipe.vae.posterior_noise = eps[i:i + 1]
+            singles.append(pipe.sr_nhwc(x[i:i + 1].contiguous(), prompt, 64, 32))
+    assert torch.isfinite(full.float()).all()
+    assert torch.equal(full, again)
+    for i in range(3):
+        e = rel_l2(full[i:i + 1, ..., :3].float().cpu(), singles[i][..., :3].float().cpu())
+        print(f"image {i}: batch-3 vs batch-1 rel-L2 {e:.2e}")
+        assert e < 5e-2
+
+
+def test_latent_stitch_identity_1024(full_s):
+    """128 x 128 latent, tile 64 / overlap 32 (the 1024-px configuration): stitching the tiles of an identity denoiser
+    returns the latent (Gaussian weights normalise to one) within one 16-bit rounding."""
+    from omgsr_amd.pipelines.latent_tiling import tiled_denoise
+    z = torch.zeros(2, 128, 128, 8, device=DEV, dtype=torch.bfloat16)
+    z[..., :4] = torch.randn(2, 128, 128, 4, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).to(DEV)
+    out = tiled_denoise(z, 4, 64, 32, lambda t: t)
+    assert (out[..., :4].float() - z[..., :4].float()).abs().max().item() <= 2 ** -7 * z.float().abs().max().item()
+    assert bool((out[..., 4:] == 0).all())
+
+
+@pytest.mark.parametrize("N,C,Cout,H,W", [(4, 128, 128, 512, 512), (4, 512, 512, 128, 128), (36, 320, 320, 64, 64), (36, 1280, 1280, 16, 16)])
+def test_conv_scaling_linearity_full_size(N, C, Cout, H, W):
+    """conv(2x) == 2 conv(x) bit for bit without a bias (power-of-two scaling commutes with every rounding) on the
+    layer shapes of the default bench: halo-tile, LDS-DMA (narrow map) and split paths."""
+    from omgsr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(N, H, W, C, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    w = torch.randn(Cout, C, 3, 3, generator=g) * (9 * C) ** -0.5
+    pw = ops.pack_conv_weight(w, None, device=DEV)
+    y1 = ops.conv2d(x, pw, pad=1)
+    y2 = ops.conv2d(x * 2, pw, pad=1)
+    assert torch.isfinite(y1.float()).all() and y1.float().abs().max() > 0
+    assert torch.equal(y2.float(), y1.float() * 2)
+
+
+def test_tiled_vae_with_one_tile_equals_untiled(full_s):
+    """VAEHook with a tile that covers the image takes the reference's "tiny, unnecessary to tile" branch: bit-identical."""
+    pipe, _ = full_s
+    from omgsr_amd.pipelines.vaehook import VAEHook
+    z = torch.zeros(1, 64, 64, 8, device=DEV, dtype=torch.bfloat16)
+    z[..., :4] = torch.randn(1, 64, 64, 4, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16).to(DEV)
+    with torch.no_grad():
+        plain = pipe.vae.decoder.run_nhwc(z) if hasattr(pipe.vae.decoder, "run_nhwc") else pipe.vae.decoder.nhwc(z)
+        hook = VAEHook(pipe.vae.decoder, 64, is_decoder=True, fast_decoder=False, fast_encoder=False, color_fix=False, to_gpu=True)
+        tiled = hook(z)
+    assert torch.equal(plain, tiled)
+
+
+def test_bf16_and_fp16_modes_agree_full_size(full_s):
+    """The two 16-bit modes run the same kernels (templates on the element type): on OMGSR-S 128->512 at SD2.1 shapes their
+    outputs agree to the bf16 mode's own error level (PSNR > 40 dB), i.e. neither mode has a dtype-specific defect."""
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api import AutoencoderKL, UNet2DConditionModel
+    from omgsr_amd.pipelines.omgsr_s import OMGSR_S_Infer
+    from omgsr_amd.testing import psnr, seeded_init_
+    pipe, prompt = full_s
+    x = _lq(1, 512, 21)
+    eps = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(22)).to(DEV)
+    with torch.no_grad():
+        pipe.vae.posterior_noise = eps
+        a = pipe.sr_nhwc(x, prompt, 64, 32).float().cpu()
+    try:
+        vae, unet = seeded_init_(AutoencoderKL(), 101), seeded_init_(UNet2DConditionModel(), 202)
+        p16 = OMGSR_S_Infer(None, None, 273, DEV, torch.float16, vae=vae, unet=unet)          # switches the library to fp16
+        p16.vae.posterior_noise = eps
+        with torch.no_grad():
+            b = p16.sr_nhwc(x.to(torch.float16), prompt.to(torch.float16), 64, 32).float().cpu()
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
+    assert torch.isfinite(b).all()
+    p = psnr(b[..., :3].clamp(-1, 1), a[..., :3].clamp(-1, 1))
+    print(f"bf16 vs fp16 mode, OMGSR-S 512: PSNR {p:.1f} dB")
+    assert p > 40.0
