@@ -464,3 +464,56 @@ def test_groupnorm_merged_tile_statistics():
         r = torch.rsqrt(var_ref + 1e-6).repeat(tiles[k], 1)[:, :, None, None].repeat_interleave(C // G, 1)
         ref = F.silu((t - m) * r * gamma[None, :, None, None] + beta[None, :, None, None])
         assert_close(to_nchw(y), ref, f"shared-stat apply group {k}")
+
+
+def _threshold_cases():
+    """Shapes that straddle the dispatcher's decision points (192 / 256 / 512 tiles, split-K length, 32-pixel halo width,
+    192-row tiles), with and without residual / fused statistics: every path must agree with torch."""
+    import random
+    rng = random.Random(2024)
+    cases = []
+    for _ in range(28):
+        C = rng.choice([32, 64, 128, 256, 320, 512, 640])
+        Cout = rng.choice([96, 128, 256, 320, 384, 512])
+        target_tiles = rng.choice([150, 190, 200, 250, 260, 500, 520, 700])
+        ntn = (Cout + 127) // 128
+        px = max(256, target_tiles * 256 // ntn)
+        W = rng.choice([16, 24, 32, 40, 48, 64, 86, 96])
+        N = rng.choice([1, 2, 3])
+        H = max(8, px // (W * N))
+        if 2.0 * N * H * W * C * 9 * Cout > 6e10:           # keep the CPU reference to a second or two
+            continue
+        cases.append((N, C, Cout, H, W, rng.random() < 0.5, rng.random() < 0.5))
+    return cases
+
+
+@pytest.mark.parametrize("case", _threshold_cases())
+def test_conv_shapes_around_dispatch_thresholds(case):
+    ops = _ops()
+    N, C, Cout, H, W, use_res, want_stats = case
+    x = rnd(N, C, H, W, seed=200)
+    w = rnd(Cout, C, 3, 3, seed=201, scale=(9 * C) ** -0.5)
+    b = rnd(Cout, seed=202)
+    r = rnd(N, Cout, H, W, seed=203) if use_res else None
+    ref = F.conv2d(x, w, b, padding=1) + (r if use_res else 0)
+    pw = ops.pack_conv_weight(w, b, device=DEV)
+    y = ops.conv2d(nhwc(x), pw, pad=1, residual=None if r is None else nhwc(r), gn_groups=32 if want_stats and Cout % 32 == 0 else 0)
+    assert_close(to_nchw(y), ref, f"conv{case}")
+    if want_stats and Cout % 32 == 0:
+        mean, rstd, var = ops.group_norm_stats(y, 32, 1e-6)          # fused partials when the path left them, else the read pass
+        g = ref.view(N, 32, -1)
+        assert torch.allclose(mean.cpu(), g.mean(-1), atol=3e-3, rtol=3e-3), f"stats{case}"
+        assert torch.allclose(var.cpu(), g.var(-1, unbiased=False), atol=3e-3, rtol=6e-3), f"stats{case}"
+
+
+@pytest.mark.parametrize("M,K,Nout", [(9216, 1280, 1280), (9216, 640, 320), (4608, 3072, 768), (2304, 2560, 1280), (36864, 320, 640),
+                                       (12288, 512, 384), (50000, 320, 320)])
+def test_linear_shapes_around_dispatch_thresholds(M, K, Nout):
+    ops = _ops()
+    x = rnd(1, M, K, seed=210)
+    w = rnd(Nout, K, seed=211, scale=K ** -0.5)
+    b = rnd(Nout, seed=212)
+    res = rnd(1, M, Nout, seed=213)
+    pw = ops.pack_linear_weight(w, b, device=DEV)
+    y = ops.linear(bf(x).to(DEV), pw, residual=bf(res).to(DEV))
+    assert_close(y, F.linear(x, w, b) + res, f"linear{(M, K, Nout)}")
