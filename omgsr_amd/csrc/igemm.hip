@@ -256,7 +256,8 @@ bool use_halo(const omgsr_igemm_args& a) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     const bool halo_ok = a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 &&
                          (a.Cin % 32) == 0 && a.batch == 1 && a.Ho == (a.H << a.upsample) && a.Wo == (a.W << a.upsample) && a.Wo >= 16 &&
-                         logical_cols >= 96 && a.out_layout == OMGSR_LAYOUT_NHWC;
+                         (logical_cols >= 96 || (logical_cols <= 32 && a.act != OMGSR_ACT_GEGLU && !getenv("OMGSR_HALO_NO_NARROW"))) &&
+                         a.out_layout == OMGSR_LAYOUT_NHWC;
     if (!halo_ok || (mode && (!strcmp(mode, "reg") || !strcmp(mode, "dma")))) return false;
     if (mode && !strcmp(mode, "halo")) return true;
     // the halo tile is 32 pixels wide: on narrow maps (the UNet's 16 x 16 level) half of every tile would be padding
@@ -272,6 +273,7 @@ extern "C" int32_t omgsr_igemm_gn_slots(const omgsr_igemm_args* ap) {
     if (!ap || ap->gn_groups <= 0 || ap->Cout <= 0 || (ap->Cout % ap->gn_groups)) return 0;
     const int gsz = ap->Cout / ap->gn_groups;
     if (!(gsz == 4 || gsz == 8 || gsz == 16 || gsz == 32 || gsz == 64)) return 0;
+    if (ap->Cout < 96) return 0;                               // the narrow halo shape does not emit statistics
     const int64_t ldo = ap->out_ld > 0 ? ap->out_ld : ap->Cout;
     if ((ap->Cout & 7) || (ldo & 7) || ap->act == OMGSR_ACT_GEGLU) return 0;     // the epilogue's 16-byte-row fast path
     if (!use_halo(*ap)) return 0;

@@ -78,6 +78,10 @@ CONV_CASES = [
     (2, 256, 128, 64, 64, 1, (1, 1, 1, 1), False, True, True, 0),
     (2, 128, 128, 64, 96, 1, (1, 1, 1, 1), True, True, False, 0),       # 2x upsample on the halo-tile path (>= 192 tiles)
     (1, 64, 128, 43, 150, 1, (1, 1, 1, 1), True, False, False, 0),     # ... ragged
+    (2, 128, 3, 128, 192, 1, (1, 1, 1, 1), False, True, False, 0),     # conv_out on the narrow halo shape (Cout <= 32, >= 192 tiles)
+    (4, 128, 8, 86, 150, 1, (1, 1, 1, 1), False, True, False, 0),
+    (1, 64, 16, 256, 200, 1, (1, 1, 1, 1), False, False, True, 1),
+    (2, 32, 32, 100, 260, 1, (1, 1, 1, 1), True, True, False, 0),
 ]
 
 
