@@ -89,19 +89,23 @@ typedef struct omgsr_igemm_args {
     const void* weight_cm; /* optional second packing of a 3x3 weight, slice-major [Cin/32][9 taps][Cout_pad][32]
                               (Cin % 32 == 0; tap = r*3+s): enables the halo-tile kernel | NULL */
     void* workspace;       /* split-K scratch (f32), omgsr_igemm_workspace_bytes() bytes | NULL = never split */
-    float* gn_partial;     /* optional fused GroupNorm statistics of `out`: f32 [N][gn_slots][gn_groups][2] (sum, sum of
-                              squares per slot), to be folded by omgsr_groupnorm_finalize | NULL. Only when
-                              omgsr_igemm_gn_slots() > 0 for these arguments. */
+    float* gn_partial;     /* optional fused GroupNorm statistics of `out`: f32 [N][gn_slots][gn_entries][2] (sum, sum of
+                              squares per slot and entry), to be folded by omgsr_groupnorm_finalize | NULL. Only when
+                              omgsr_igemm_gn_slots() > 0 for these arguments; gn_entries = omgsr_igemm_gn_entries():
+                              gn_groups (one entry per group) or Cout (one per channel: group sizes that are not 4..64 pow2). */
     int32_t gn_groups;
+    int32_t gn_entries;
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
 /* Bytes of `workspace` that would let omgsr_igemm split the contraction of a small-M / large-K problem over
  * several workgroups (fp32 partial tiles + a reduce pass that applies the epilogue); 0 = no split for this shape. */
 int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* a);
-/* Slots per image of `gn_partial` if omgsr_igemm can emit the GroupNorm statistics of its output for these
- * arguments (with gn_groups set; 3x3 halo-tile path, NHWC 16-byte rows, Cout/gn_groups in {4, 8, 16, 32, 64}),
- * else 0: the caller then runs omgsr_groupnorm_stats on the output instead. */
+/* Slots per image / entries per slot of `gn_partial` if omgsr_igemm can emit the GroupNorm statistics of its output for
+ * these arguments (gn_groups set; NHWC 16-byte rows, no GEGLU, batch 1; halo-tile path: one slot per wave tile; GEMM-shaped
+ * kernels: one slot per 32-row block when Ho*Wo % 32 == 0; not on the split-K path), else 0: the caller then runs
+ * omgsr_groupnorm_stats on the output instead. */
 int32_t omgsr_igemm_gn_slots(const omgsr_igemm_args* a);
+int32_t omgsr_igemm_gn_entries(const omgsr_igemm_args* a);
 
 /*
  * K4 — GroupNorm statistics and apply (replaces F.group_norm; the externally supplied
@@ -115,7 +119,7 @@ int omgsr_groupnorm_stats(const void* x, float* partial, float* mean, float* rst
 /* Second half of omgsr_groupnorm_stats alone: fold partial [N][nslot][G][2] (from omgsr_igemm's gn_partial) into
  * mean / rstd (/ biased variance); count = elements per (image, group) = HW * C / G. */
 int omgsr_groupnorm_finalize(const float* partial, float* mean, float* rstd, float* var_out, int32_t N,
-                             int32_t nslot, int32_t G, double count, float eps, void* stream);
+                             int32_t nslot, int32_t G, int32_t entries, double count, float eps, void* stream);
 /* First half of omgsr_groupnorm_stats alone: partial [N][omgsr_groupnorm_nchunk(HW)][G][2]. */
 int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N, int64_t HW, int32_t C, int32_t G, void* stream);
 /*
@@ -132,6 +136,7 @@ typedef struct omgsr_gn_merge_args {
     float weight[OMGSR_GN_MAX_GROUPS];
     int32_t tiles[OMGSR_GN_MAX_GROUPS];
     int32_t nslot[OMGSR_GN_MAX_GROUPS];
+    int32_t entries[OMGSR_GN_MAX_GROUPS];   /* entries per slot of partial[k]: G or C */
     int32_t ngroups;
 } omgsr_gn_merge_args;
 int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, float* mean, float* rstd, float* var_out,

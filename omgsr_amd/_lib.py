@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class OmgsrError(RuntimeError):
@@ -35,7 +35,7 @@ class IgemmArgs(C.Structure):
         ("batch", C.c_int32),
         ("in_bstride", C.c_int64), ("w_bstride", C.c_int64), ("out_bstride", C.c_int64),
         ("alpha", C.c_float), ("weight_cm", C.c_void_p), ("workspace", C.c_void_p),
-        ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
+        ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32), ("gn_entries", C.c_int32),
     ]
 
 
@@ -45,7 +45,7 @@ GN_MAX_GROUPS = 8
 class GnMergeArgs(C.Structure):
     _fields_ = [("partial", C.c_void_p * GN_MAX_GROUPS), ("count", C.c_double * GN_MAX_GROUPS),
                 ("weight", C.c_float * GN_MAX_GROUPS), ("tiles", C.c_int32 * GN_MAX_GROUPS),
-                ("nslot", C.c_int32 * GN_MAX_GROUPS), ("ngroups", C.c_int32)]
+                ("nslot", C.c_int32 * GN_MAX_GROUPS), ("entries", C.c_int32 * GN_MAX_GROUPS), ("ngroups", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -75,7 +75,8 @@ SIGNATURES = {
     "omgsr_igemm": (C.c_int, [C.POINTER(IgemmArgs), _P]),
     "omgsr_igemm_workspace_bytes": (C.c_int64, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_slots": (C.c_int32, [C.POINTER(IgemmArgs)]),
-    "omgsr_groupnorm_finalize": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, C.c_double, _F, _P]),
+    "omgsr_igemm_gn_entries": (C.c_int32, [C.POINTER(IgemmArgs)]),
+    "omgsr_groupnorm_finalize": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, C.c_double, _F, _P]),
     "omgsr_groupnorm_partial": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
     "omgsr_groupnorm_finalize_merged": (C.c_int, [C.POINTER(GnMergeArgs), _P, _P, _P, _I, _I, _F, _P]),
     "omgsr_groupnorm_apply_shared": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args 
 
     // ---- epilogue: fragments -> LDS (fp32) -> 8 consecutive channels per lane -------------
     float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
-    igemm_epilogue_linear<T, WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
+    igemm_epilogue_linear<T, WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz, p.gn_partial ? g.HoWo : 0);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -269,17 +269,42 @@ bool use_halo(const omgsr_igemm_args& a) {
 
 }  // namespace
 
+namespace {
+// Where and in which form omgsr_igemm can emit the GroupNorm statistics of its output (0 slots = it cannot).
+void gn_plan(const omgsr_igemm_args& a, int* nslot, int* entries) {
+    *nslot = 0; *entries = 0;
+    if (a.gn_groups <= 0 || a.Cout <= 0 || (a.Cout % a.gn_groups)) return;
+    const int gsz = a.Cout / a.gn_groups;
+    const bool pow2 = gsz == 4 || gsz == 8 || gsz == 16 || gsz == 32 || gsz == 64;
+    const int64_t ldo = a.out_ld > 0 ? a.out_ld : a.Cout;
+    if ((a.Cout & 7) || (ldo & 7) || a.act == OMGSR_ACT_GEGLU || a.out_layout != OMGSR_LAYOUT_NHWC || a.batch != 1) return;   // the epilogue's 16-byte-row fast path
+    const int64_t M64 = (int64_t)a.N * a.Ho * a.Wo;
+    if (use_halo(a)) {
+        if (a.Cout < 96) return;                                 // the narrow halo shape does not emit statistics
+        *nslot = omgsr::igemm_halo_gn_slots(a);                  // one slot per wave tile (it lies in one image)
+        *entries = pow2 ? a.gn_groups : a.Cout;
+        return;
+    }
+    if (a.workspace && splitk_plan(a, M64) > 1) return;          // the split-K reduce pass does not emit them
+    const int howo = a.Ho * a.Wo;
+    if (howo % 32) return;                                       // GEMM-shaped kernels: one slot per 32-row block, never straddling images
+    *nslot = howo / 32;
+    *entries = (pow2 && gsz <= 32) ? a.gn_groups : a.Cout;       // a 32-column wave tile holds whole groups up to 32 channels
+}
+}  // namespace
+
 extern "C" int32_t omgsr_igemm_gn_slots(const omgsr_igemm_args* ap) {
-    if (!ap || ap->gn_groups <= 0 || ap->Cout <= 0 || (ap->Cout % ap->gn_groups)) return 0;
-    const int gsz = ap->Cout / ap->gn_groups;
-    if (!(gsz == 4 || gsz == 8 || gsz == 16 || gsz == 32 || gsz == 64)) return 0;
-    if (ap->Cout < 96) return 0;                               // the narrow halo shape does not emit statistics
-    const int64_t ldo = ap->out_ld > 0 ? ap->out_ld : ap->Cout;
-    if ((ap->Cout & 7) || (ldo & 7) || ap->act == OMGSR_ACT_GEGLU) return 0;     // the epilogue's 16-byte-row fast path
-    if (!use_halo(*ap)) return 0;
-    const int64_t M64 = (int64_t)ap->N * ap->Ho * ap->Wo;
-    if (ap->workspace && splitk_plan(*ap, M64) > 1) return 0;
-    return omgsr::igemm_halo_gn_slots(*ap);
+    if (!ap) return 0;
+    int nslot, entries;
+    gn_plan(*ap, &nslot, &entries);
+    return nslot;
+}
+
+extern "C" int32_t omgsr_igemm_gn_entries(const omgsr_igemm_args* ap) {
+    if (!ap) return 0;
+    int nslot, entries;
+    gn_plan(*ap, &nslot, &entries);
+    return entries;
 }
 
 extern "C" int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* ap) {
@@ -338,8 +363,12 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         }
     }
     // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
+    if (a.gn_partial) {                            // must be exactly what omgsr_igemm_gn_slots / _gn_entries promised
+        int nslot, entries;
+        gn_plan(a, &nslot, &entries);
+        if (nslot <= 0 || a.gn_entries != entries) return OMGSR_E_BADARG;
+    }
     if (use_halo(a)) return omgsr::igemm_halo_launch(a, g, st);
-    if (a.gn_partial) return OMGSR_E_BADARG;      // fused GroupNorm statistics exist on the halo path only (omgsr_igemm_gn_slots)
     const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0;   // the DMA kernel's K-steps never straddle taps
     if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192)))
         return omgsr::igemm_dma_launch(a, g, st);

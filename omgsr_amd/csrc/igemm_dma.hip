@@ -54,11 +54,11 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 
 template <int N>
 OMGSR_DEVINL void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     else static_assert(N == 0, "unsupported count");
 }
 
@@ -238,11 +238,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
         const int ldw = g.ntn * BN;
         q.out = (float*)p.workspace + (int64_t)blockIdx.y * g.M * ldw;
         q.out_dtype = OMGSR_OUT_F32; q.out_layout = OMGSR_LAYOUT_NHWC; q.out_ld = ldw; q.Cout = ldw;
-        q.bias = nullptr; q.gate = nullptr; q.residual = nullptr; q.act = OMGSR_ACT_NONE; q.alpha = 1.0f;
+        q.bias = nullptr; q.gate = nullptr; q.residual = nullptr; q.act = OMGSR_ACT_NONE; q.alpha = 1.0f; q.gn_partial = nullptr;
         igemm_epilogue_linear<T, WTN, FM, FN>(q, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, 0);
         return;
     }
-    igemm_epilogue_linear<T, WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz);
+    igemm_epilogue_linear<T, WTN, FM, FN>(p, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, bz, p.gn_partial ? g.HoWo : 0);
 }
 
 template <int WGM, int WGN, int ABL = 0, int BM = 256>

@@ -21,7 +21,7 @@ OMGSR_DEVINL void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "me
 template <typename T, int WTN, int FM, int FN>
 OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
                                  const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
-                                 float* gn_dst = nullptr) {
+                                 float* gn_dst = nullptr, const int gn_howo = 0) {
     constexpr int EPI_LD = WTN + 4;
     static_assert(WTN == FN * 32, "wave tile width");
     const int half = lane >> 5, px = lane & 31;
@@ -87,9 +87,48 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                 load_res(0, res[0]);
                 if constexpr (FM > 1) load_res(1, res[1]);
             }
-            // fused GroupNorm statistics (gn_dst != NULL): this wave's (sum, sum of squares) of the values it
-            // stores, per group, for the two 4-channel halves of the lane's 8 channels
-            float gs[2] = {0.0f, 0.0f}, gq[2] = {0.0f, 0.0f};
+            // Fused GroupNorm statistics: (sum, sum of squares) of the values this wave stores, kept per channel of the
+            // lane's octet while rows stream by, then folded over the rows with a fixed butterfly (deterministic) and
+            // written as one entry per GROUP (group size 4 / 8 / 16 / 32 / 64) or per CHANNEL (any other group size, e.g.
+            // the UNet's 10 / 20 / 40: omgsr_groupnorm_finalize folds entries-per-group). Where: one slot per wave tile
+            // (gn_dst, halo kernel: the tile lies in one image) or one slot per 32-row block (gn_howo = Ho*Wo, GEMM-shaped
+            // kernels with Ho*Wo % 32 == 0: a row block never straddles images).
+            const bool gn_on = gn_dst != nullptr || gn_howo > 0;
+            const int gsz = gn_on ? p.Cout / p.gn_groups : 8;
+            const int gn_entries = p.gn_entries;                        // gn_groups (one entry per group) or Cout (per channel)
+            const bool gn_grouped = gn_on && gn_entries == p.gn_groups && gsz >= 4;     // group size 1: per channel IS per group
+            float gs[8], gq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
+            auto gn_flush = [&](float* dst) {
+                if (gn_grouped) {
+                    float a0 = (gs[0] + gs[1]) + (gs[2] + gs[3]), a1 = (gs[4] + gs[5]) + (gs[6] + gs[7]);
+                    float b0 = (gq[0] + gq[1]) + (gq[2] + gq[3]), b1 = (gq[4] + gq[5]) + (gq[6] + gq[7]);
+                    for (int o = lanes_per_row; o < 64; o <<= 1) {
+                        a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); b0 += __shfl_xor(b0, o); b1 += __shfl_xor(b1, o);
+                    }
+                    if (gsz == 4) {
+                        if (lrow == 0 && col_ok) *reinterpret_cast<f32x4_t*>(dst + (n_out >> 2) * 2) = (f32x4_t){a0, b0, a1, b1};
+                    } else {
+                        float s1 = a0 + a1, q1 = b0 + b1;
+                        for (int o = 1; o * 8 < gsz; o <<= 1) { s1 += __shfl_xor(s1, o); q1 += __shfl_xor(q1, o); }
+                        if (lrow == 0 && col_ok && (n_out % gsz) == 0) *reinterpret_cast<f32x2_t*>(dst + (n_out / gsz) * 2) = (f32x2_t){s1, q1};
+                    }
+                } else {
+                    for (int o = lanes_per_row; o < 64; o <<= 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { gs[e] += __shfl_xor(gs[e], o); gq[e] += __shfl_xor(gq[e], o); }
+                    }
+                    if (lrow == 0 && col_ok) {
+                        float* d = dst + (int64_t)n_out * 2;
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2)
+                            *reinterpret_cast<f32x4_t*>(d + 2 * e) = (f32x4_t){gs[e], gq[e], gs[e + 1], gq[e + 1]};
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
+            };
             __syncthreads();            // every wave is done reading the operand ring the staging region overlaps
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
@@ -141,12 +180,9 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                     }
                     if (row < nvalid[i] && col_ok) {
                         const int64_t o = (int64_t)(mb[i] + row) * ldo + n_out;
-                        if (gn_dst) {
+                        if (gn_on) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                gs[0] += v[e]; gq[0] += v[e] * v[e];
-                                gs[1] += v[4 + e]; gq[1] += v[4 + e] * v[4 + e];
-                            }
+                            for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
                         }
                         if (p.out_dtype == OMGSR_OUT_BF16) {
                             *reinterpret_cast<u32x4_t*>(outb + o) = pack8<T>(v);
@@ -157,27 +193,14 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                     }
                 }
                 if (resb && i + 2 < FM) load_res(i + 2, res[i & 1]);
+                if (gn_howo > 0 && nvalid[i] > 0) {        // one slot per 32-row block (wave-uniform condition)
+                    const int img = mb[i] / gn_howo;
+                    const int slot = (mb[i] - img * gn_howo) >> 5;
+                    gn_flush(p.gn_partial + ((int64_t)img * (gn_howo >> 5) + slot) * gn_entries * 2);
+                }
                 wave_lds_fence();       // this wave's reads are done before the next row block overwrites the region
             }
-            if (gn_dst) {
-                // lanes of one column chunk differ in lrow only: fold rows with a fixed butterfly (deterministic)
-                for (int o = lanes_per_row; o < 64; o <<= 1) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) { gs[h] += __shfl_xor(gs[h], o); gq[h] += __shfl_xor(gq[h], o); }
-                }
-                const int gsz = p.Cout / p.gn_groups;          // channels per group: 4 or a multiple of 8 (<= WTN)
-                if (gsz == 4) {
-                    if (lrow == 0 && col_ok) {
-                        float* d = gn_dst + (n_out >> 2) * 2;
-                        *reinterpret_cast<f32x4_t*>(d) = (f32x4_t){gs[0], gq[0], gs[1], gq[1]};
-                    }
-                } else {
-                    float s1 = gs[0] + gs[1], q1 = gq[0] + gq[1];
-                    for (int o = 1; o * 8 < gsz; o <<= 1) { s1 += __shfl_xor(s1, o); q1 += __shfl_xor(q1, o); }
-                    if (lrow == 0 && col_ok && (n_out % gsz) == 0)
-                        *reinterpret_cast<f32x2_t*>(gn_dst + (n_out / gsz) * 2) = (f32x2_t){s1, q1};
-                }
-            }
+            if (gn_dst) gn_flush(gn_dst);
             return;
         }
     }
@@ -264,7 +287,7 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
 // linear-M helper for the GEMM-shaped kernels: row block i starts at m_base + 32*i
 template <typename T, int WTN, int FM, int FN>
 OMGSR_DEVINL void igemm_epilogue_linear(const omgsr_igemm_args& p, const int M, f32x16_t (&acc)[FM][FN], float* epi,
-                                        const int lane, const int m_base, const int n_base, const int bz) {
+                                        const int lane, const int m_base, const int n_base, const int bz, const int gn_howo = 0) {
     int mb[FM], nv[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -272,7 +295,7 @@ OMGSR_DEVINL void igemm_epilogue_linear(const omgsr_igemm_args& p, const int M, 
         const int left = M - mb[i];
         nv[i] = left < 0 ? 0 : (left > 32 ? 32 : left);
     }
-    igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n_base, bz);
+    igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n_base, bz, nullptr, gn_howo);
 }
 
 struct IgemmGeo {

@@ -162,16 +162,20 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     // one K-step with compile-time tap and patch parity
     auto step = [&](auto tap_c, auto par_c, const int cc, const int s) {
         constexpr int tap = decltype(tap_c)::value, par = decltype(par_c)::value;
-        // wait for slice s: only what the PREVIOUS step issued may still be in flight
+        // wait for slice s: only what the PREVIOUS step issued may still be in flight. lgkmcnt(0): every fragment read of the
+        // previous step has RETURNED before this wave passes the barrier that lets the others overwrite that stage - hipcc
+        // is free to sink MFMAs (and the lgkmcnt wait in front of them) below the barrier, and a ds_read still queued
+        // there raced the next LDS-DMA write about once per 10^5 tiles (one wave, a few weight rows of one K-step: found by
+        // the bit-repeatability test; the s_setprio variant pins the MFMAs and never showed it)
         if constexpr (ABL == 2) {
         } else if constexpr (tap == 1) {
-            if (cc + 1 < ncc) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (cc + 1 < ncc) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         } else if constexpr (tap == 8) {
-            if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     {
         float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
         // fused GroupNorm statistics: slot = (spatial tile, upper / lower 4 tile rows), [N][2*tiles][G][2]
-        float* gn_dst = (p.gn_partial && !NARROW) ? p.gn_partial + ((int64_t)(img * per_img + trem) * 2 + wm) * p.gn_groups * 2 : nullptr;
+        float* gn_dst = (p.gn_partial && !NARROW) ? p.gn_partial + ((int64_t)(img * per_img + trem) * 2 + wm) * p.gn_entries * 2 : nullptr;
         igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0, gn_dst);
     }
 }

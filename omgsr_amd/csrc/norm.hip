@@ -74,15 +74,16 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 
 // pass 2: one thread per (n, g): fold the chunk partials in double.
 __global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd,
-                                   float* __restrict__ var_out, int N, int G, int nchunk, double count, float eps) {
+                                   float* __restrict__ var_out, int N, int G, int nchunk, double count, float eps, int entries) {
     // one wave per (n, g): lanes stride the chunk list, fixed-order butterfly in double
     const int i = blockIdx.x;
     const int lane = threadIdx.x;
     const int n = i / G, g = i - n * G;
     double s = 0.0, q = 0.0;
+    const int epg = entries / G;           // entries per group: 1, or the group's channels when the producer wrote per channel
     for (int c = lane; c < nchunk; c += 64) {
-        const float* p = partial + (((int64_t)n * nchunk + c) * G + g) * 2;
-        s += (double)p[0]; q += (double)p[1];
+        const float* p = partial + (((int64_t)n * nchunk + c) * entries + g * epg) * 2;
+        for (int j = 0; j < epg; ++j) { s += (double)p[2 * j]; q += (double)p[2 * j + 1]; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
@@ -411,15 +412,15 @@ extern "C" int omgsr_groupnorm_stats(const void* x, float* partial, float* mean,
                                         (const T*)x, partial, HW, C, G, nchunk));
     const int tot = N * G;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(tot), dim3(64), 0, st, partial, mean, rstd, var_out,
-                       N, G, nchunk, (double)HW * (C / G), eps);
+                       N, G, nchunk, (double)HW * (C / G), eps, G);
     return (int)hipGetLastError();
 }
 
 extern "C" int omgsr_groupnorm_finalize(const float* partial, float* mean, float* rstd, float* var_out, int32_t N,
-                                        int32_t nslot, int32_t G, double count, float eps, void* stream) {
-    if (!partial || !mean || !rstd || N <= 0 || nslot <= 0 || G <= 0 || count <= 0.0) return OMGSR_E_BADARG;
+                                        int32_t nslot, int32_t G, int32_t entries, double count, float eps, void* stream) {
+    if (!partial || !mean || !rstd || N <= 0 || nslot <= 0 || G <= 0 || count <= 0.0 || entries < G || (entries % G)) return OMGSR_E_BADARG;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(64), 0, (hipStream_t)stream, partial, mean, rstd, var_out,
-                       N, G, nslot, count, eps);
+                       N, G, nslot, count, eps, entries);
     return (int)hipGetLastError();
 }
 
@@ -442,9 +443,10 @@ __global__ __launch_bounds__(256) void gn_finalize_merged_kernel(const omgsr_gn_
             if ((pair & 3) != wave) continue;
             const int row = t * N + n;
             double s = 0.0, q = 0.0;
+            const int entries = a.entries[k], epg = entries / G;
             for (int c = lane; c < nslot; c += 64) {
-                const f32x2_t p = *reinterpret_cast<const f32x2_t*>(partial + (((int64_t)row * nslot + c) * G + g) * 2);
-                s += (double)p[0]; q += (double)p[1];
+                const float* pp = partial + (((int64_t)row * nslot + c) * entries + g * epg) * 2;
+                for (int j = 0; j < epg; ++j) { s += (double)pp[2 * j]; q += (double)pp[2 * j + 1]; }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
@@ -488,7 +490,7 @@ extern "C" int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, flo
                                                int32_t N, int32_t G, float eps, void* stream) {
     if (!a || !mean || !rstd || N <= 0 || G <= 0 || a->ngroups <= 0 || a->ngroups > OMGSR_GN_MAX_GROUPS) return OMGSR_E_BADARG;
     for (int k = 0; k < a->ngroups; ++k)
-        if (!a->partial[k] || a->tiles[k] <= 0 || a->nslot[k] <= 0 || a->count[k] <= 0.0) return OMGSR_E_BADARG;
+        if (!a->partial[k] || a->tiles[k] <= 0 || a->nslot[k] <= 0 || a->count[k] <= 0.0 || a->entries[k] < G || (a->entries[k] % G)) return OMGSR_E_BADARG;
     hipLaunchKernelGGL(gn_finalize_merged_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, *a, mean, rstd, var_out, N, G, eps);
     return (int)hipGetLastError();
 }

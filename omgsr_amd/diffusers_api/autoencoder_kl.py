@@ -58,10 +58,10 @@ class Downsample2D(nn.Module):
         self.padding = padding
         self.conv = Conv2d(channels, channels, 3, stride=2, padding=padding)
 
-    def nhwc(self, x):
+    def nhwc(self, x, gn_groups: int = 0):
         # VAE: F.pad(x, (0,1,0,1)) then a valid stride-2 conv; UNet: symmetric padding 1
         pad = (0, 1, 0, 1) if self.padding == 0 else self.padding
-        return self.conv.nhwc(x, pad=pad)
+        return self.conv.nhwc(x, pad=pad, gn_groups=gn_groups)
 
 
 class Upsample2D(nn.Module):
@@ -110,8 +110,8 @@ class VaeAttention(nn.Module):
         p = ops.softmax_rows(s, valid=L)
         del s
         o = ops.bmm_nt(p, vt)                                                 # [N, L, C]
-        out = self.to_out[0].nhwc(o, residual=x.reshape(N, L, Cc))
-        return out.reshape(N, H, W, Cc)
+        out = self.to_out[0].nhwc(o, residual=x.reshape(N, L, Cc), gn_groups=self.group_norm.num_groups)   # -> mid resnet norm1
+        return ops.carry_gn(out, out.reshape(N, H, W, Cc))
 
 
 class _VaeMid(nn.Module):
@@ -136,7 +136,7 @@ class DownEncoderBlock2D(nn.Module):
         for r in self.resnets:
             h = r.nhwc(h)
         if self.downsamplers is not None:
-            h = self.downsamplers[0].nhwc(h)
+            h = self.downsamplers[0].nhwc(h, gn_groups=self.resnets[0].norm1.num_groups)
         return h
 
 
@@ -170,7 +170,7 @@ class Encoder(nn.Module):
         self.conv_out = Conv2d(boc[-1], 2 * c.latent_channels, 3, padding=1)
 
     def nhwc(self, x):
-        h = self.conv_in.nhwc(x)
+        h = self.conv_in.nhwc(x, gn_groups=self.conv_norm_out.num_groups)
         for b in self.down_blocks:
             h = b.nhwc(h)
         h = self.mid_block.nhwc(h)
@@ -206,7 +206,7 @@ class Decoder(nn.Module):
         self.conv_out = Conv2d(boc[0], c.out_channels, 3, padding=1)
 
     def nhwc(self, z):
-        h = self.conv_in.nhwc(z)
+        h = self.conv_in.nhwc(z, gn_groups=self.conv_norm_out.num_groups)
         h = self.mid_block.nhwc(h)
         for b in self.up_blocks:
             h = b.nhwc(h)

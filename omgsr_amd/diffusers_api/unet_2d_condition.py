@@ -162,7 +162,8 @@ class Transformer2DModel(nn.Module):
         y = self.proj_in.nhwc(self.norm.nhwc(x).reshape(N, H * W, Cc))
         for blk in self.transformer_blocks:
             y = blk.nhwc(y, ehs)
-        return self.proj_out.nhwc(y, residual=res).reshape(N, H, W, Cc)
+        out = self.proj_out.nhwc(y, residual=res, gn_groups=self.norm.num_groups)     # a resnet's GroupNorm usually consumes it
+        return ops.carry_gn(out, out.reshape(N, H, W, Cc))
 
 
 class _DownBlock(nn.Module):
@@ -257,7 +258,8 @@ class UNet2DConditionModel(ModelMixin):
     def nhwc(self, x: torch.Tensor, timestep, ehs: torch.Tensor) -> torch.Tensor:
         """x [B,h,w,8] (4 latent channels + zero pad) -> eps [B,h,w,8] bf16 (4 channels + zero pad)."""
         fb = self._folded_biases(timestep)
-        h = self.conv_in.nhwc(x)
+        g = self.config.norm_num_groups       # producers leave the statistics of the GroupNorm that reads them next
+        h = self.conv_in.nhwc(x, gn_groups=g)
         skips = [h]
         for blk in self.down_blocks:
             for j, r in enumerate(blk.resnets):
@@ -266,7 +268,7 @@ class UNet2DConditionModel(ModelMixin):
                     h = blk.attentions[j].nhwc(h, ehs)
                 skips.append(h)
             if blk.downsamplers is not None:
-                h = blk.downsamplers[0].nhwc(h)
+                h = blk.downsamplers[0].nhwc(h, gn_groups=g)
                 skips.append(h)
         m = self.mid_block
         h = m.resnets[0].nhwc(h, fb[id(m.resnets[0])])

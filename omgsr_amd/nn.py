@@ -57,8 +57,8 @@ class Linear(nn.Linear, _Packed):
     def packed(self) -> ops.PackedWeight:
         return self._packed(lambda: ops.pack_linear_weight(self.weight, self.bias), self.weight, self.bias)
 
-    def nhwc(self, x, *, act=ops.ACT_NONE, residual=None, gate=None, out_dtype=ops.OUT_BF16):
-        return ops.linear(x, self.packed(), act=act, residual=residual, gate=gate, out_dtype=out_dtype)
+    def nhwc(self, x, *, act=ops.ACT_NONE, residual=None, gate=None, out_dtype=ops.OUT_BF16, gn_groups=0):
+        return ops.linear(x, self.packed(), act=act, residual=residual, gate=gate, out_dtype=out_dtype, gn_groups=gn_groups)
 
     def forward(self, x):
         y = self.nhwc(x.to(ops.act_dtype()).contiguous())

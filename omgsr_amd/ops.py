@@ -197,9 +197,12 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     partial = None
     if gn_groups > 0:
         a.gn_groups = gn_groups
-        nslot = _lib.load().omgsr_igemm_gn_slots(C.byref(a))
+        lib = _lib.load()
+        # a problem that _igemm will split over K (it hands over the workspace) finishes in the reduce pass: no statistics there
+        nslot = 0 if lib.omgsr_igemm_workspace_bytes(C.byref(a)) > 0 else lib.omgsr_igemm_gn_slots(C.byref(a))
         if nslot > 0:
-            partial = torch.empty((N, nslot, gn_groups, 2), device=x.device, dtype=torch.float32)
+            a.gn_entries = lib.omgsr_igemm_gn_entries(C.byref(a))       # per group, or per channel for odd group sizes
+            partial = torch.empty((N, nslot, a.gn_entries, 2), device=x.device, dtype=torch.float32)
             a.gn_partial = partial.data_ptr()
     _igemm(a, x.device, "omgsr_igemm(conv2d)")
     if partial is not None:
@@ -208,16 +211,28 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
 
 
 def linear(x: torch.Tensor, pw: PackedWeight, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
-           gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_BF16, alpha: float = 1.0) -> torch.Tensor:
-    """x [..., K] bf16 -> [..., Cout]."""
+           gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_BF16, alpha: float = 1.0, gn_groups: int = 0) -> torch.Tensor:
+    """x [..., K] bf16 -> [..., Cout]. gn_groups > 0 (x [B, ..., K]): the result feeds a GroupNorm over each x[b]; the GEMM
+    then runs as B images of prod(...) rows so its epilogue can leave the per-image statistics (see conv2d)."""
     lead = x.shape[:-1]
     M = 1
     for d in lead:
         M *= d
-    x2 = x.reshape(1, 1, M, x.shape[-1])
-    r2 = None if residual is None else residual.reshape(1, 1, M, pw.cout)
-    y = conv2d(x2, pw, stride=1, pad=0, act=act, residual=r2, gate=gate, out_dtype=out_dtype, alpha=alpha)
-    return y.reshape(*lead, pw.cout)
+    B = lead[0] if (gn_groups > 0 and len(lead) >= 2) else 1
+    x2 = x.reshape(B, 1, M // B, x.shape[-1])
+    r2 = None if residual is None else residual.reshape(B, 1, M // B, pw.cout)
+    y = conv2d(x2, pw, stride=1, pad=0, act=act, residual=r2, gate=gate, out_dtype=out_dtype, alpha=alpha, gn_groups=gn_groups)
+    out = y.reshape(*lead, pw.cout)
+    carry_gn(y, out)
+    return out
+
+
+def carry_gn(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
+    """Views are new Python objects: hand the fused-statistics handle of `src` on to a view of the same storage."""
+    h = getattr(src, "_omgsr_gn", None)
+    if h is not None and view.data_ptr() == src.data_ptr() and view.shape[0] == src.shape[0]:
+        view._omgsr_gn = h
+    return view
 
 
 def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int, col0: int, *, act: int = ACT_NONE,
@@ -334,7 +349,7 @@ def group_norm_stats(x: torch.Tensor, groups: int, eps: float):
             and fused[0].shape[0] == N:
         # the producing conv already reduced this tensor (omgsr_igemm gn_partial): fold its partials only
         check(lib.omgsr_groupnorm_finalize(fused[0].data_ptr(), mean.data_ptr(), rstd.data_ptr(), var.data_ptr(), N,
-                                           fused[0].shape[1], groups, float(HW) * (Cc // groups), eps, _stream()),
+                                           fused[0].shape[1], groups, fused[0].shape[2], float(HW) * (Cc // groups), eps, _stream()),
               "omgsr_groupnorm_finalize")
         return mean, rstd, var
     nchunk = lib.omgsr_groupnorm_nchunk(HW)
@@ -372,6 +387,7 @@ def group_norm_stats_merged(tensors, tiles, N: int, groups: int, eps: float):
         keep.append(part)
         a.partial[k] = part.data_ptr()
         a.nslot[k] = part.shape[1]
+        a.entries[k] = part.shape[2]
         a.tiles[k] = tiles[k]
         a.count[k] = float(t.shape[1] * t.shape[2] * (t.shape[3] // groups))
         a.weight[k] = t.shape[1] * t.shape[2] / tot

@@ -66,7 +66,7 @@ class VAEHook:
     # ---- op list (order of build_task_queue, infer/vaehook.py:332-359) ----------------------
     def _ops(self):
         net, dec = self.net, self.is_decoder
-        seq = [("f", lambda x: net.conv_in.nhwc(x))]
+        seq = [("f", lambda x: net.conv_in.nhwc(x, gn_groups=net.conv_norm_out.num_groups))]
 
         def resblock(b):
             seq.append(("res_push", (lambda x, b=b: b.conv_shortcut.nhwc(x, pad=0)) if b.conv_shortcut is not None else None))
@@ -93,7 +93,7 @@ class VAEHook:
                 resblock(r)
             if i != len(blocks) - 1:
                 samp = blk.upsamplers[0] if dec else blk.downsamplers[0]
-                seq.append(("f", (lambda x, s=samp, g=blk.resnets[0].norm1.num_groups: s.nhwc(x, gn_groups=g)) if dec else (lambda x, s=samp: s.nhwc(x))))
+                seq.append(("f", (lambda x, s=samp, g=blk.resnets[0].norm1.num_groups: s.nhwc(x, gn_groups=g))))
         if not dec:
             mid()
         seq.append(("gn", net.conv_norm_out, ops.ACT_SILU))

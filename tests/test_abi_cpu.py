@@ -37,11 +37,11 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     """ctypes mirrors of the argument structs: field order/size agree with the C declaration."""
     from omgsr_amd._lib import AttnArgs, GnMergeArgs, IgemmArgs, TimingEntry
-    # 6 ptrs, 22 int32, 3 int64, float (+pad), 3 ptrs, int32 (+pad)
+    # 6 ptrs, 22 int32, 3 int64, float (+pad), 3 ptrs, 2 int32
     assert ctypes.sizeof(IgemmArgs) == 6 * 8 + 22 * 4 + 3 * 8 + 8 + 3 * 8 + 8
     assert ctypes.sizeof(AttnArgs) == 4 * 8 + 5 * 4 + 4 + 8 * 8 + 8
     assert ctypes.sizeof(TimingEntry) == 4 + 4 + 8 + 8 + 3 * 8
-    assert ctypes.sizeof(GnMergeArgs) == 8 * 8 + 8 * 8 + 8 * 4 + 8 * 4 + 8 * 4 + 8     # 8 groups; int32 + tail padding
+    assert ctypes.sizeof(GnMergeArgs) == 8 * 8 + 8 * 8 + 8 * 4 + 8 * 4 + 8 * 4 + 8 * 4 + 8     # 8 groups; int32 + tail padding
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

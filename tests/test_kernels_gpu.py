@@ -521,3 +521,70 @@ def test_linear_shapes_around_dispatch_thresholds(M, K, Nout):
     pw = ops.pack_linear_weight(w, b, device=DEV)
     y = ops.linear(bf(x).to(DEV), pw, residual=bf(res).to(DEV))
     assert_close(y, F.linear(x, w, b) + res, f"linear{(M, K, Nout)}")
+
+
+@pytest.mark.parametrize("kind,N,C,Cout,H,W,G", [
+    ("halo-channel", 4, 320, 320, 64, 64, 32),        # UNet level 0: group size 10 -> one entry per channel, slot per wave tile
+    ("halo-channel", 4, 320, 640, 32, 96, 32),        # group size 20
+    ("dma-group", 4, 128, 128, 128, 96, 32),          # stride-2 conv on the GEMM kernel: slot per 32-row block, per group
+    ("dma-channel", 4, 320, 320, 64, 64, 32),         # 1x1 conv (linear) with group size 10
+    ("reg-group", 1, 64, 128, 32, 40, 32),            # small problem on the register-staged kernel
+    ("linear", 6, 320, 320, 1, 1024, 32),             # ops.linear on [B, L, K]: B images of L rows
+    ("reg-group", 2, 32, 32, 32, 32, 32),             # group size 1 (per channel == per group)
+    ("reg-group", 2, 32, 64, 32, 32, 32),             # group size 2
+    ("halo-channel", 8, 32, 128, 96, 64, 32),         # group size 4 through the halo path
+])
+def test_fused_groupnorm_statistics_all_paths(kind, N, C, Cout, H, W, G):
+    """Every igemm path that can leave GroupNorm statistics (halo tile, GEMM-shaped row blocks; per group or per channel)
+    against torch; the handle must be present, i.e. no read pass over the tensor."""
+    ops = _ops()
+    x = rnd(N, C, H, W, seed=300)
+    gamma, beta = rnd(Cout, seed=304) + 1.0, rnd(Cout, seed=305)
+    if kind.startswith("halo"):
+        w = rnd(Cout, C, 3, 3, seed=301, scale=(9 * C) ** -0.5); b = rnd(Cout, seed=302)
+        ref_conv = F.conv2d(x, w, b, padding=1)
+        y = ops.conv2d(nhwc(x), ops.pack_conv_weight(w, b, device=DEV), pad=1, gn_groups=G)
+    elif kind == "dma-group":
+        w = rnd(Cout, C, 3, 3, seed=301, scale=(9 * C) ** -0.5); b = rnd(Cout, seed=302)
+        ref_conv = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+        y = ops.conv2d(nhwc(x), ops.pack_conv_weight(w, b, device=DEV), stride=2, pad=(0, 1, 0, 1), gn_groups=G)
+    elif kind == "reg-group":
+        w = rnd(Cout, C, 3, 3, seed=301, scale=(9 * C) ** -0.5); b = rnd(Cout, seed=302)
+        ref_conv = F.conv2d(x, w, b, padding=1)
+        y = ops.conv2d(nhwc(x), ops.pack_conv_weight(w, b, device=DEV), pad=1, gn_groups=G)
+    elif kind == "dma-channel":
+        w = rnd(Cout, C, 1, 1, seed=301, scale=C ** -0.5); b = rnd(Cout, seed=302)
+        r = rnd(N, Cout, H, W, seed=303)
+        ref_conv = F.conv2d(x, w, b) + r
+        y = ops.conv2d(nhwc(x), ops.pack_conv_weight(w, b, device=DEV), pad=0, residual=nhwc(r), gn_groups=G)
+    else:
+        w = rnd(Cout, C, seed=301, scale=C ** -0.5); b = rnd(Cout, seed=302)
+        xt = x.view(N, C, H * W).transpose(1, 2).contiguous()                   # [B, L, K]
+        ref_lin = F.linear(xt, w, b)                                             # [B, L, Cout]
+        y = ops.linear(bf(xt).to(DEV), ops.pack_linear_weight(w, b, device=DEV), gn_groups=G)
+        assert y.shape == ref_lin.shape
+        ref_conv = ref_lin.transpose(1, 2).reshape(N, Cout, 1, H * W)
+    assert getattr(y, "_omgsr_gn", None) is not None, f"{kind}: the producer should have left statistics"
+    mean, rstd, var = ops.group_norm_stats(y, G, 1e-5)
+    g = ref_conv.reshape(N, G, -1)
+    assert torch.allclose(mean.cpu(), g.mean(-1), atol=3e-3, rtol=3e-3), kind
+    assert torch.allclose(var.cpu(), g.var(-1, unbiased=False), atol=3e-3, rtol=6e-3), kind
+    y4 = y if y.dim() == 4 else y.reshape(N, 1, H * W, Cout)
+    out = ops.group_norm_apply(y4.contiguous(), mean, rstd, gamma.to(DEV), beta.to(DEV), G, ops.ACT_NONE)
+    ref = F.group_norm(ref_conv, G, gamma, beta, eps=1e-5)
+    assert_close(to_nchw(out), ref, f"{kind} groupnorm", rel_l2=6e-3, max_ulps=6.0)
+
+
+@pytest.mark.parametrize("N,C,Cout,H,W,reps", [(3, 128, 128, 512, 512, 150), (3, 256, 256, 256, 256, 150), (36, 320, 320, 64, 64, 100)])
+def test_conv_bit_repeatability(N, C, Cout, H, W, reps):
+    """The same launch repeated must give the same BITS. This caught a real LDS race in the halo kernel: a fragment read
+    still queued when the wave passed the K-step barrier could meet the next LDS-DMA write (one wave, a few weight rows,
+    about one tile in 10^5) - every counted wait in front of a barrier now also retires the wave's LDS reads."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(N, H, W, C, generator=g) * 0.5).to(ops.act_dtype()).to(DEV)
+    w = torch.randn(Cout, C, 3, 3, generator=g) * (9 * C) ** -0.5
+    pw = ops.pack_conv_weight(w, torch.randn(Cout, generator=g), device=DEV)
+    ref = ops.conv2d(x, pw, pad=1)
+    bad = sum(0 if torch.equal(ops.conv2d(x, pw, pad=1), ref) else 1 for _ in range(reps))
+    assert bad == 0, f"{bad} of {reps} repeats differ"
