@@ -588,3 +588,32 @@ def test_conv_bit_repeatability(N, C, Cout, H, W, reps):
     ref = ops.conv2d(x, pw, pad=1)
     bad = sum(0 if torch.equal(ops.conv2d(x, pw, pad=1), ref) else 1 for _ in range(reps))
     assert bad == 0, f"{bad} of {reps} repeats differ"
+
+
+def test_linear_attention_norm_bit_repeatability():
+    """Same property for the LDS-DMA GEMM (256x128, 256x256 and 192x128 tiles, split-K), attention, GroupNorm, LayerNorm."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(78)
+    dt = ops.act_dtype()
+
+    def check(name, fn, reps):
+        ref = fn()
+        refs = ref if isinstance(ref, (tuple, list)) else (ref,)
+        for _ in range(reps):
+            cur = fn()
+            curs = cur if isinstance(cur, (tuple, list)) else (cur,)
+            assert all(torch.equal(a, b) for a, b in zip(refs, curs)), name
+
+    for M, K, Nout in [(147456, 320, 320), (36864, 640, 1280), (9216, 1280, 1280), (2304, 2560, 1280), (4608, 3072, 3072)]:
+        x = (torch.randn(1, M, K, generator=g) * 0.5).to(dt).to(DEV)
+        pw = ops.pack_linear_weight(torch.randn(Nout, K, generator=g) * K ** -0.5, torch.randn(Nout, generator=g), device=DEV)
+        res = (torch.randn(1, M, Nout, generator=g) * 0.5).to(dt).to(DEV)
+        check(f"linear {M}x{K}->{Nout}", lambda: ops.linear(x, pw, residual=res), 40)
+    B, L, H, D = 4, 4096, 5, 64
+    qk = (torch.randn(B, L, 2 * H * D, generator=g) * 0.5).to(dt).to(DEV)
+    vt = (torch.randn(B, H * D, L, generator=g) * 0.5).to(dt).to(DEV)
+    check("attention", lambda: ops.attention(qk, qk, vt, H, D, D ** -0.5, q_col=0, k_col=H * D, Lk=L), 30)
+    xg = (torch.randn(4, 256, 256, 256, generator=g)).to(dt).to(DEV)
+    check("groupnorm stats", lambda: ops.group_norm_stats(xg, 32, 1e-6), 30)
+    xl = (torch.randn(1, 36864, 640, generator=g)).to(dt).to(DEV)
+    check("layernorm", lambda: ops.layer_norm(xl, None, None, 1e-5), 30)
