@@ -47,8 +47,9 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-// PRIO: raise the wave's priority around its MFMA cluster. Measured +6..10 % on K-heavy layers (Cin >= 512)
-// and -3..5 % on the epilogue-heavy 128/256-channel layers, so the dispatcher picks per layer.
+// PRIO: raise the wave's priority around its MFMA cluster. Measured +6..10 % on K-heavy layers (Cin >= 512) and
+// -3..5 % on the epilogue-heavy 128/256-channel layers with row-major weights; with the slice-major packing it no longer
+// pays anywhere (S-1024 step 136.3 with it on Cin >= 384, 135.7 without): off by default, OMGSR_HALO_PRIO_CIN=<n> for A/B.
 // NARROW: Cout <= 32 (the VAE's conv_out, 128 -> 3): the four waves split the 8 tile rows (2 each) over ONE 32-column
 // fragment instead of 2 x 2 waves over 128 columns. The im2col kernels gather every input pixel nine times out of L2
 // (3.2 GB for a 1.4 MPixel x 128-channel map: 350 us, L2-bound at 70 TFLOP/s); here the patch is read once.
@@ -246,6 +247,12 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
 namespace omgsr {
 // Preconditions (checked by the dispatcher): R = S = 3, stride 1, pad 1 (on the virtual, optionally 2x-upsampled input), Cin % 32 == 0,
 // weight_cm != NULL, batch == 1, W >= 16.
+static int prio_min_cin() {
+    static const char* e = getenv("OMGSR_HALO_PRIO_CIN");      // A/B runs
+    static const int v = e ? atoi(e) : (1 << 30);      // default: never. +6..10 % on Cin >= 512 before the slice-major weights, -0.5 % of the S-1024 step after
+    return v;
+}
+
 int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     g.nk = a.Cin / 32;
@@ -278,7 +285,7 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     else if (abl && abl[0] == '2') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 2, false>), grid, dim3(256), LDS_BYTES, st, a, g);
     else if (abl && abl[0] == '3') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 3, false>), grid, dim3(256), LDS_BYTES, st, a, g);
     else if (narrow) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false, true>), grid, dim3(256), LDS_BYTES, st, a, g));
-    else if (a.Cin >= 384) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, true>), grid, dim3(256), LDS_BYTES, st, a, g));
+    else if (a.Cin >= prio_min_cin()) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, true>), grid, dim3(256), LDS_BYTES, st, a, g));
     else OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false>), grid, dim3(256), LDS_BYTES, st, a, g));
     return (int)hipGetLastError();
 }
