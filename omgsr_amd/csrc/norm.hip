@@ -516,7 +516,9 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
     if (act != OMGSR_ACT_NONE && act != OMGSR_ACT_SILU) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     // ~64 KB of activations per block keeps >= 2k blocks in flight on the big VAE maps
-    int64_t ppb = (32768 + C - 1) / C;      // ~64 KB of activations per block (256 KB measured 30 % slower)
+    static const char* ppe = getenv("OMGSR_GN_BLOCK_ELEMS");           // A/B runs
+    static const int64_t belems = ppe ? atol(ppe) : 16384;
+    int64_t ppb = (belems + C - 1) / C;      // ~32 KB of activations per block (5.6 TB/s; 64 KB 5.4, 128 KB 4.9, 256 KB 30 % slower)
     if (ppb < 1) ppb = 1;
     const int nblk = (int)((HW + ppb - 1) / ppb);
     omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 4.0 * N * (double)HW * C, st);
