@@ -19,6 +19,12 @@ SHAPES = [  # name, M, K, N, geglu, residual
     ("unet L2 ff out 5120->1280", 9216, 5120, 1280, False, True),
     ("flux 3072->3072 M=4608", 4608, 3072, 3072, False, True),
     ("flux 3072->9216 M=4608", 4608, 3072, 9216, False, False),
+    ("small flux txt 3072->3072 M=512", 512, 3072, 3072, False, True),
+    ("small flux txt 3072->12288 M=512", 512, 3072, 12288, False, False),
+    ("small flux txt 12288->3072 M=512", 512, 12288, 3072, False, True),
+    ("small unet512 1280->1280 M=2048", 2048, 1280, 1280, False, True),
+    ("small unet512 640->640 M=8192", 8192, 640, 640, False, True),
+    ("small unet512 320->320 M=32768", 32768, 320, 320, False, True),
 ]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = "cuda"
