@@ -41,6 +41,17 @@ extern "C" {
 #define OMGSR_LAYOUT_NHWC 0   /* out[m][n]                                                        */
 #define OMGSR_LAYOUT_T 1      /* out[(m / t_rows) * Cout + n][m % t_rows] with row stride t_ld     */
 
+/* Element kinds of a tensor argument (`*_el` parameters). The library's data model has two tensor classes:
+ *   operand tensors  feed an MFMA: the 16-bit compute type (OMGSR_EL_16), optionally as a two-term split
+ *                    x = hi + lo with both halves in the compute type (OMGSR_EL_SPLIT, outputs only): a row of C
+ *                    logical channels is stored as [hi_0..hi_{C-1} | lo_0..lo_{C-1}] (row stride 2C), and the consumer's
+ *                    weights are packed with their input channels duplicated, so hi*W + lo*W accumulates in fp32
+ *   stream tensors   everything between two GEMMs (residual stream, conv outputs awaiting a norm, latents): the
+ *                    compute type in the fast tiers, fp32 (OMGSR_EL_F32) in the accurate tier (`--weight_dtype fp32`) */
+#define OMGSR_EL_16 0
+#define OMGSR_EL_F32 1
+#define OMGSR_EL_SPLIT 2
+
 #define OMGSR_DT_BF16 0
 #define OMGSR_DT_F16 1
 /*
@@ -95,6 +106,11 @@ typedef struct omgsr_igemm_args {
                               gn_groups (one entry per group) or Cout (one per channel: group sizes that are not 4..64 pow2). */
     int32_t gn_groups;
     int32_t gn_entries;
+    int32_t res_el;        /* element kind of `residual`: OMGSR_EL_16 | OMGSR_EL_F32 (fp32 residual stream) */
+    int32_t in_split;      /* 0 | 1: `in` is a two-term split operand (Cin = 2 x the logical channels; the packed weight holds
+                              every input channel twice). Informational: FLOP accounting, kernel selection. */
+    int32_t out_lo_off;    /* > 0: a 16-bit output is written as the two-term split: hi at column n, lo at column n + out_lo_off
+                              of the same row (out_lo_off >= Cout, out_ld >= out_lo_off + Cout, both % 8 == 0; NHWC, Cout % 8 == 0) */
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
 /* Bytes of `workspace` that would let omgsr_igemm split the contraction of a small-M / large-K problem over
@@ -115,13 +131,13 @@ int32_t omgsr_igemm_gn_entries(const omgsr_igemm_args* a);
  */
 int omgsr_groupnorm_nchunk(int64_t HW);
 int omgsr_groupnorm_stats(const void* x, float* partial, float* mean, float* rstd, float* var_out,
-                          int32_t N, int64_t HW, int32_t C, int32_t G, float eps, void* stream);
+                          int32_t N, int64_t HW, int32_t C, int32_t G, float eps, int32_t x_el, void* stream);
 /* Second half of omgsr_groupnorm_stats alone: fold partial [N][nslot][G][2] (from omgsr_igemm's gn_partial) into
  * mean / rstd (/ biased variance); count = elements per (image, group) = HW * C / G. */
 int omgsr_groupnorm_finalize(const float* partial, float* mean, float* rstd, float* var_out, int32_t N,
                              int32_t nslot, int32_t G, int32_t entries, double count, float eps, void* stream);
 /* First half of omgsr_groupnorm_stats alone: partial [N][omgsr_groupnorm_nchunk(HW)][G][2]. */
-int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N, int64_t HW, int32_t C, int32_t G, void* stream);
+int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t x_el, void* stream);
 /*
  * Tiled-VAE statistics (infer/vaehook.py:459-534 GroupNormParam.summary + :384-413 custom_group_norm): the tiles of
  * one image come in up to OMGSR_GN_MAX_GROUPS shape groups; group k holds tiles[k] x N rows (tile-major) of partials
@@ -141,21 +157,26 @@ typedef struct omgsr_gn_merge_args {
 } omgsr_gn_merge_args;
 int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, float* mean, float* rstd, float* var_out,
                                     int32_t N, int32_t G, float eps, void* stream);
-/* y = act((x - mean[n,g]) * rstd[n,g] * gamma[c] + beta[c]);  act in {NONE, SILU}. x and y may alias. */
+/* y = act((x - mean[n,g]) * rstd[n,g] * gamma[c] + beta[c]);  act in {NONE, SILU}. x and y may alias when both are
+ * OMGSR_EL_16. x_el: OMGSR_EL_16 | OMGSR_EL_F32; y_el: OMGSR_EL_16 | OMGSR_EL_SPLIT (y is an MFMA operand). */
 int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int32_t N, int64_t HW, int32_t C,
-                          int32_t G, int32_t act, void* stream);
+                          int32_t G, int32_t act, int32_t x_el, int32_t y_el, void* stream);
 /* Same with `rows` rows of x sharing `stat_rows` rows of statistics: row r uses mean[r % stat_rows] (tile-major tiles). */
 int omgsr_groupnorm_apply_shared(const void* x, void* y, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, int32_t rows, int64_t HW, int32_t C,
-                                 int32_t G, int32_t act, int32_t stat_rows, void* stream);
+                                 int32_t G, int32_t act, int32_t stat_rows, int32_t x_el, int32_t y_el, void* stream);
 
 /*
  * K9/K10 — LayerNorm over the last dim (replaces F.layer_norm and the AdaLN-Zero modulate chain of
  * FluxTransformerBlock): y = (x - mu) * rsqrt(var + eps) * a[c] + b[c], a/b f32 [C] or NULL (1 / 0).
  */
 int omgsr_layernorm(const void* x, void* y, const float* a, const float* b, int64_t rows, int32_t C,
-                    float eps, void* stream);
+                    float eps, int32_t x_el, int32_t y_el, void* stream);
+/* Stream tensor -> MFMA operand: y = x rounded to the compute type (y_el OMGSR_EL_16) or its two-term split
+ * (OMGSR_EL_SPLIT); x f32 [rows][C], C % 8 == 0. (Inputs of convs that no norm precedes: up / down-sampling convs,
+ * 1x1 shortcuts, conv_in, proj_out, post_quant_conv.) */
+int omgsr_to_operand(const float* x, void* y, int64_t rows, int32_t C, int32_t y_el, void* stream);
 
 /*
  * K7/K8 — fused softmax(Q K^T * scale) V on MFMA (replaces F.scaled_dot_product_attention).
@@ -171,6 +192,8 @@ typedef struct omgsr_attn_args {
     int64_t q_ld, k_ld, vt_ld, o_ld;
     int64_t q_bstride, k_bstride, vt_bstride, o_bstride;
     float scale;
+    int32_t o_lo_off;      /* > 0: o is written as the two-term split: lo lands o_lo_off columns after hi
+                              (o_lo_off >= H*D, o_ld >= o_lo_off + H*D, o_lo_off % 4 == 0) */
 } omgsr_attn_args;
 int omgsr_attention(const omgsr_attn_args* a, void* stream);
 
@@ -191,44 +214,44 @@ int omgsr_rmsnorm_rope(void* x, const float* w, const float* cos_t, const float*
 /* K14 — layout and latent algebra. */
 /* NCHW (f32 or bf16 per src_dtype: 0 bf16, 1 f32) -> NHWC bf16 with channels zero-padded to Cpad. */
 int omgsr_nchw_to_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W,
-                       int32_t Cpad, int32_t src_dtype, void* stream);
+                       int32_t Cpad, int32_t src_dtype, int32_t dst_el, void* stream);
 /* NHWC bf16 (row stride ld, first C channels) -> NCHW (dst_dtype 0 bf16, 1 f32); optional clamp to [lo,hi]. */
 int omgsr_nhwc_to_nchw(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W,
-                       int32_t ld, int32_t dst_dtype, int32_t do_clamp, float lo, float hi, void* stream);
+                       int32_t ld, int32_t dst_dtype, int32_t do_clamp, float lo, float hi, int32_t src_el, void* stream);
 /* dst[..., off:off+C] = src (bf16 rows) — channel concat building block (torch.cat(dim=1) in NCHW). */
 int omgsr_copy_channels(const void* src, void* dst, int64_t rows, int32_t C, int32_t src_ld,
-                        int32_t dst_ld, int32_t dst_off, void* stream);
+                        int32_t dst_ld, int32_t dst_off, int32_t el, void* stream);
 /*
  * DiagonalGaussianDistribution.sample() * scale (infer/omgsr_s_infer_model.py:173,
  * infer/omgsr_f_infer_model.py:16-17): z = ((mu + exp(0.5*clamp(logvar,-30,20)) * eps) - shift) * scale.
  * moments bf16 NHWC [rows][2*C]; eps f32 NHWC [rows][C]; z bf16 NHWC [rows][ld_out] (cols >= C zeroed).
  */
 int omgsr_vae_sample(const void* moments, const float* eps, void* z, int64_t rows, int32_t C,
-                     int32_t ld_out, float shift, float scale, void* stream);
+                     int32_t ld_out, float shift, float scale, int32_t el, void* stream);
 /* out = (x * a + y * b + c) * d, bf16 tensors with bf16 rounding after every op when `bf16_steps`
  * (mirrors the reference's eager bf16 arithmetic, infer/omgsr_s_infer_model.py:80-84). */
 int omgsr_axpby(const void* x, const void* y, void* out, int64_t n, float a, float b, float c, float d,
-                int32_t bf16_steps, void* stream);
+                int32_t bf16_steps, int32_t el, void* stream);
 /* acc[n,y0+y,x0+x,c] += tile[n,y,x,c] * w[y,x] (f32 acc, bf16 tile NHWC ld=tile_ld), and the matching
  * normaliser; infer/omgsr_s_infer_model.py:137-161. */
 int omgsr_tile_accumulate(const void* tile, const float* w, float* acc, int32_t N, int32_t C,
                           int32_t th, int32_t tw, int32_t tile_ld, int32_t H, int32_t W, int32_t y0,
-                          int32_t x0, void* stream);
+                          int32_t x0, int32_t tile_el, void* stream);
 /* out bf16[rows][ld] = acc f32[rows][C] / wsum[pixel]  (cols >= C zeroed) */
 int omgsr_tile_normalise(const float* acc, const float* wsum, void* out, int32_t N, int64_t HW,
-                         int32_t C, int32_t ld, void* stream);
+                         int32_t C, int32_t ld, int32_t out_el, void* stream);
 /* bf16 window copy: dst[n,y,x,:] = src[n,y0+y,x0+x,:] */
 int omgsr_crop_nhwc(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t y0,
-                    int32_t x0, int32_t th, int32_t tw, void* stream);
+                    int32_t x0, int32_t th, int32_t tw, int32_t el, void* stream);
 /* bf16 window paste: dst[n, dy0+y, dx0+x, :] = src[n, sy0+y, sx0+x, :] for y < th, x < tw (tiled-VAE
  * crop_valid_region + result[...] = tile, infer/vaehook.py:416-427,805). */
 int omgsr_paste_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t sH, int32_t sW, int32_t sy0,
                      int32_t sx0, int32_t dH, int32_t dW, int32_t dy0, int32_t dx0, int32_t th, int32_t tw,
-                     void* stream);
+                     int32_t el, void* stream);
 /* Flux 2x2 pack / unpack between NHWC [N,H,W,C(ld)] and tokens [N,(H/2)(W/2),4C] with channel
  * order c*4 + dy*2 + dx (infer/omgsr_f_infer_model.py:21-41). dir 0 = pack, 1 = unpack. */
 int omgsr_flux_pack(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ld,
-                    int32_t dir, void* stream);
+                    int32_t dir, int32_t el, void* stream);
 
 /*
  * SURVEY §8(f) f1 — the driver's post-process on the device (replaces infer/infer_omgsr_s.py:96-103 and
@@ -243,13 +266,13 @@ int omgsr_flux_pack(const void* src, void* dst, int32_t N, int32_t H, int32_t W,
  */
 /* uint8 [N,H,W,3] -> model input [N,H,W,8] (compute dtype, channels 3..7 zero): to_tensor(img).to(dtype) * 2 - 1
  * (infer/infer_omgsr_s.py:92), rounded to the dtype after each torch op. */
-int omgsr_image_to_model_input(const uint8_t* img_hwc3, void* out_nhwc8, int32_t N, int32_t H, int32_t W, void* stream);
+int omgsr_image_to_model_input(const uint8_t* img_hwc3, void* out_nhwc8, int32_t N, int32_t H, int32_t W, int32_t out_el, void* stream);
 #define OMGSR_COLORFIX_NONE 0
 #define OMGSR_COLORFIX_ADAIN 1
 #define OMGSR_COLORFIX_WAVELET 2
 int64_t omgsr_colorfix_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t method);
 int omgsr_colorfix(const void* sr_nhwc, int32_t sr_ld, const uint8_t* src_hwc3, uint8_t* out_hwc3, void* workspace,
-                   int32_t N, int32_t H, int32_t W, int32_t method, void* stream);
+                   int32_t N, int32_t H, int32_t W, int32_t method, int32_t sr_el, void* stream);
 
 /* Optional per-launch timing (HIP events on the launch stream) for bench.py's roofline leg. */
 int omgsr_timing_enable(int on);

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class OmgsrError(RuntimeError):
@@ -36,6 +36,7 @@ class IgemmArgs(C.Structure):
         ("in_bstride", C.c_int64), ("w_bstride", C.c_int64), ("out_bstride", C.c_int64),
         ("alpha", C.c_float), ("weight_cm", C.c_void_p), ("workspace", C.c_void_p),
         ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32), ("gn_entries", C.c_int32),
+        ("res_el", C.c_int32), ("in_split", C.c_int32), ("out_lo_off", C.c_int32),
     ]
 
 
@@ -54,7 +55,7 @@ class AttnArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
         ("q_ld", C.c_int64), ("k_ld", C.c_int64), ("vt_ld", C.c_int64), ("o_ld", C.c_int64),
         ("q_bstride", C.c_int64), ("k_bstride", C.c_int64), ("vt_bstride", C.c_int64), ("o_bstride", C.c_int64),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("o_lo_off", C.c_int32),
     ]
 
 
@@ -77,29 +78,30 @@ SIGNATURES = {
     "omgsr_igemm_gn_slots": (C.c_int32, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_entries": (C.c_int32, [C.POINTER(IgemmArgs)]),
     "omgsr_groupnorm_finalize": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, C.c_double, _F, _P]),
-    "omgsr_groupnorm_partial": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
+    "omgsr_groupnorm_partial": (C.c_int, [_P, _P, _I, _L, _I, _I, _I, _P]),
     "omgsr_groupnorm_finalize_merged": (C.c_int, [C.POINTER(GnMergeArgs), _P, _P, _P, _I, _I, _F, _P]),
-    "omgsr_groupnorm_apply_shared": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
-    "omgsr_image_to_model_input": (C.c_int, [_P, _P, _I, _I, _I, _P]),
+    "omgsr_groupnorm_apply_shared": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "omgsr_image_to_model_input": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "omgsr_colorfix_workspace_bytes": (C.c_int64, [_I, _I, _I, _I]),
-    "omgsr_colorfix": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "omgsr_colorfix": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "omgsr_groupnorm_nchunk": (C.c_int, [_L]),
-    "omgsr_groupnorm_stats": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _P]),
-    "omgsr_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P]),
-    "omgsr_layernorm": (C.c_int, [_P, _P, _P, _P, _L, _I, _F, _P]),
+    "omgsr_groupnorm_stats": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P]),
+    "omgsr_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P]),
+    "omgsr_layernorm": (C.c_int, [_P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
+    "omgsr_to_operand": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "omgsr_attention": (C.c_int, [C.POINTER(AttnArgs), _P]),
     "omgsr_softmax_rows": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "omgsr_rmsnorm_rope": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _F, _P]),
-    "omgsr_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "omgsr_nhwc_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
-    "omgsr_copy_channels": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),
-    "omgsr_vae_sample": (C.c_int, [_P, _P, _P, _L, _I, _I, _F, _F, _P]),
-    "omgsr_axpby": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _F, _I, _P]),
-    "omgsr_tile_accumulate": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "omgsr_tile_normalise": (C.c_int, [_P, _P, _P, _I, _L, _I, _I, _P]),
-    "omgsr_crop_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "omgsr_paste_nhwc": (C.c_int, [_P, _P] + [_I] * 12 + [_P]),
-    "omgsr_flux_pack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "omgsr_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "omgsr_nhwc_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
+    "omgsr_copy_channels": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "omgsr_vae_sample": (C.c_int, [_P, _P, _P, _L, _I, _I, _F, _F, _I, _P]),
+    "omgsr_axpby": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _F, _I, _I, _P]),
+    "omgsr_tile_accumulate": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "omgsr_tile_normalise": (C.c_int, [_P, _P, _P, _I, _L, _I, _I, _I, _P]),
+    "omgsr_crop_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "omgsr_paste_nhwc": (C.c_int, [_P, _P] + [_I] * 13 + [_P]),
+    "omgsr_flux_pack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "omgsr_timing_enable": (C.c_int, [C.c_int]),
     "omgsr_timing_reset": (C.c_int, []),
     "omgsr_timing_collect": (C.c_int, [C.POINTER(TimingEntry), C.c_int]),

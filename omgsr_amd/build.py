@@ -46,15 +46,19 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         return out
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libomgsr_hip.so")
-    objs = []
-    for src in SOURCES:
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(src: str) -> str:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:      # one hipcc per translation unit
+        objs = list(pool.map(compile_one, SOURCES))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -23,7 +23,7 @@ def color_fix(sr_nhwc: torch.Tensor, source_u8: Optional[torch.Tensor], method: 
     if method not in METHODS:
         raise ValueError(f"align_method must be one of {sorted(k for k in METHODS if k)}; got {method!r}")
     m = METHODS[method]
-    ops._req(sr_nhwc, ops.act_dtype(), "sr_nhwc")
+    sr_el = ops._el(sr_nhwc, "sr_nhwc")
     B, H, W, ld = sr_nhwc.shape
     if m:
         if source_u8 is None:
@@ -36,7 +36,7 @@ def color_fix(sr_nhwc: torch.Tensor, source_u8: Optional[torch.Tensor], method: 
     need = lib.omgsr_colorfix_workspace_bytes(B, H, W, m)
     ws = torch.empty(max(need, 8), device=sr_nhwc.device, dtype=torch.uint8) if m else None
     check(lib.omgsr_colorfix(sr_nhwc.data_ptr(), ld, ops._ptr(source_u8) if m else None, out.data_ptr(), ops._ptr(ws),
-                             B, H, W, m, ops._stream()), "omgsr_colorfix")
+                             B, H, W, m, sr_el, ops._stream()), "omgsr_colorfix")
     return out
 
 
@@ -49,13 +49,14 @@ def wavelet_color_fix(target_nhwc: torch.Tensor, source_u8: torch.Tensor) -> tor
 
 
 def image_to_model_input(image_u8: torch.Tensor) -> torch.Tensor:
-    """uint8 [B,H,W,3] -> NHWC [B,H,W,8] in the compute dtype: `F.to_tensor(img).to(dtype) * 2 - 1` (infer/infer_omgsr_s.py:92)."""
+    """uint8 [B,H,W,3] -> NHWC stream tensor [B,H,W,8]: `F.to_tensor(img).to(weight_dtype) * 2 - 1` (infer/infer_omgsr_s.py:92)."""
     ops._req(image_u8, torch.uint8, "image_u8")
     B, H, W, c = image_u8.shape
     if c != 3:
         raise ValueError("image_u8 must be [B,H,W,3]")
-    out = torch.empty((B, H, W, 8), device=image_u8.device, dtype=ops.act_dtype())
-    check(_lib.load().omgsr_image_to_model_input(image_u8.data_ptr(), out.data_ptr(), B, H, W, ops._stream()), "omgsr_image_to_model_input")
+    out = torch.empty((B, H, W, 8), device=image_u8.device, dtype=ops.stream_dtype())
+    check(_lib.load().omgsr_image_to_model_input(image_u8.data_ptr(), out.data_ptr(), B, H, W,
+                                                 ops.EL_F32 if out.dtype == torch.float32 else ops.EL_16, ops._stream()), "omgsr_image_to_model_input")
     return out
 
 

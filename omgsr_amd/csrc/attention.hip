@@ -204,14 +204,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     const int qrow = q0 + l31;
     if (qrow < p.Lq) {
         T* op = (T*)p.o + (int64_t)b * p.o_bstride + (int64_t)qrow * p.o_ld + h * D + 4 * half;
+        const int lo_off = p.o_lo_off;       // > 0: the low halves of the two-term split land that many columns later
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                const float v0 = o[db][4 * g] * inv, v1 = o[db][4 * g + 1] * inv, v2 = o[db][4 * g + 2] * inv, v3 = o[db][4 * g + 3] * inv;
                 u32x2_t w;
-                w[0] = pack2<T>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
-                w[1] = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                w[0] = pack2<T>(v0, v1);
+                w[1] = pack2<T>(v2, v3);
                 *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g) = w;
+                if (lo_off > 0) {
+                    const x8_t<T> hv = __builtin_bit_cast(x8_t<T>, (u32x4_t){w[0], w[1], 0u, 0u});
+                    u32x2_t l;
+                    l[0] = pack2<T>(v0 - (float)hv[0], v1 - (float)hv[1]);
+                    l[1] = pack2<T>(v2 - (float)hv[2], v3 - (float)hv[3]);
+                    *reinterpret_cast<u32x2_t*>(op + lo_off + 32 * db + 8 * g) = l;
+                }
             }
     }
 }
@@ -241,6 +250,7 @@ extern "C" int omgsr_attention(const omgsr_attn_args* ap, void* stream) {
     const omgsr_attn_args a = *ap;
     if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return OMGSR_E_BADARG;
     if ((a.q_ld & 7) || (a.k_ld & 7) || (a.vt_ld & 7) || (a.o_ld & 3) || a.vt_ld < a.Lk) return OMGSR_E_SHAPE;
+    if (a.o_lo_off < 0 || (a.o_lo_off && ((a.o_lo_off & 3) || a.o_lo_off < a.H * a.D || a.o_ld < (int64_t)a.o_lo_off + a.H * a.D))) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const double flops = 4.0 * (double)a.B * a.H * (double)a.Lq * a.Lk * a.D;
     const double bytes = 2.0 * (double)a.B * a.H * a.D * (2.0 * a.Lq + 2.0 * a.Lk);

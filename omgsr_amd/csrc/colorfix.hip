@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void cf_wavelet_out_kernel(const float* __rest
 
 // uint8 HWC image -> model input NHWC (8 channels, 5 zero): F.to_tensor(img).to(dtype) * 2 - 1 (infer/infer_omgsr_s.py:92),
 // rounded to the model dtype after the conversion AND after the affine, as torch does op by op
-template <typename T>
-__global__ __launch_bounds__(256) void cf_input_kernel(const unsigned char* __restrict__ img, T* __restrict__ out, int64_t total) {
+template <typename T, int OEL>      // OEL 1: T = float, fp32 stream tensor out (accurate tier)
+__global__ __launch_bounds__(256) void cf_input_kernel(const unsigned char* __restrict__ img, void* __restrict__ out, int64_t total) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
     const unsigned char* s = img + p * 3;
@@ -190,18 +190,21 @@ __global__ __launch_bounds__(256) void cf_input_kernel(const unsigned char* __re
         const float x = (float)(T)__fdiv_rn((float)s[e], 255.0f);
         f[e] = __fsub_rn(x * 2.0f, 1.0f);
     }
-    *reinterpret_cast<u32x4_t*>(out + p * 8) = pack8<T>(f);
+    if constexpr (OEL == 1) store8<bf16_t, 1>(out, p * 8, 0, f);
+    else store8<T, 0>(out, p * 8, 0, f);
 }
 
 int64_t stats_blocks(int64_t HW) { return (HW + CF_PPB - 1) / CF_PPB; }
 
 }  // namespace
 
-extern "C" int omgsr_image_to_model_input(const uint8_t* img_hwc3, void* out_nhwc8, int32_t N, int32_t H, int32_t W, void* stream) {
-    if (!img_hwc3 || !out_nhwc8 || N <= 0 || H <= 0 || W <= 0) return OMGSR_E_BADARG;
+extern "C" int omgsr_image_to_model_input(const uint8_t* img_hwc3, void* out_nhwc8, int32_t N, int32_t H, int32_t W, int32_t out_el,
+                                          void* stream) {
+    if (!img_hwc3 || !out_nhwc8 || N <= 0 || H <= 0 || W <= 0 || (out_el != OMGSR_EL_16 && out_el != OMGSR_EL_F32)) return OMGSR_E_BADARG;
     const int64_t total = (int64_t)N * H * W;
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL(cf_input_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                                        img_hwc3, (T*)out_nhwc8, total));
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (out_el == OMGSR_EL_F32) hipLaunchKernelGGL((cf_input_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, img_hwc3, out_nhwc8, total);
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((cf_input_kernel<T, 0>), grid, dim3(256), 0, (hipStream_t)stream, img_hwc3, out_nhwc8, total));
     return (int)hipGetLastError();
 }
 
@@ -214,8 +217,15 @@ extern "C" int64_t omgsr_colorfix_workspace_bytes(int32_t N, int32_t H, int32_t 
 }
 
 extern "C" int omgsr_colorfix(const void* sr_nhwc, int32_t sr_ld, const uint8_t* src_hwc3, uint8_t* out_hwc3, void* workspace,
-                              int32_t N, int32_t H, int32_t W, int32_t method, void* stream) {
+                              int32_t N, int32_t H, int32_t W, int32_t method, int32_t sr_el, void* stream) {
     if (!sr_nhwc || !out_hwc3 || N <= 0 || H <= 0 || W <= 0 || sr_ld < 3) return OMGSR_E_BADARG;
+    if (sr_el != OMGSR_EL_16 && sr_el != OMGSR_EL_F32) return OMGSR_E_BADARG;
+    // sr_el = OMGSR_EL_F32: the model ran in the accurate tier (--weight_dtype fp32): the "* 0.5 + 0.5" then rounds to fp32
+#define OMGSR_CF_DISPATCH(...)                                              \
+    do {                                                                    \
+        if (sr_el == OMGSR_EL_F32) { using T = float; __VA_ARGS__; }        \
+        else OMGSR_DISPATCH_T(__VA_ARGS__);                                 \
+    } while (0)
     if (method != OMGSR_COLORFIX_NONE && method != OMGSR_COLORFIX_ADAIN && method != OMGSR_COLORFIX_WAVELET) return OMGSR_E_BADARG;
     if (method != OMGSR_COLORFIX_NONE && (!src_hwc3 || !workspace)) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -227,7 +237,7 @@ extern "C" int omgsr_colorfix(const void* sr_nhwc, int32_t sr_ld, const uint8_t*
         float* ping = (float*)workspace;
         float* pong = ping + (int64_t)2 * N * 3 * HW;
         float* high = pong + (int64_t)2 * N * 3 * HW;
-        OMGSR_DISPATCH_T(hipLaunchKernelGGL(cf_planes_kernel<T>, px_grid, dim3(256), 0, st, (const T*)sr_nhwc, sr_ld, src_hwc3, ping, HW, N));
+        OMGSR_CF_DISPATCH(hipLaunchKernelGGL(cf_planes_kernel<T>, px_grid, dim3(256), 0, st, (const T*)sr_nhwc, sr_ld, src_hwc3, ping, HW, N));
         const dim3 lvl_grid((unsigned)((HW + 255) / 256), 2 * N * 3);
         for (int i = 0; i < 5; ++i) {
             hipLaunchKernelGGL(cf_level_kernel, lvl_grid, dim3(256), 0, st, ping, pong, high, H, W, 1 << i, N * 3, i == 0 ? 1 : 0);
@@ -241,9 +251,10 @@ extern "C" int omgsr_colorfix(const void* sr_nhwc, int32_t sr_ld, const uint8_t*
         const int nblk = (int)stats_blocks(HW);
         unsigned long long* partial = (unsigned long long*)workspace;
         stats = (float*)(partial + (int64_t)N * nblk * 12);
-        OMGSR_DISPATCH_T(hipLaunchKernelGGL(cf_stats_kernel<T>, dim3(nblk, N), dim3(256), 0, st, (const T*)sr_nhwc, sr_ld, src_hwc3, partial, HW));
+        OMGSR_CF_DISPATCH(hipLaunchKernelGGL(cf_stats_kernel<T>, dim3(nblk, N), dim3(256), 0, st, (const T*)sr_nhwc, sr_ld, src_hwc3, partial, HW));
         hipLaunchKernelGGL(cf_finalize_kernel, dim3(N), dim3(64), 0, st, partial, stats, nblk, HW);
     }
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL(cf_apply_kernel<T>, px_grid, dim3(256), 0, st, (const T*)sr_nhwc, sr_ld, stats, out_hwc3, HW, method));
+    OMGSR_CF_DISPATCH(hipLaunchKernelGGL(cf_apply_kernel<T>, px_grid, dim3(256), 0, st, (const T*)sr_nhwc, sr_ld, stats, out_hwc3, HW, method));
+#undef OMGSR_CF_DISPATCH
     return (int)hipGetLastError();
 }

@@ -85,6 +85,43 @@ template <typename T> OMGSR_DEVINL u32x4_t pack8(const float (&f)[8]) {
     return v;
 }
 
+// ---- element-kind generic 8-channel access (OMGSR_EL_*: include/omgsr_hip.h) --------------------------------
+// load: 8 consecutive channels as floats from a 16-bit (one 16-byte load) or an fp32 (two 16-byte loads) row
+template <typename T, bool F32> OMGSR_DEVINL void load8(const void* base, const int64_t idx, float (&f)[8]) {
+    if constexpr (F32) {
+        const float* p = reinterpret_cast<const float*>(base) + idx;
+        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(p), hi = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+    } else {
+        unpack8<T>(*reinterpret_cast<const u32x4_t*>(reinterpret_cast<const T*>(base) + idx), f);
+    }
+}
+// the two-term split of 8 values: hi = round(v), lo = round(v - hi), both in the compute type
+template <typename T> OMGSR_DEVINL void split8(const float (&v)[8], u32x4_t& hi, u32x4_t& lo) {
+    hi = pack8<T>(v);
+    float back[8], d[8];
+    unpack8<T>(hi, back);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = v[e] - back[e];
+    lo = pack8<T>(d);
+}
+// store: EL 0 = 16-bit at base[idx]; 1 = fp32 at base[idx]; 2 = split, hi at base[idx], lo at base[idx + lo_off]
+template <typename T, int EL> OMGSR_DEVINL void store8(void* base, const int64_t idx, const int64_t lo_off, const float (&f)[8]) {
+    if constexpr (EL == 1) {
+        float* p = reinterpret_cast<float*>(base) + idx;
+        *reinterpret_cast<f32x4_t*>(p) = (f32x4_t){f[0], f[1], f[2], f[3]};
+        *reinterpret_cast<f32x4_t*>(p + 4) = (f32x4_t){f[4], f[5], f[6], f[7]};
+    } else if constexpr (EL == 2) {
+        u32x4_t hi, lo;
+        split8<T>(f, hi, lo);
+        *reinterpret_cast<u32x4_t*>(reinterpret_cast<T*>(base) + idx) = hi;
+        *reinterpret_cast<u32x4_t*>(reinterpret_cast<T*>(base) + idx + lo_off) = lo;
+    } else {
+        *reinterpret_cast<u32x4_t*>(reinterpret_cast<T*>(base) + idx) = pack8<T>(f);
+    }
+}
+
 // x * sigmoid(x); v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
 OMGSR_DEVINL float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact (erf) GELU. erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the 16-bit output step): one

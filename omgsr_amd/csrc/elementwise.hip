@@ -15,9 +15,9 @@ namespace {
 
 template <typename T> OMGSR_DEVINL float round_to(float x) { return (float)(T)x; }
 
-// NCHW -> NHWC(Cpad) bf16. One thread per output pixel-channel-group of 8.
-template <typename SRC, typename T>
-__global__ void nchw_to_nhwc_kernel(const SRC* __restrict__ src, T* __restrict__ dst, int N, int C, int64_t HW, int Cpad) {
+// NCHW -> NHWC(Cpad), 16-bit or fp32 (DEL). One thread per output pixel-channel-group of 8.
+template <typename SRC, typename T, int DEL>
+__global__ void nchw_to_nhwc_kernel(const SRC* __restrict__ src, void* __restrict__ dst, int N, int C, int64_t HW, int Cpad) {
     const int ng = Cpad >> 3;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)N * HW * ng;
@@ -32,11 +32,11 @@ __global__ void nchw_to_nhwc_kernel(const SRC* __restrict__ src, T* __restrict__
         const int c = g * 8 + e;
         f[e] = (c < C) ? (float)src[((int64_t)n * C + c) * HW + hw] : 0.0f;
     }
-    *reinterpret_cast<u32x4_t*>(dst + pix * Cpad + g * 8) = pack8<T>(f);
+    store8<T, DEL>(dst, pix * Cpad + g * 8, 0, f);
 }
 
-// NHWC(ld) bf16 -> NCHW. Thread per (n, c, hw) element; hw fastest => coalesced writes.
-template <typename DST, typename T>
+// NHWC(ld) 16-bit or fp32 -> NCHW. Thread per (n, c, hw) element; hw fastest => coalesced writes.
+template <typename DST, typename T>      // T: the source element type (compute type or float)
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, DST* __restrict__ dst, int N, int C, int64_t HW, int ld,
                                     int do_clamp, float lo, float hi) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,19 +51,31 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, DST* __restrict__
     dst[i] = (DST)v;
 }
 
-__global__ void copy_channels_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int C, int src_ld,
+// all extents in 16-byte chunks (8 x 16-bit or 4 x fp32 channels)
+__global__ void copy_channels_kernel(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, int64_t rows, int ng, int src_ld,
                                      int dst_ld, int dst_off) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ng) return;
+    const int g = (int)(i % ng);
+    const int64_t r = i / ng;
+    dst[r * dst_ld + dst_off + g] = src[r * src_ld + g];
+}
+
+// stream (fp32) -> operand (compute type, plain or two-term split [hi | lo])
+template <typename T, int YEL>
+__global__ void to_operand_kernel(const float* __restrict__ x, void* __restrict__ y, int64_t rows, int C) {
     const int ng = C >> 3;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * ng) return;
     const int g = (int)(i % ng);
     const int64_t r = i / ng;
-    *reinterpret_cast<u32x4_t*>(dst + r * dst_ld + dst_off + g * 8) =
-        *reinterpret_cast<const u32x4_t*>(src + r * src_ld + g * 8);
+    float f[8];
+    load8<T, true>(x, r * C + g * 8, f);
+    store8<T, YEL>(y, r * (YEL == 2 ? 2 * C : C) + g * 8, C, f);
 }
 
 // z = ((mu + exp(0.5*clamp(logvar,-30,20)) * eps) - shift) * scale, fp32 math, one rounding.
-template <typename T>
+template <typename T>      // T: compute type or float (moments and z share it)
 __global__ void vae_sample_kernel(const T* __restrict__ mom, const float* __restrict__ eps, T* __restrict__ z, int64_t rows,
                                   int C, int ld_out, float shift, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,7 +129,7 @@ __global__ void tile_accumulate_kernel(const T* __restrict__ tile, const float* 
     acc[(((int64_t)n * H + y0 + y) * W + x0 + x) * C + c] += tv * wv;
 }
 
-template <typename T>
+template <typename T>      // T: compute type or float
 __global__ void tile_normalise_kernel(const float* __restrict__ acc, const float* __restrict__ wsum, T* __restrict__ out, int N,
                                       int64_t HW, int C, int ld) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,9 +141,8 @@ __global__ void tile_normalise_kernel(const float* __restrict__ acc, const float
     out[i] = (T)v;
 }
 
-__global__ void crop_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int H, int W, int C, int y0, int x0, int th,
+__global__ void crop_kernel(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, int N, int H, int W, int ng, int y0, int x0, int th,
                             int tw) {
-    const int ng = C >> 3;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * th * tw * ng) return;
     const int g = (int)(i % ng);
@@ -139,13 +150,11 @@ __global__ void crop_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__
     const int x = (int)(r % tw); r /= tw;
     const int y = (int)(r % th);
     const int n = (int)(r / th);
-    *reinterpret_cast<u32x4_t*>(dst + i * 8) =
-        *reinterpret_cast<const u32x4_t*>(src + (((int64_t)n * H + y0 + y) * W + x0 + x) * C + g * 8);
+    dst[i] = src[(((int64_t)n * H + y0 + y) * W + x0 + x) * ng + g];
 }
 
-__global__ void paste_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int C, int sH, int sW, int sy0, int sx0,
+__global__ void paste_kernel(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, int N, int ng, int sH, int sW, int sy0, int sx0,
                              int dH, int dW, int dy0, int dx0, int th, int tw) {
-    const int ng = C >> 3;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * th * tw * ng) return;
     const int g = (int)(i % ng);
@@ -153,12 +162,12 @@ __global__ void paste_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict_
     const int x = (int)(r % tw); r /= tw;
     const int y = (int)(r % th);
     const int n = (int)(r / th);
-    *reinterpret_cast<u32x4_t*>(dst + (((int64_t)n * dH + dy0 + y) * dW + dx0 + x) * C + g * 8) =
-        *reinterpret_cast<const u32x4_t*>(src + (((int64_t)n * sH + sy0 + y) * sW + sx0 + x) * C + g * 8);
+    dst[(((int64_t)n * dH + dy0 + y) * dW + dx0 + x) * ng + g] = src[(((int64_t)n * sH + sy0 + y) * sW + sx0 + x) * ng + g];
 }
 
 // Flux 2x2 pack: tokens[n, (y/2)*(W/2) + x/2, c*4 + (y&1)*2 + (x&1)] <-> nhwc[n, y, x, c]
-__global__ void flux_pack_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int H, int W, int C, int ld, int dir) {
+template <typename E>       // E: any 2- or 4-byte element (pure data movement)
+__global__ void flux_pack_kernel(const E* __restrict__ src, E* __restrict__ dst, int N, int H, int W, int C, int ld, int dir) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * H * W * C) return;
     const int c = (int)(i % C);
@@ -175,7 +184,7 @@ inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)((tot
 
 }  // namespace
 
-extern "C" int omgsr_abi_version(void) { return 10; }
+extern "C" int omgsr_abi_version(void) { return 11; }
 
 extern "C" int omgsr_set_compute_dtype(int dtype) {
     if (dtype != OMGSR_DT_BF16 && dtype != OMGSR_DT_F16) return OMGSR_E_BADARG;
@@ -203,108 +212,133 @@ extern "C" const char* omgsr_error_string(int code) {
 }
 
 extern "C" int omgsr_nchw_to_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad,
-                                  int32_t src_dtype, void* stream) {
+                                  int32_t src_dtype, int32_t dst_el, void* stream) {
     if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0) return OMGSR_E_BADARG;
     if ((Cpad & 7) || Cpad < C) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t HW = (int64_t)H * W, total = (int64_t)N * HW * (Cpad >> 3);
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 2.0 * N * HW * (C + Cpad), st);
-    if (src_dtype == 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, T>), grid1d(total), dim3(256), 0, st, (const float*)src, (T*)dst, N, C, HW, Cpad));
-    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((nchw_to_nhwc_kernel<T, T>), grid1d(total), dim3(256), 0, st, (const T*)src, (T*)dst, N, C, HW, Cpad));
+    if (dst_el != OMGSR_EL_16 && dst_el != OMGSR_EL_F32) return OMGSR_E_BADARG;
+    if (src_dtype == 1 && dst_el == OMGSR_EL_F32) OMGSR_DISPATCH_T(hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, T, 1>), grid1d(total), dim3(256), 0, st, (const float*)src, dst, N, C, HW, Cpad));
+    else if (src_dtype == 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, T, 0>), grid1d(total), dim3(256), 0, st, (const float*)src, dst, N, C, HW, Cpad));
+    else if (dst_el == OMGSR_EL_F32) OMGSR_DISPATCH_T(hipLaunchKernelGGL((nchw_to_nhwc_kernel<T, T, 1>), grid1d(total), dim3(256), 0, st, (const T*)src, dst, N, C, HW, Cpad));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((nchw_to_nhwc_kernel<T, T, 0>), grid1d(total), dim3(256), 0, st, (const T*)src, dst, N, C, HW, Cpad));
     return (int)hipGetLastError();
 }
 
 extern "C" int omgsr_nhwc_to_nchw(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ld,
-                                  int32_t dst_dtype, int32_t do_clamp, float lo, float hi, void* stream) {
+                                  int32_t dst_dtype, int32_t do_clamp, float lo, float hi, int32_t src_el, void* stream) {
     if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int64_t HW = (int64_t)H * W, total = (int64_t)N * C * HW;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 4.0 * total, st);
-    if (dst_dtype == 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, T>), grid1d(total), dim3(256), 0, st, (const T*)src, (float*)dst, N, C, HW, ld, do_clamp, lo, hi));
+    if (src_el == OMGSR_EL_F32) {
+        if (dst_dtype == 1) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, float>), grid1d(total), dim3(256), 0, st, (const float*)src, (float*)dst, N, C, HW, ld, do_clamp, lo, hi);
+        else OMGSR_DISPATCH_T(hipLaunchKernelGGL((nhwc_to_nchw_kernel<T, float>), grid1d(total), dim3(256), 0, st, (const float*)src, (T*)dst, N, C, HW, ld, do_clamp, lo, hi));
+    } else if (dst_dtype == 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, T>), grid1d(total), dim3(256), 0, st, (const T*)src, (float*)dst, N, C, HW, ld, do_clamp, lo, hi));
     else OMGSR_DISPATCH_T(hipLaunchKernelGGL((nhwc_to_nchw_kernel<T, T>), grid1d(total), dim3(256), 0, st, (const T*)src, (T*)dst, N, C, HW, ld, do_clamp, lo, hi));
     return (int)hipGetLastError();
 }
 
 extern "C" int omgsr_copy_channels(const void* src, void* dst, int64_t rows, int32_t C, int32_t src_ld, int32_t dst_ld,
-                                   int32_t dst_off, void* stream) {
-    if (!src || !dst || rows <= 0 || C <= 0) return OMGSR_E_BADARG;
+                                   int32_t dst_off, int32_t el, void* stream) {
+    if (!src || !dst || rows <= 0 || C <= 0 || (el != OMGSR_EL_16 && el != OMGSR_EL_F32)) return OMGSR_E_BADARG;
     if ((C & 7) || (src_ld & 7) || (dst_ld & 7) || (dst_off & 7) || dst_off + C > dst_ld || src_ld < C) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 4.0 * rows * C, st);
-    hipLaunchKernelGGL(copy_channels_kernel, grid1d(rows * (C >> 3)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, C, src_ld, dst_ld, dst_off);
+    const int sh = el == OMGSR_EL_F32 ? 2 : 3;          // channels per 16-byte chunk: 4 (fp32) or 8 (16-bit)
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, (el == OMGSR_EL_F32 ? 8.0 : 4.0) * rows * C, st);
+    hipLaunchKernelGGL(copy_channels_kernel, grid1d(rows * (C >> sh)), dim3(256), 0, st, (const u32x4_t*)src, (u32x4_t*)dst, rows, C >> sh,
+                       src_ld >> sh, dst_ld >> sh, dst_off >> sh);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_to_operand(const float* x, void* y, int64_t rows, int32_t C, int32_t y_el, void* stream) {
+    if (!x || !y || rows <= 0 || C <= 0 || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT)) return OMGSR_E_BADARG;
+    if (C & 7) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, (y_el == OMGSR_EL_SPLIT ? 8.0 : 6.0) * rows * C, st);
+    if (y_el == OMGSR_EL_SPLIT) OMGSR_DISPATCH_T(hipLaunchKernelGGL((to_operand_kernel<T, 2>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((to_operand_kernel<T, 0>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C));
     return (int)hipGetLastError();
 }
 
 extern "C" int omgsr_vae_sample(const void* moments, const float* eps, void* z, int64_t rows, int32_t C, int32_t ld_out,
-                                float shift, float scale, void* stream) {
+                                float shift, float scale, int32_t el, void* stream) {
     if (!moments || !eps || !z || rows <= 0 || C <= 0 || ld_out < C) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 10.0 * rows * C, st);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL(vae_sample_kernel<T>, grid1d(rows * ld_out), dim3(256), 0, st, (const T*)moments, eps, (T*)z, rows, C, ld_out, shift, scale));
+    if (el == OMGSR_EL_F32) hipLaunchKernelGGL(vae_sample_kernel<float>, grid1d(rows * ld_out), dim3(256), 0, st, (const float*)moments, eps, (float*)z, rows, C, ld_out, shift, scale);
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL(vae_sample_kernel<T>, grid1d(rows * ld_out), dim3(256), 0, st, (const T*)moments, eps, (T*)z, rows, C, ld_out, shift, scale));
     return (int)hipGetLastError();
 }
 
 extern "C" int omgsr_axpby(const void* x, const void* y, void* out, int64_t n, float a, float b, float c, float d,
-                           int32_t bf16_steps, void* stream) {
+                           int32_t bf16_steps, int32_t el, void* stream) {
     if (!x || !out || n <= 0) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 6.0 * n, st);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL(axpby_kernel<T>, grid1d(n), dim3(256), 0, st, (const T*)x, (const T*)y, (T*)out, n, a, b, c, d, bf16_steps));
+    if (el == OMGSR_EL_F32) hipLaunchKernelGGL(axpby_kernel<float>, grid1d(n), dim3(256), 0, st, (const float*)x, (const float*)y, (float*)out, n, a, b, c, d, 0);
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL(axpby_kernel<T>, grid1d(n), dim3(256), 0, st, (const T*)x, (const T*)y, (T*)out, n, a, b, c, d, bf16_steps));
     return (int)hipGetLastError();
 }
 
 extern "C" int omgsr_tile_accumulate(const void* tile, const float* w, float* acc, int32_t N, int32_t C, int32_t th, int32_t tw,
-                                     int32_t tile_ld, int32_t H, int32_t W, int32_t y0, int32_t x0, void* stream) {
+                                     int32_t tile_ld, int32_t H, int32_t W, int32_t y0, int32_t x0, int32_t tile_el, void* stream) {
     if (!w || !acc || N <= 0 || C <= 0 || th <= 0 || tw <= 0) return OMGSR_E_BADARG;
     if (y0 < 0 || x0 < 0 || y0 + th > H || x0 + tw > W || (tile && tile_ld < C)) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)N * th * tw * C;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 10.0 * total, st);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL(tile_accumulate_kernel<T>, grid1d(total), dim3(256), 0, st, (const T*)tile, w, acc, N, C, th, tw, tile_ld, H, W, y0, x0));
+    if (tile_el == OMGSR_EL_F32) hipLaunchKernelGGL(tile_accumulate_kernel<float>, grid1d(total), dim3(256), 0, st, (const float*)tile, w, acc, N, C, th, tw, tile_ld, H, W, y0, x0);
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL(tile_accumulate_kernel<T>, grid1d(total), dim3(256), 0, st, (const T*)tile, w, acc, N, C, th, tw, tile_ld, H, W, y0, x0));
     return (int)hipGetLastError();
 }
 
 extern "C" int omgsr_tile_normalise(const float* acc, const float* wsum, void* out, int32_t N, int64_t HW, int32_t C, int32_t ld,
-                                    void* stream) {
+                                    int32_t out_el, void* stream) {
     if (!acc || !wsum || !out || N <= 0 || HW <= 0 || C <= 0 || ld < C) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)N * HW * ld;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 6.0 * total, st);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL(tile_normalise_kernel<T>, grid1d(total), dim3(256), 0, st, acc, wsum, (T*)out, N, HW, C, ld));
+    if (out_el == OMGSR_EL_F32) hipLaunchKernelGGL(tile_normalise_kernel<float>, grid1d(total), dim3(256), 0, st, acc, wsum, (float*)out, N, HW, C, ld);
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL(tile_normalise_kernel<T>, grid1d(total), dim3(256), 0, st, acc, wsum, (T*)out, N, HW, C, ld));
     return (int)hipGetLastError();
 }
 
 extern "C" int omgsr_crop_nhwc(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t y0, int32_t x0,
-                               int32_t th, int32_t tw, void* stream) {
+                               int32_t th, int32_t tw, int32_t el, void* stream) {
     if (!src || !dst || N <= 0 || C <= 0 || th <= 0 || tw <= 0) return OMGSR_E_BADARG;
     if ((C & 7) || y0 < 0 || x0 < 0 || y0 + th > H || x0 + tw > W) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total = (int64_t)N * th * tw * (C >> 3);
+    const int ng = el == OMGSR_EL_F32 ? C >> 2 : C >> 3;          // 16-byte chunks per pixel
+    const int64_t total = (int64_t)N * th * tw * ng;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 32.0 * total, st);
-    hipLaunchKernelGGL(crop_kernel, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, H, W, C, y0, x0, th, tw);
+    hipLaunchKernelGGL(crop_kernel, grid1d(total), dim3(256), 0, st, (const u32x4_t*)src, (u32x4_t*)dst, N, H, W, ng, y0, x0, th, tw);
     return (int)hipGetLastError();
 }
 
 extern "C" int omgsr_paste_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t sH, int32_t sW, int32_t sy0, int32_t sx0,
-                                int32_t dH, int32_t dW, int32_t dy0, int32_t dx0, int32_t th, int32_t tw, void* stream) {
+                                int32_t dH, int32_t dW, int32_t dy0, int32_t dx0, int32_t th, int32_t tw, int32_t el, void* stream) {
     if (!src || !dst || N <= 0 || C <= 0 || th <= 0 || tw <= 0) return OMGSR_E_BADARG;
     if ((C & 7) || sy0 < 0 || sx0 < 0 || dy0 < 0 || dx0 < 0 || sy0 + th > sH || sx0 + tw > sW || dy0 + th > dH || dx0 + tw > dW)
         return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total = (int64_t)N * th * tw * (C >> 3);
+    const int ng = el == OMGSR_EL_F32 ? C >> 2 : C >> 3;
+    const int64_t total = (int64_t)N * th * tw * ng;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 32.0 * total, st);
-    hipLaunchKernelGGL(paste_kernel, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, C, sH, sW, sy0, sx0, dH, dW, dy0, dx0, th, tw);
+    hipLaunchKernelGGL(paste_kernel, grid1d(total), dim3(256), 0, st, (const u32x4_t*)src, (u32x4_t*)dst, N, ng, sH, sW, sy0, sx0, dH, dW, dy0, dx0, th, tw);
     return (int)hipGetLastError();
 }
 
 extern "C" int omgsr_flux_pack(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ld, int32_t dir,
-                               void* stream) {
+                               int32_t el, void* stream) {
     if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return OMGSR_E_BADARG;
     if ((H & 1) || (W & 1)) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)N * H * W * C;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 4.0 * total, st);
-    hipLaunchKernelGGL(flux_pack_kernel, grid1d(total), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, H, W, C, ld, dir);
+    if (el == OMGSR_EL_F32) hipLaunchKernelGGL(flux_pack_kernel<float>, grid1d(total), dim3(256), 0, st, (const float*)src, (float*)dst, N, H, W, C, ld, dir);
+    else hipLaunchKernelGGL(flux_pack_kernel<unsigned short>, grid1d(total), dim3(256), 0, st, (const unsigned short*)src, (unsigned short*)dst, N, H, W, C, ld, dir);
     return (int)hipGetLastError();
 }
 

@@ -226,9 +226,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
     for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
         float x = v[e];
         if (p.gate) x *= p.gate[n + e];
-        if (p.residual) x += (float)((const T*)p.residual)[(int64_t)m * p.Cout + n + e];
-        if (p.out_dtype == OMGSR_OUT_BF16) ((T*)p.out)[(int64_t)m * ldo + n + e] = (T)x;
-        else ((float*)p.out)[(int64_t)m * ldo + n + e] = x;
+        if (p.residual) x += p.res_el == OMGSR_EL_F32 ? ((const float*)p.residual)[(int64_t)m * p.Cout + n + e]
+                                                       : (float)((const T*)p.residual)[(int64_t)m * p.Cout + n + e];
+        if (p.out_dtype == OMGSR_OUT_BF16) {
+            const T hi = (T)x;
+            ((T*)p.out)[(int64_t)m * ldo + n + e] = hi;
+            if (p.out_lo_off > 0) ((T*)p.out)[(int64_t)m * ldo + p.out_lo_off + n + e] = (T)(x - (float)hi);
+        } else ((float*)p.out)[(int64_t)m * ldo + n + e] = x;
     }
 }
 
@@ -330,6 +334,11 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     if (a.act == OMGSR_ACT_GEGLU && ((a.Cout & 31) || a.out_layout != OMGSR_LAYOUT_NHWC)) return OMGSR_E_SHAPE;
     if (a.out_layout == OMGSR_LAYOUT_T && (a.t_rows <= 0 || a.t_ld < a.t_rows || a.residual)) return OMGSR_E_BADARG;
     if (a.out_ld != 0 && (a.out_ld < a.Cout || a.out_layout != OMGSR_LAYOUT_NHWC)) return OMGSR_E_BADARG;
+    if (a.res_el != OMGSR_EL_16 && a.res_el != OMGSR_EL_F32) return OMGSR_E_BADARG;
+    if (a.out_lo_off < 0) return OMGSR_E_BADARG;
+    if (a.out_lo_off && (a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cout & 7) || (a.out_ld & 7) || (a.out_lo_off & 7) ||
+                         a.out_lo_off < a.Cout || a.out_ld < a.out_lo_off + a.Cout || a.gn_partial)) return OMGSR_E_SHAPE;
+    if (a.in_split && (a.Cin & 15)) return OMGSR_E_SHAPE;
     Geo g;
     g.M = (int)M64;
     g.HoWo = a.Ho * a.Wo;
@@ -337,9 +346,11 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     g.Wv = a.W << a.upsample;
     g.nk = a.K_pad / BK;
     hipStream_t st = (hipStream_t)stream;
-    const double flops = 2.0 * (double)M64 * (double)a.R * a.S * a.Cin * (double)logical_cols * a.batch;
-    const double bytes = 2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.Cout_pad * a.K_pad +
-                                (double)M64 * a.Cout * (a.residual ? 2 : 1)) * a.batch;
+    // algorithmic work: a split operand's duplicated channels are precision overhead, not useful FLOPs
+    const int cin_logical = a.in_split ? a.Cin / 2 : a.Cin;
+    const double flops = 2.0 * (double)M64 * (double)a.R * a.S * cin_logical * (double)logical_cols * a.batch;
+    const double out_b = (a.out_dtype == OMGSR_OUT_F32 ? 4.0 : (a.out_lo_off ? 4.0 : 2.0)), res_b = a.residual ? (a.res_el == OMGSR_EL_F32 ? 4.0 : 2.0) : 0.0;
+    const double bytes = (2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.Cout_pad * a.K_pad) + (double)M64 * a.Cout * (out_b + res_b)) * a.batch;
     omgsr::TimingScope ts(OMGSR_TK_IGEMM, flops, bytes, st, M64 * a.batch, logical_cols, (long long)a.R * a.S * a.Cin);
     // Tile choice: the 128x128 tile is the MFMA-efficient default; narrow outputs use 128x32 so
     // padded columns do not burn MFMA cycles; small problems drop to 64x64 to fill the 256 CUs.

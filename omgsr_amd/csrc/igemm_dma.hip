@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_i
         const int ldw = g.ntn * BN;
         q.out = (float*)p.workspace + (int64_t)blockIdx.y * g.M * ldw;
         q.out_dtype = OMGSR_OUT_F32; q.out_layout = OMGSR_LAYOUT_NHWC; q.out_ld = ldw; q.Cout = ldw;
-        q.bias = nullptr; q.gate = nullptr; q.residual = nullptr; q.act = OMGSR_ACT_NONE; q.alpha = 1.0f; q.gn_partial = nullptr;
+        q.bias = nullptr; q.gate = nullptr; q.residual = nullptr; q.act = OMGSR_ACT_NONE; q.alpha = 1.0f; q.gn_partial = nullptr; q.out_lo_off = 0;
         igemm_epilogue_linear<T, WTN, FM, FN>(q, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, 0);
         return;
     }

@@ -12,16 +12,18 @@
 #pragma once
 #include "common.hip.h"
 #include "../../include/omgsr_hip.h"
+#include <type_traits>
 
 OMGSR_DEVINL void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // epi: this wave's private LDS region of 32 x (WTN + 4) floats. Fragment row-block i covers output rows
 // (pixels) mb[i] .. mb[i] + nvalid[i] - 1; n_base: first PACKED column of the wave tile (GEGLU: packed
 // [32 a | 32 g] per 64). Must be called by every wave of the block.
-template <typename T, int WTN, int FM, int FN>
-OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
-                                 const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
-                                 float* gn_dst = nullptr, const int gn_howo = 0) {
+// RES32: the residual is an fp32 stream tensor (accurate tier) instead of the 16-bit compute type.
+template <typename T, int WTN, int FM, int FN, bool RES32>
+OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
+                                      const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
+                                      float* gn_dst, const int gn_howo) {
     constexpr int EPI_LD = WTN + 4;
     static_assert(WTN == FN * 32, "wave tile width");
     const int half = lane >> 5, px = lane & 31;
@@ -32,8 +34,10 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
     const int lrow = lane / lanes_per_row, lcol = (lane % lanes_per_row) * 8;
     T* outb = (T*)p.out + (int64_t)bz * p.out_bstride;
     float* outf = (float*)p.out + (int64_t)bz * p.out_bstride;
-    const T* resb = p.residual ? (const T*)p.residual + (int64_t)bz * p.out_bstride : nullptr;
+    typedef typename std::conditional<RES32, float, T>::type res_t;
+    const res_t* resb = p.residual ? (const res_t*)p.residual + (int64_t)bz * p.out_bstride : nullptr;
     const int64_t ldo = p.out_ld > 0 ? p.out_ld : p.Cout;
+    const bool osplit = p.out_lo_off > 0 && p.out_dtype == OMGSR_OUT_BF16;        // two-term split: lo out_lo_off columns after hi
     const bool vec_ok = (p.Cout & 7) == 0 && (ldo & 7) == 0;
 
     // a lane's output columns are the same for every row pass: fetch bias / gate ONCE (per-pass scalar
@@ -73,19 +77,26 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
             constexpr int NPASS_MAX = 32 / (64 / (EPI_CPR / 8));           // non-GEGLU passes per row block
             const int npass = 32 / rows_per_pass;                          // GEGLU: half as many lanes per row -> 2x rows per pass
             // two row blocks of residual in flight (32 VGPRs): block i + 2 is requested as soon as block i is stored
-            u32x4_t res[2][NPASS_MAX];
-            auto load_res = [&](const int i, u32x4_t (&dst)[NPASS_MAX]) {
+            constexpr int RV = RES32 ? 2 : 1;                              // 16-byte pieces per 8 residual values
+            constexpr int NB = RES32 ? 1 : 2;                              // row blocks of residual in flight: 32 VGPRs either way (the halo
+                                                                           // kernel has no more to give: 238 of its 256 are live here)
+            u32x4_t res[NB][NPASS_MAX][RV];
+            auto load_res = [&](const int i, u32x4_t (&dst)[NPASS_MAX][RV]) {
 #pragma unroll
                 for (int ps = 0; ps < NPASS_MAX; ++ps) {
                     const int row = ps * rows_per_pass + lrow;
-                    dst[ps] = (u32x4_t){0u, 0u, 0u, 0u};
-                    if (ps < npass && row < nvalid[i] && col_ok)
-                        dst[ps] = *reinterpret_cast<const u32x4_t*>(resb + (int64_t)(mb[i] + row) * p.Cout + n_out);
+#pragma unroll
+                    for (int w = 0; w < RV; ++w) dst[ps][w] = (u32x4_t){0u, 0u, 0u, 0u};
+                    if (ps < npass && row < nvalid[i] && col_ok) {
+                        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(resb + (int64_t)(mb[i] + row) * p.Cout + n_out);
+#pragma unroll
+                        for (int w = 0; w < RV; ++w) dst[ps][w] = src[w];
+                    }
                 }
             };
             if (resb) {
                 load_res(0, res[0]);
-                if constexpr (FM > 1) load_res(1, res[1]);
+                if constexpr (FM > 1 && NB > 1) load_res(1, res[NB - 1]);
             }
             // Fused GroupNorm statistics: (sum, sum of squares) of the values this wave stores, kept per channel of the
             // lane's octet while rows stream by, then folded over the rows with a fixed butterfly (deterministic) and
@@ -174,7 +185,12 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                     }
                     if (resb) {
                         float rf[8];
-                        unpack8<T>(res[i & 1][ps], rf);
+                        if constexpr (RES32) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { rf[e] = __uint_as_float(res[i % NB][ps][0][e]); rf[4 + e] = __uint_as_float(res[i % NB][ps][RV - 1][e]); }
+                        } else {
+                            unpack8<T>(res[i % NB][ps][0], rf);
+                        }
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rf[e];
                     }
@@ -184,7 +200,12 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
 #pragma unroll
                             for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
                         }
-                        if (p.out_dtype == OMGSR_OUT_BF16) {
+                        if (osplit) {
+                            u32x4_t hi, lo;
+                            split8<T>(v, hi, lo);
+                            *reinterpret_cast<u32x4_t*>(outb + o) = hi;
+                            *reinterpret_cast<u32x4_t*>(outb + o + p.out_lo_off) = lo;
+                        } else if (p.out_dtype == OMGSR_OUT_BF16) {
                             *reinterpret_cast<u32x4_t*>(outb + o) = pack8<T>(v);
                         } else {
                             *reinterpret_cast<f32x4_t*>(outf + o) = (f32x4_t){v[0], v[1], v[2], v[3]};
@@ -192,7 +213,7 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                         }
                     }
                 }
-                if (resb && i + 2 < FM) load_res(i + 2, res[i & 1]);
+                if (resb && i + NB < FM) load_res(i + NB, res[i % NB]);
                 if (gn_howo > 0 && nvalid[i] > 0) {        // one slot per 32-row block (wave-uniform condition)
                     const int img = mb[i] / gn_howo;
                     const int slot = (mb[i] - img * gn_howo) >> 5;
@@ -255,7 +276,7 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
                 if (vec_ok) {
                     if (resb) {
                         float rf[8];
-                        unpack8<T>(*reinterpret_cast<const u32x4_t*>(resb + ro), rf);
+                        load8<T, RES32>(resb, ro, rf);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rf[e];
                     }
@@ -282,6 +303,14 @@ OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][
         }
         wave_lds_fence();       // this wave's reads are done before the next row block overwrites the region
     }
+}
+
+template <typename T, int WTN, int FM, int FN>
+OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
+                                 const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
+                                 float* gn_dst = nullptr, const int gn_howo = 0) {
+    if (p.res_el == OMGSR_EL_F32 && p.residual) igemm_epilogue_impl<T, WTN, FM, FN, true>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo);
+    else igemm_epilogue_impl<T, WTN, FM, FN, false>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo);
 }
 
 // linear-M helper for the GEMM-shaped kernels: row block i starts at m_base + 32*i

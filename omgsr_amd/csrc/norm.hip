@@ -12,8 +12,8 @@ constexpr int GN_PPC = 256;   // pixels per statistics chunk (1024 measured 30 %
 // ---------------------------------------------------------------------------------------------
 // GroupNorm statistics, pass 1: per (image, pixel-chunk) partial (sum, sumsq) per group.
 // x [N][HW][C] bf16.  grid = (nchunk, N), 256 threads.  LDS: 2*C floats.
-template <typename T>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
+template <typename T, bool XF32>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const void* __restrict__ x, float* __restrict__ partial,
                                                           int64_t HW, int C, int G, int nchunk) {
     // LDS: csum[P][C], csq[P][C] — one slot per (pixel lane, channel), reduced in a FIXED order
     // afterwards (no atomics: results are bitwise reproducible and independent of the batch size)
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     const int npx = (int)((HW - p0) < GN_PPC ? (HW - p0) : GN_PPC);
     if (t < TP * P) {
         const int pl = t / TP;
-        const T* base = x + ((int64_t)n * HW + p0) * C;
+        const int64_t base = ((int64_t)n * HW + p0) * C;
         for (int c8 = t % TP; c8 < nch8; c8 += TP) {
             float s[8], q[8];
 #pragma unroll
@@ -37,20 +37,18 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
             // 4 independent 16-byte loads in flight per thread (the 1-deep loop was latency-bound)
             int px = pl;
             for (; px + 3 * P < npx; px += 4 * P) {
-                u32x4_t r[4];
+                float r[4][8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const u32x4_t*>(base + (int64_t)(px + u * P) * C + c8 * 8);
+                for (int u = 0; u < 4; ++u) load8<T, XF32>(x, base + (int64_t)(px + u * P) * C + c8 * 8, r[u]);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    float f[8];
-                    unpack8<T>(r[u], f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+                    for (int e = 0; e < 8; ++e) { s[e] += r[u][e]; q[e] += r[u][e] * r[u][e]; }
                 }
             }
             for (; px < npx; px += P) {
                 float f[8];
-                unpack8<T>(*reinterpret_cast<const u32x4_t*>(base + (int64_t)px * C + c8 * 8), f);
+                load8<T, XF32>(x, base + (int64_t)px * C + c8 * 8, f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
             }
@@ -163,6 +161,54 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// The same for the accurate tier's element kinds: fp32 stream input (XF32) and / or a two-term split operand output
+// (YEL = OMGSR_EL_SPLIT: hi at channel c, lo at channel C + c of a 2C-wide row). Chunk i of the block is (pixel, octet) =
+// (i / nch8, i % nch8), tracked incrementally.
+template <typename T, bool XF32, int YEL>
+__global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int64_t HW, int C, int G, int act, int64_t px_per_block, int stat_rows) {
+    extern __shared__ __attribute__((aligned(16))) float gn_lds[];
+    float* sc = gn_lds;
+    float* sh = gn_lds + C;
+    const int t = threadIdx.x, n = blockIdx.y;
+    const int ns = n % stat_rows;
+    const int cpg = C / G;
+    for (int c = t; c < C; c += 256) {
+        const int g = c / cpg;
+        const float r = rstd[ns * G + g], m = mean[ns * G + g];
+        const float a = r * (gamma ? gamma[c] : 1.0f);
+        sc[c] = a;
+        sh[c] = (beta ? beta[c] : 0.0f) - m * a;
+    }
+    __syncthreads();
+    const int nch8 = C >> 3;
+    const int64_t p0 = (int64_t)blockIdx.x * px_per_block;
+    int64_t p1 = p0 + px_per_block; if (p1 > HW) p1 = HW;
+    const int total = (int)((p1 - p0) * nch8);
+    const int64_t pix0 = (int64_t)n * HW + p0;
+    const int step8 = 256 % nch8, stepp = 256 / nch8;
+    const int ldy = YEL == 2 ? 2 * C : C;
+    int c8 = t % nch8, px = t / nch8;
+#pragma unroll 2
+    for (int i = t; i < total; i += 256) {
+        float f[8];
+        load8<T, XF32>(x, (pix0 + px) * C + c8 * 8, f);
+        const f32x4_t* sa = reinterpret_cast<const f32x4_t*>(sc + c8 * 8);
+        const f32x4_t* ha = reinterpret_cast<const f32x4_t*>(sh + c8 * 8);
+        const f32x4_t sa0 = sa[0], sa1 = sa[1], ha0 = ha[0], ha1 = ha[1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = f[e] * (e < 4 ? sa0[e & 3] : sa1[e & 3]) + (e < 4 ? ha0[e & 3] : ha1[e & 3]);
+            f[e] = (act == OMGSR_ACT_SILU) ? silu_f(v) : v;
+        }
+        store8<T, YEL>(y, (pix0 + px) * ldy + c8 * 8, C, f);
+        c8 += step8; px += stepp;
+        if (c8 >= nch8) { c8 -= nch8; ++px; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 OMGSR_DEVINL void load_affine8(const float* __restrict__ v, const int c, const float dflt, float (&o)[8]) {
     if (v) {
@@ -179,8 +225,8 @@ OMGSR_DEVINL void load_affine8(const float* __restrict__ v, const int c, const f
 // All RPW*MAXCH 16-byte loads of a wave are issued before the first reduction (one row per wave kept a single load
 // in flight: 1.05 TB/s on the UNet's [147456, 320] token matrices), the RPW butterfly chains interleave, and the
 // affine vectors are fetched once per wave.
-template <typename T, int MAXCH, int RPW>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
+template <typename T, int MAXCH, int RPW, bool XF32 = false, int YEL = 0>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                          const float* __restrict__ a, const float* __restrict__ b,
                                                          int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
@@ -196,9 +242,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
             const int c8 = lane + 64 * i;
-            u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
-            if (live && c8 < nch8) v = *reinterpret_cast<const u32x4_t*>(x + (row0 + r) * C + c8 * 8);
-            unpack8<T>(v, f[r][i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[r][i][e] = 0.0f;
+            if (live && c8 < nch8) load8<T, XF32>(x, (row0 + r) * C + c8 * 8, f[r][i]);
         }
     }
     constexpr bool PRE = MAXCH <= 3;          // wide rows: the affine vectors would cost 16*MAXCH registers, fetch them at use
@@ -251,7 +297,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     o8[e] = (f[r][i][e] - mu[r]) * rs * (PRE ? av[PRE ? i : 0][e] : ga[e]) + (PRE ? bv[PRE ? i : 0][e] : be[e]);
-                *reinterpret_cast<u32x4_t*>(y + (row0 + r) * C + c8 * 8) = pack8<T>(o8);
+                store8<T, YEL>(y, (row0 + r) * (YEL == 2 ? 2 * C : C) + c8 * 8, C, o8);
             }
         }
     }
@@ -259,8 +305,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 
 // Wide rows (C >= 1024: UNet level 2, every Flux LayerNorm): one 256-thread block per row, <= MAXV 16-byte chunks per
 // thread all in flight at once, block reductions through LDS.
-template <typename T, int MAXV>
-__global__ __launch_bounds__(256) void layernorm_block_kernel(const T* __restrict__ x, T* __restrict__ y,
+template <typename T, int MAXV, bool XF32 = false, int YEL = 0>
+__global__ __launch_bounds__(256) void layernorm_block_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                                const float* __restrict__ a, const float* __restrict__ b,
                                                                int C, float eps) {
     __shared__ float red[2][4];
@@ -272,9 +318,9 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const T* __restric
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c8 = t + 256 * i;
-        u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
-        if (c8 < nch8) v = *reinterpret_cast<const u32x4_t*>(x + row * C + c8 * 8);
-        unpack8<T>(v, f[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[i][e] = 0.0f;
+        if (c8 < nch8) load8<T, XF32>(x, row * C + c8 * 8, f[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += f[i][e];
     }
@@ -302,7 +348,7 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const T* __restric
             load_affine8(a, c8 * 8, 1.0f, ga); load_affine8(b, c8 * 8, 0.0f, be);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o8[e] = (f[i][e] - mu) * rs * ga[e] + be[e];
-            *reinterpret_cast<u32x4_t*>(y + row * C + c8 * 8) = pack8<T>(o8);
+            store8<T, YEL>(y, row * (YEL == 2 ? 2 * C : C) + c8 * 8, C, o8);
         }
     }
 }
@@ -400,16 +446,16 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(T* __restrict__ x, co
 extern "C" int omgsr_groupnorm_nchunk(int64_t HW) { return (int)((HW + GN_PPC - 1) / GN_PPC); }
 
 extern "C" int omgsr_groupnorm_stats(const void* x, float* partial, float* mean, float* rstd, float* var_out,
-                                     int32_t N, int64_t HW, int32_t C, int32_t G, float eps, void* stream) {
+                                     int32_t N, int64_t HW, int32_t C, int32_t G, float eps, int32_t x_el, void* stream) {
     if (!x || !partial || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
     if ((C & 7) || (C % G) || G > 256 || C > 8192) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = omgsr_groupnorm_nchunk(HW);
-    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 2.0 * N * (double)HW * C, st);
+    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, (x_el == OMGSR_EL_F32 ? 4.0 : 2.0) * N * (double)HW * C, st);
     const int tp = (C >> 3) < 256 ? (C >> 3) : 256;
     const size_t lds = 2 * (size_t)(256 / tp) * C * sizeof(float);      // <= 20 KB
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, N), dim3(256), lds, st,
-                                        (const T*)x, partial, HW, C, G, nchunk));
+    if (x_el == OMGSR_EL_F32) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, true>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, false>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk));
     const int tot = N * G;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(tot), dim3(64), 0, st, partial, mean, rstd, var_out,
                        N, G, nchunk, (double)HW * (C / G), eps, G);
@@ -470,19 +516,20 @@ __global__ __launch_bounds__(256) void gn_finalize_merged_kernel(const omgsr_gn_
 }  // namespace
 namespace {
 int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
-                    const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, void* stream);
+                    const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, int32_t x_el,
+                    int32_t y_el, void* stream);
 }
 
-extern "C" int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N, int64_t HW, int32_t C, int32_t G, void* stream) {
+extern "C" int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t x_el, void* stream) {
     if (!x || !partial || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
     if ((C & 7) || (C % G) || G > 256 || C > 8192) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = omgsr_groupnorm_nchunk(HW);
-    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 2.0 * N * (double)HW * C, st);
+    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, (x_el == OMGSR_EL_F32 ? 4.0 : 2.0) * N * (double)HW * C, st);
     const int tp = (C >> 3) < 256 ? (C >> 3) : 256;
     const size_t lds = 2 * (size_t)(256 / tp) * C * sizeof(float);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nchunk, N), dim3(256), lds, st,
-                                        (const T*)x, partial, HW, C, G, nchunk));
+    if (x_el == OMGSR_EL_F32) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, true>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, false>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk));
     return (int)hipGetLastError();
 }
 
@@ -497,21 +544,23 @@ extern "C" int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, flo
 
 extern "C" int omgsr_groupnorm_apply_shared(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                                             const float* beta, int32_t rows, int64_t HW, int32_t C, int32_t G, int32_t act,
-                                            int32_t stat_rows, void* stream) {
+                                            int32_t stat_rows, int32_t x_el, int32_t y_el, void* stream) {
     if (stat_rows <= 0 || rows % stat_rows) return OMGSR_E_BADARG;
-    return gn_apply_launch(x, y, mean, rstd, gamma, beta, rows, HW, C, G, act, stat_rows, stream);
+    return gn_apply_launch(x, y, mean, rstd, gamma, beta, rows, HW, C, G, act, stat_rows, x_el, y_el, stream);
 }
 
 extern "C" int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                                      const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act,
-                                     void* stream) {
-    return gn_apply_launch(x, y, mean, rstd, gamma, beta, N, HW, C, G, act, N, stream);
+                                     int32_t x_el, int32_t y_el, void* stream) {
+    return gn_apply_launch(x, y, mean, rstd, gamma, beta, N, HW, C, G, act, N, x_el, y_el, stream);
 }
 
 namespace {
 int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
-                    const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, void* stream) {
+                    const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, int32_t x_el,
+                    int32_t y_el, void* stream) {
     if (!x || !y || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
+    if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT)) return OMGSR_E_BADARG;
     if ((C & 7) || (C % G) || C > 8192) return OMGSR_E_SHAPE;
     if (act != OMGSR_ACT_NONE && act != OMGSR_ACT_SILU) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -521,27 +570,45 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
     int64_t ppb = (belems + C - 1) / C;      // ~32 KB of activations per block (5.6 TB/s; 64 KB 5.4, 128 KB 4.9, 256 KB 30 % slower)
     if (ppb < 1) ppb = 1;
     const int nblk = (int)((HW + ppb - 1) / ppb);
-    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, 4.0 * N * (double)HW * C, st);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nblk, N), dim3(256), 2 * C * sizeof(float), st, (const T*)x,
-                                        (T*)y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows));
+    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, ((x_el == OMGSR_EL_F32 ? 4.0 : 2.0) + (y_el == OMGSR_EL_SPLIT ? 4.0 : 2.0)) * N * (double)HW * C, st);
+    const size_t lds = 2 * C * sizeof(float);
+    const dim3 grid(nblk, N);
+#define OMGSR_GN_ANY(XF, YE) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, XF, YE>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows))
+    if (x_el == OMGSR_EL_F32 && y_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY(true, 2);
+    else if (x_el == OMGSR_EL_F32) OMGSR_GN_ANY(true, 0);
+    else if (y_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY(false, 2);
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL(gn_apply_kernel<T>, grid, dim3(256), lds, st, (const T*)x,
+                                             (T*)y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows));
+#undef OMGSR_GN_ANY
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+namespace {
+template <bool XF32, int YEL>
+int layernorm_launch(const void* x, void* y, const float* a, const float* b, int64_t rows, int32_t C, float eps, hipStream_t st) {
+    const int nch = ((C >> 3) + 63) / 64;
+    auto grid = [&](int rpw) { return dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))); };
+    if (nch <= 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 1, 4, XF32, YEL>), grid(4), dim3(256), 0, st, x, y, a, b, rows, C, eps));
+    else if (nch <= 2) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 2, 4, XF32, YEL>), grid(4), dim3(256), 0, st, x, y, a, b, rows, C, eps));
+    else if (nch <= 3) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 3, 2, XF32, YEL>), grid(2), dim3(256), 0, st, x, y, a, b, rows, C, eps));
+    else if (rows >= (1ll << 31)) return OMGSR_E_SHAPE;
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_block_kernel<T, 2, XF32, YEL>), dim3((unsigned)rows), dim3(256), 0, st, x, y, a, b, C, eps));
     return (int)hipGetLastError();
 }
 }  // namespace
 
 extern "C" int omgsr_layernorm(const void* x, void* y, const float* a, const float* b, int64_t rows, int32_t C,
-                               float eps, void* stream) {
+                               float eps, int32_t x_el, int32_t y_el, void* stream) {
     if (!x || !y || rows <= 0 || C <= 0) return OMGSR_E_BADARG;
+    if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT)) return OMGSR_E_BADARG;
     if ((C & 7) || C > 64 * 8 * 8) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    omgsr::TimingScope ts(OMGSR_TK_LN, 0.0, 4.0 * (double)rows * C, st);
-    const int nch = ((C >> 3) + 63) / 64;
-    auto grid = [&](int rpw) { return dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))); };
-    if (nch <= 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 1, 4>), grid(4), dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
-    else if (nch <= 2) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 2, 4>), grid(4), dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
-    else if (nch <= 3) OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_kernel<T, 3, 2>), grid(2), dim3(256), 0, st, (const T*)x, (T*)y, a, b, rows, C, eps));
-    else if (rows >= (1ll << 31)) return OMGSR_E_SHAPE;
-    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((layernorm_block_kernel<T, 2>), dim3((unsigned)rows), dim3(256), 0, st, (const T*)x, (T*)y, a, b, C, eps));
-    return (int)hipGetLastError();
+    omgsr::TimingScope ts(OMGSR_TK_LN, 0.0, ((x_el == OMGSR_EL_F32 ? 4.0 : 2.0) + (y_el == OMGSR_EL_SPLIT ? 4.0 : 2.0)) * (double)rows * C, st);
+    if (x_el == OMGSR_EL_F32 && y_el == OMGSR_EL_SPLIT) return layernorm_launch<true, 2>(x, y, a, b, rows, C, eps, st);
+    if (x_el == OMGSR_EL_F32) return layernorm_launch<true, 0>(x, y, a, b, rows, C, eps, st);
+    if (y_el == OMGSR_EL_SPLIT) return layernorm_launch<false, 2>(x, y, a, b, rows, C, eps, st);
+    return layernorm_launch<false, 0>(x, y, a, b, rows, C, eps, st);
 }
 
 extern "C" int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t L, int32_t Lvalid, void* stream) {

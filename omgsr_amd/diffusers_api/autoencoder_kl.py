@@ -45,9 +45,9 @@ class ResnetBlock2D(nn.Module):
 
     def nhwc(self, x, conv1_bias=None):
         """conv1_bias: conv1.bias + time_emb_proj(silu(temb)) folded by the UNet (constant at fixed t*)."""
-        h = self.norm1.nhwc(x, ops.ACT_SILU)
+        h = self.norm1.nhwc(x, ops.ACT_SILU, split=self.conv1.in_split())
         h = self.conv1.nhwc(h, bias_override=conv1_bias, gn_groups=self.norm2.num_groups)     # norm2's statistics ride the epilogue
-        h = self.norm2.nhwc(h, ops.ACT_SILU)
+        h = self.norm2.nhwc(h, ops.ACT_SILU, split=self.conv2.in_split())
         sc = self.conv_shortcut.nhwc(x, pad=0) if self.conv_shortcut is not None else x
         return self.conv2.nhwc(h, residual=sc, gn_groups=self.norm1.num_groups)             # ... and the next block's norm1
 
@@ -89,18 +89,23 @@ class VaeAttention(nn.Module):
         self.to_out = nn.ModuleList([Linear(channels, channels), nn.Dropout(0.0)])
         self.norm_cross = None
 
+    def qkv_split(self) -> int:
+        """Split of the operand the three projections share (the GroupNorm output)."""
+        return self.to_q.in_split()
+
     def nhwc(self, x):
-        return self.attend(self.group_norm.nhwc(x), x)
+        return self.attend(self.group_norm.nhwc(x, split=self.qkv_split()), x)
 
     def attend(self, g, residual):
-        """g: GroupNorm'ed input [N,H,W,C] (the tiled VAE supplies cross-tile statistics); returns residual + attn."""
-        N, H, W, Cc = g.shape
+        """g: GroupNorm'ed operand [N,H,W,C*split] (the tiled VAE supplies cross-tile statistics); returns residual + attn."""
+        N, H, W, Cg = g.shape
+        Cc = residual.shape[-1]
         L = H * W
         x = residual
-        g = g.reshape(N, L, Cc)
-        q = self.to_q.nhwc(g)
+        g = g.reshape(N, L, Cg)
+        q = self.to_q.nhwc(g, out_dtype=ops.OUT_BF16)
         Lp = ops._round_up(L, 128)
-        k = self.to_k.nhwc(g)
+        k = self.to_k.nhwc(g, out_dtype=ops.OUT_BF16)
         if Lp != L:
             kp = torch.zeros((N, Lp, Cc), device=x.device, dtype=ops.act_dtype())
             kp[:, :L] = k
@@ -109,9 +114,36 @@ class VaeAttention(nn.Module):
         s = ops.bmm_nt(q, k, alpha=self.scale, out_dtype=ops.OUT_F32)         # [N, L, Lp] fp32 scores
         p = ops.softmax_rows(s, valid=L)
         del s
-        o = ops.bmm_nt(p, vt)                                                 # [N, L, C]
+        o = ops.bmm_nt(p, vt, out_split=self.to_out[0].in_split())            # [N, L, C] operand of the output projection
         out = self.to_out[0].nhwc(o, residual=x.reshape(N, L, Cc), gn_groups=self.group_norm.num_groups)   # -> mid resnet norm1
         return ops.carry_gn(out, out.reshape(N, H, W, Cc))
+
+    # ---- diffusers' Attention helper surface, as infer/vaehook.py:137-171 (attn_forward_new) calls it op by op on
+    # [B, L, C] tensors in the CALLER's dtype (torch plumbing around the same GEMM / softmax kernels) -------------------
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
+        return attention_mask                   # the VAE mid block never has a mask (the hook passes None through)
+
+    def head_to_batch_dim(self, tensor, out_dim=3):
+        B, L, Cc = tensor.shape
+        t = tensor.reshape(B, L, self.heads, Cc // self.heads).permute(0, 2, 1, 3)
+        return t.reshape(B * self.heads, L, Cc // self.heads) if out_dim == 3 else t
+
+    def batch_to_head_dim(self, tensor):
+        BH, L, d = tensor.shape
+        return tensor.reshape(BH // self.heads, self.heads, L, d).permute(0, 2, 1, 3).reshape(BH // self.heads, L, d * self.heads)
+
+    def get_attention_scores(self, query, key, attention_mask=None):
+        """softmax(scale * Q K^T) [B*heads, Lq, Lk] in query's dtype: the batched MFMA GEMM (fp32 scores) + the masked row
+        softmax (diffusers: baddbmm(beta=0, alpha=scale) -> float() softmax -> cast, upcast_softmax=True for the VAE)."""
+        if attention_mask is not None:
+            raise NotImplementedError("VaeAttention.get_attention_scores: the VAE mid block is never masked")
+        B, Lq, d = query.shape
+        Lk = key.shape[1]
+        dp, Lkp = ops._round_up(d, 32), ops._round_up(Lk, 128)
+        q = torch.zeros((B, Lq, dp), device=query.device, dtype=ops.act_dtype()); q[..., :d] = query
+        k = torch.zeros((B, Lkp, dp), device=query.device, dtype=ops.act_dtype()); k[:, :Lk, :d] = key
+        s = ops.bmm_nt(q, k, alpha=self.scale, out_dtype=ops.OUT_F32)
+        return ops.softmax_rows(s, valid=Lk)[:, :, :Lk].to(query.dtype)
 
 
 class _VaeMid(nn.Module):
@@ -174,7 +206,7 @@ class Encoder(nn.Module):
         for b in self.down_blocks:
             h = b.nhwc(h)
         h = self.mid_block.nhwc(h)
-        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU)
+        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU, split=self.conv_out.in_split())
         return self.conv_out.nhwc(h)
 
     def run_nhwc(self, x):
@@ -210,7 +242,7 @@ class Decoder(nn.Module):
         h = self.mid_block.nhwc(h)
         for b in self.up_blocks:
             h = b.nhwc(h)
-        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU)
+        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU, split=self.conv_out.in_split())
         return self.conv_out.nhwc(h)
 
     def run_nhwc(self, z):

@@ -28,7 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..nn import LayerNorm, Linear, RMSNormWeight, _key
+from ..nn import InputCache, LayerNorm, Linear, RMSNormWeight, _key
 from .modeling_utils import ConfigDict, ModelMixin
 from .unet_2d_condition import TimestepEmbedding, timestep_sinusoid
 
@@ -61,8 +61,9 @@ class FluxAttention(nn.Module, _Cached):
 
     def qk_packed(self, ctx: bool = False) -> ops.PackedWeight:
         q, k = (self.add_q_proj, self.add_k_proj) if ctx else (self.to_q, self.to_k)
+        sp = q.in_split()
         return self._cache("qk_ctx" if ctx else "qk", lambda: ops.pack_linear_weight(
-            torch.cat([q.weight, k.weight], 0), torch.cat([q.bias, k.bias], 0)), q.weight, k.weight, q.bias, k.bias)
+            torch.cat([q.weight, k.weight], 0), torch.cat([q.bias, k.bias], 0), split=sp), q.weight, k.weight, q.bias, k.bias, sp)
 
     def norm_table(self, ctx: bool = False) -> torch.Tensor:
         nq, nk = (self.norm_added_q, self.norm_added_k) if ctx else (self.norm_q, self.norm_k)
@@ -82,7 +83,7 @@ class FluxFeedForward(nn.Module):
         self.net = nn.ModuleList([GELUProj(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim)])
 
     def run(self, xn, residual, gate):
-        h = self.net[0].proj.nhwc(xn, act=ops.ACT_GELU_TANH)
+        h = self.net[0].proj.nhwc(xn, act=ops.ACT_GELU_TANH, out_dtype=ops.OUT_BF16, out_split=self.net[2].in_split())
         return self.net[2].nhwc(h, residual=residual, gate=gate)
 
 
@@ -118,13 +119,14 @@ class FluxTransformerBlock(nn.Module):
         return dict(img=six(self.norm1), ctx=six(self.norm1_context))
 
     def run(self, h, c, mod, rope, ws):
-        """h [Li, D] image tokens, c [Lc, D] text tokens (bf16); ws = joint work buffers."""
+        """h [Li, D] image tokens, c [Lc, D] text tokens (stream tensors); ws = joint operand buffers."""
         at = self.attn
         Lc, Li, D = c.shape[0], h.shape[0], h.shape[1]
         mi, mc = mod["img"], mod["ctx"]
-        hn = ops.layer_norm(h, mi["a1"], mi["b1"], 1e-6)
-        cn = ops.layer_norm(c, mc["a1"], mc["b1"], 1e-6)
-        qk, vt, o = ws["qk"], ws["vt"], ws["o"]
+        hn = ops.layer_norm(h, mi["a1"], mi["b1"], 1e-6, split=at.to_q.in_split())
+        cn = ops.layer_norm(c, mc["a1"], mc["b1"], 1e-6, split=at.add_q_proj.in_split())
+        osp = at.to_out[0].in_split()                      # to_out and to_add_out read one buffer: same form (precision.check_policy)
+        qk, vt, o = ws["qk"], ws["vt"], ws["o2" if osp == 2 else "o"]
         ops.linear_into(cn, at.qk_packed(ctx=True), qk, 0, 0)
         ops.linear_into(hn, at.qk_packed(), qk, Lc, 0)
         ops.linear_t_into(cn, at.add_v_proj.packed(), vt, 0)
@@ -132,11 +134,12 @@ class FluxTransformerBlock(nn.Module):
         cos, sin = rope
         ops.rmsnorm_rope_(qk[None, :Lc], at.norm_table(ctx=True), cos, sin, 2 * at.heads, at.head_dim, pos0=0)
         ops.rmsnorm_rope_(qk[None, Lc:], at.norm_table(), cos, sin, 2 * at.heads, at.head_dim, pos0=Lc)
-        ops.attention(qk[None], qk[None], vt[None], at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=Lc + Li, out=o[None])
+        ops.attention(qk[None], qk[None], vt[None], at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=Lc + Li, out=o[None],
+                      out_split=osp)
         h = at.to_out[0].nhwc(o[Lc:], residual=h, gate=mi["g1"])
         c = at.to_add_out.nhwc(o[:Lc], residual=c, gate=mc["g1"])
-        h = self.ff.run(ops.layer_norm(h, mi["a2"], mi["b2"], 1e-6), h, mi["g2"])
-        c = self.ff_context.run(ops.layer_norm(c, mc["a2"], mc["b2"], 1e-6), c, mc["g2"])
+        h = self.ff.run(ops.layer_norm(h, mi["a2"], mi["b2"], 1e-6, split=self.ff.net[0].proj.in_split()), h, mi["g2"])
+        c = self.ff_context.run(ops.layer_norm(c, mc["a2"], mc["b2"], 1e-6, split=self.ff_context.net[0].proj.in_split()), c, mc["g2"])
         return h, c
 
 
@@ -149,6 +152,7 @@ class FluxSingleTransformerBlock(nn.Module):
         self.act_mlp = nn.GELU(approximate="tanh")
         self.proj_out = Linear(dim + self.mlp_hidden, dim)
         self.attn = FluxAttention(dim, heads, head_dim, joint=False, pre_only=True)
+        self.attn._shares_input_with = (self.proj_mlp,)        # precision.check_policy: one LayerNorm'd operand feeds all four
 
     def fold(self, act32):
         shift, scale, gate = self.norm.fold(act32)
@@ -157,13 +161,16 @@ class FluxSingleTransformerBlock(nn.Module):
     def run(self, x, mod, rope, ws):
         at = self.attn
         L, D = x.shape
-        xn = ops.layer_norm(x, mod["a"], mod["b"], 1e-6)
-        qk, vt, cat = ws["qk"], ws["vt"], ws["cat"]
+        xn = ops.layer_norm(x, mod["a"], mod["b"], 1e-6, split=at.to_q.in_split())      # read by to_q | to_k, to_v and proj_mlp
+        csp = self.proj_out.in_split()
+        qk, vt, cat = ws["qk"], ws["vt"], ws["cat2" if csp == 2 else "cat"]
+        Kc = D + self.mlp_hidden                           # the [attn | mlp] operand of proj_out; split form: [hi (Kc) | lo (Kc)]
         ops.linear_into(xn, at.qk_packed(), qk, 0, 0)
         ops.linear_t_into(xn, at.to_v.packed(), vt, 0)
         ops.rmsnorm_rope_(qk[None], at.norm_table(), rope[0], rope[1], 2 * at.heads, at.head_dim, pos0=0)
-        ops.attention(qk[None], qk[None], vt[None], at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=L, out=cat[None])
-        ops.linear_into(xn, self.proj_mlp.packed(), cat, 0, D, act=ops.ACT_GELU_TANH)
+        ops.attention(qk[None], qk[None], vt[None], at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=L, out=cat[None],
+                      out_split=csp, o_lo_col=Kc)
+        ops.linear_into(xn, self.proj_mlp.packed(), cat, 0, D, act=ops.ACT_GELU_TANH, out_split=csp, lo_col0=Kc + D)
         return self.proj_out.nhwc(cat, residual=x, gate=mod["g"])
 
 
@@ -231,38 +238,54 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
         self.single_transformer_blocks = nn.ModuleList([FluxSingleTransformerBlock(dim, c.num_attention_heads, c.attention_head_dim) for _ in range(c.num_single_layers)])
         self.norm_out = AdaLayerNormContinuous(dim)
         self.proj_out = Linear(dim, c.patch_size * c.patch_size * (c.out_channels or c.in_channels))
-        self._mod_cache = None
+        self._mod_cache, self._rope_cache, self._ctx_cache = InputCache(), InputCache(), InputCache()
+        # 16-bit weights: round timestep / guidance through the weight dtype before the x1000 like diffusers does (the LoRA was
+        # trained through that path); set False to condition on the exact value (what an fp32 model sees)
+        self.round_timestep_to_weight_dtype = True
 
     # ---- constant folding ------------------------------------------------------------------
     @torch.no_grad()
     def _modulation(self, timestep: torch.Tensor, guidance: Optional[torch.Tensor], pooled: torch.Tensor):
-        t = float(timestep.reshape(-1)[0])
-        g = None if guidance is None else float(guidance.reshape(-1)[0].float())
-        key = (t, g, _key(pooled), _key(self.norm_out.linear.weight, self.x_embedder.weight))
-        if self._mod_cache is None or self._mod_cache[0] != key:
+        # diffusers: `timestep.to(hidden_states.dtype) * 1000` - a 16-bit model sees the timestep ROUNDED to its dtype before
+        # the scaling (bf16: 0.50511 -> 0.50390625 -> 503.9 -> bf16 504.0; SURVEY C-7), the fp32 model 505.11
+        wd = self.x_embedder.weight.dtype
+        rt = (lambda v: float((torch.tensor(v, dtype=torch.float32).to(wd) * 1000).float())) if (wd != torch.float32 and self.round_timestep_to_weight_dtype) \
+            else (lambda v: v * 1000.0)
+        t = rt(float(timestep.reshape(-1)[0]))
+        g = None if guidance is None else rt(float(guidance.reshape(-1)[0].float()))
+        deps = [p for m in (self.time_text_embed, self.norm_out) for p in m.parameters()]
+        for b in list(self.transformer_blocks) + list(self.single_transformer_blocks):
+            for nm in ("norm1", "norm1_context", "norm"):
+                if hasattr(b, nm):
+                    deps += list(getattr(b, nm).parameters())
+        wkey = (t, g, _key(*deps))
+
+        def build():
             dev = self.x_embedder.weight.device
-            # fp32 timestep path (the fp32 oracle's semantics; the bf16 reference rounds t*1000 to 504.0, SURVEY C-7)
-            tt = torch.tensor([t * 1000.0], dtype=torch.float32, device=dev)
-            gg = None if g is None else torch.tensor([g * 1000.0], dtype=torch.float32, device=dev)
+            tt = torch.tensor([t], dtype=torch.float32, device=dev)
+            gg = None if g is None else torch.tensor([g], dtype=torch.float32, device=dev)
             temb = self.time_text_embed.fp32(tt, gg, pooled.to(dev)[:1])[0]
             act = F.silu(temb)
             double = [b.fold(act) for b in self.transformer_blocks]
             single = [b.fold(act) for b in self.single_transformer_blocks]
             scale, shift = F.linear(act, self.norm_out.linear.weight.float(), self.norm_out.linear.bias.float()).chunk(2)   # scale FIRST
             out = dict(a=(1 + scale).contiguous(), b=shift.contiguous())
-            self._mod_cache = (key, dict(double=double, single=single, out=out))
-        return self._mod_cache[1]
+            return dict(double=double, single=single, out=out)
+        return self._mod_cache.get((pooled,), wkey, build)
 
     def _rope(self, txt_ids, img_ids):
-        return self._cache("rope", lambda: rope_tables(torch.cat([txt_ids, img_ids], 0).float(), self.config.axes_dims_rope), txt_ids, img_ids)
+        # keyed on the id TENSORS (identity + version, references held): an address alone is not an identity
+        return self._rope_cache.get((txt_ids, img_ids), (), lambda: rope_tables(torch.cat([txt_ids, img_ids], 0).float(), self.config.axes_dims_rope))
 
     def _context(self, ehs):
-        return self._cache("ctx", lambda: self.context_embedder.nhwc(ehs.to(ops.act_dtype()).contiguous()), ehs,
-                           self.context_embedder.weight)
+        def build():
+            e = ehs.float().contiguous() if ops.precise() else ehs.to(ops.act_dtype()).contiguous()
+            return self.context_embedder.nhwc(e)
+        return self._ctx_cache.get((ehs,), _key(self.context_embedder.weight, self.context_embedder.bias, self.context_embedder.in_split()), build)
 
     # ---- token executor --------------------------------------------------------------------
     def tokens(self, x_tok: torch.Tensor, timestep, guidance, pooled, ehs, txt_ids, img_ids) -> torch.Tensor:
-        """x_tok [B, Li, in_channels] bf16 -> velocity [B, Li, in_channels] bf16."""
+        """x_tok [B, Li, in_channels] stream tensor -> velocity [B, Li, in_channels] stream tensor."""
         mod = self._modulation(timestep, guidance, pooled)
         rope = self._rope(txt_ids, img_ids)
         ctx0 = self._context(ehs)                               # [1|B, Lc, D]
@@ -275,6 +298,11 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
                   vt=torch.empty((D, ops._round_up(L, 8)), device=dev, dtype=ops.act_dtype()),
                   o=torch.empty((L, D), device=dev, dtype=ops.act_dtype()),
                   cat=torch.empty((L, D + mlp), device=dev, dtype=ops.act_dtype()))
+        if ops.precise():       # two-term split forms of the operands that to_out / to_add_out / proj_out read (policy dependent)
+            if any(b.attn.to_out[0].in_split() == 2 for b in self.transformer_blocks):
+                ws["o2"] = torch.empty((L, 2 * D), device=dev, dtype=ops.act_dtype())
+            if any(b.proj_out.in_split() == 2 for b in self.single_transformer_blocks):
+                ws["cat2"] = torch.empty((L, 2 * (D + mlp)), device=dev, dtype=ops.act_dtype())
         if ws["vt"].shape[1] != L:
             ws["vt"].zero_()
         outs = []
@@ -286,14 +314,14 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
             x = torch.cat([c, h], 0)
             for blk, m in zip(self.single_transformer_blocks, mod["single"]):
                 x = blk.run(x, m, rope, ws)
-            hn = ops.layer_norm(x[Lc:], mod["out"]["a"], mod["out"]["b"], 1e-6)
+            hn = ops.layer_norm(x[Lc:], mod["out"]["a"], mod["out"]["b"], 1e-6, split=self.proj_out.in_split())
             outs.append(self.proj_out.nhwc(hn))
         return torch.stack(outs, 0)
 
     # ---- diffusers API ---------------------------------------------------------------------
     def forward(self, hidden_states, timestep, guidance=None, pooled_projections=None, encoder_hidden_states=None,
                 txt_ids=None, img_ids=None, return_dict: bool = True, **_):
-        x = hidden_states.to(ops.act_dtype()).contiguous()
+        x = hidden_states.to(ops.stream_dtype()).contiguous()
         out = self.tokens(x, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids)
         out = out.to(hidden_states.dtype)
         return SimpleNamespace(sample=out) if return_dict else (out,)

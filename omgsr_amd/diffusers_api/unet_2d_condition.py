@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..nn import Conv2d, GroupNorm, LayerNorm, Linear, _key
+from ..nn import Conv2d, GroupNorm, InputCache, LayerNorm, Linear, _key
 from .autoencoder_kl import Downsample2D, ResnetBlock2D, Upsample2D
 from .modeling_utils import ConfigDict, ModelMixin
 
@@ -75,38 +75,45 @@ class Attention(nn.Module):
         self.to_k = Linear(kv, inner, bias=False)
         self.to_v = Linear(kv, inner, bias=False)
         self.to_out = nn.ModuleList([Linear(inner, query_dim), nn.Dropout(0.0)])
-        self._ctx_cache = None
+        self._ctx_cache = InputCache()
+
+    def in_split(self) -> int:
+        """Split of the LayerNorm'd operand that to_q (| to_k, to_v) consume."""
+        return self.to_q.in_split()
 
     def _qk_packed(self):
+        sp = self.in_split()
+
         def build():
-            return ops.pack_linear_weight(torch.cat([self.to_q.weight, self.to_k.weight], dim=0), None)
-        k = _key(self.to_q.weight, self.to_k.weight)
+            return ops.pack_linear_weight(torch.cat([self.to_q.weight, self.to_k.weight], dim=0), None, split=sp)
+        k = _key(self.to_q.weight, self.to_k.weight, sp)
         if getattr(self, "_qk_key", None) != k:
             self._qk, self._qk_key = build(), k
         return self._qk
 
     def self_nhwc(self, xn: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
-        """xn: LayerNorm'd tokens [B, L, C]; returns residual + to_out(attn)."""
+        """xn: LayerNorm'd operand tokens [B, L, C*split]; returns residual + to_out(attn) on the stream."""
         B, L, _ = xn.shape
-        qk = ops.linear(xn, self._qk_packed())                          # [B, L, 2*inner]
+        qk = ops.linear(xn, self._qk_packed(), out_dtype=ops.OUT_BF16)  # [B, L, 2*inner]
         vt = ops.linear_t(xn, self.to_v.packed(), L)                    # [B, inner, L8]
-        o = ops.attention(qk, qk, vt, self.heads, self.dim_head, self.scale, q_col=0, k_col=self.inner, Lk=L)
+        o = ops.attention(qk, qk, vt, self.heads, self.dim_head, self.scale, q_col=0, k_col=self.inner, Lk=L,
+                          out_split=self.to_out[0].in_split())
         return self.to_out[0].nhwc(o, residual=residual)
 
     def context(self, ehs: torch.Tensor):
-        """K and V^T of a fixed prompt (cached on the tensor's identity)."""
-        k = _key(ehs, self.to_k.weight, self.to_v.weight)
-        if self._ctx_cache is None or self._ctx_cache[0] != k:
-            e = ehs.to(ops.act_dtype()).contiguous()
-            kk = ops.linear(e, self.to_k.packed())                      # [Bc, 77, inner]
-            vt = ops.linear_t(e, self.to_v.packed(), e.shape[1])        # [Bc, inner, 80]
-            self._ctx_cache = (k, kk, vt, e.shape[1])
-        return self._ctx_cache[1:]
+        """K and V^T of a fixed prompt: computed once per prompt TENSOR (the cache holds a reference to it and compares
+        identity + version; an address is not an identity, the allocator reuses addresses)."""
+        def build():
+            e = ehs.float().contiguous() if ops.precise() else ehs.to(ops.act_dtype()).contiguous()
+            kk = ops.linear(e, self.to_k.packed(), out_dtype=ops.OUT_BF16)      # [Bc, 77, inner]
+            vt = ops.linear_t(e, self.to_v.packed(), e.shape[1])                # [Bc, inner, 80]
+            return kk, vt, e.shape[1]
+        return self._ctx_cache.get((ehs,), _key(self.to_k.weight, self.to_v.weight, self.to_k.in_split()), build)
 
     def cross_nhwc(self, xn: torch.Tensor, ehs: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         kk, vt, Lk = self.context(ehs)
-        q = self.to_q.nhwc(xn)
-        o = ops.attention(q, kk, vt, self.heads, self.dim_head, self.scale, Lk=Lk)
+        q = self.to_q.nhwc(xn, out_dtype=ops.OUT_BF16)
+        o = ops.attention(q, kk, vt, self.heads, self.dim_head, self.scale, Lk=Lk, out_split=self.to_out[0].in_split())
         return self.to_out[0].nhwc(o, residual=residual)
 
 
@@ -116,9 +123,10 @@ class GEGLU(nn.Module):
         self.proj = Linear(dim_in, dim_out * 2)
 
     def packed(self):
-        k = _key(self.proj.weight, self.proj.bias)
+        sp = self.proj.in_split()
+        k = _key(self.proj.weight, self.proj.bias, sp)
         if getattr(self, "_pk_key", None) != k:
-            self._pk, self._pk_key = ops.pack_geglu_weight(self.proj.weight, self.proj.bias), k
+            self._pk, self._pk_key = ops.pack_geglu_weight(self.proj.weight, self.proj.bias, split=sp), k
         return self._pk
 
 
@@ -128,7 +136,8 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim)])
 
     def nhwc(self, xn, residual):
-        h = ops.linear(xn, self.net[0].packed())          # a * gelu(gate) in the GEMM epilogue
+        # a * gelu(gate) in the GEMM epilogue; the hidden tensor is the operand of net[2]
+        h = ops.linear(xn, self.net[0].packed(), out_dtype=ops.OUT_BF16, out_split=self.net[2].in_split())
         return self.net[2].nhwc(h, residual=residual)
 
 
@@ -143,9 +152,9 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def nhwc(self, y, ehs):
-        y = self.attn1.self_nhwc(self.norm1.nhwc(y), y)
-        y = self.attn2.cross_nhwc(self.norm2.nhwc(y), ehs, y)
-        return self.ff.nhwc(self.norm3.nhwc(y), y)
+        y = self.attn1.self_nhwc(self.norm1.nhwc(y, split=self.attn1.in_split()), y)
+        y = self.attn2.cross_nhwc(self.norm2.nhwc(y, split=self.attn2.in_split()), ehs, y)
+        return self.ff.nhwc(self.norm3.nhwc(y, split=self.ff.net[0].proj.in_split()), y)
 
 
 class Transformer2DModel(nn.Module):
@@ -159,7 +168,7 @@ class Transformer2DModel(nn.Module):
     def nhwc(self, x, ehs):
         N, H, W, Cc = x.shape
         res = x.reshape(N, H * W, Cc)
-        y = self.proj_in.nhwc(self.norm.nhwc(x).reshape(N, H * W, Cc))
+        y = self.proj_in.nhwc(self.norm.nhwc(x, split=self.proj_in.in_split()).reshape(N, H * W, -1))
         for blk in self.transformer_blocks:
             y = blk.nhwc(y, ehs)
         out = self.proj_out.nhwc(y, residual=res, gn_groups=self.norm.num_groups)     # a resnet's GroupNorm usually consumes it
@@ -239,7 +248,12 @@ class UNet2DConditionModel(ModelMixin):
     def _folded_biases(self, timestep) -> dict:
         """{id(resnet): conv1.bias + time_emb_proj(silu(time_embedding(sinusoid(t))))} in fp32."""
         t = int(timestep) if not torch.is_tensor(timestep) else int(timestep.reshape(-1)[0].item())
-        key = (t, _key(self.time_embedding.linear_1.weight, self.time_embedding.linear_2.weight, self.conv_in.weight))
+        # every parameter the folded biases depend on is in the key (a LoRA merge into one resnet's time_emb_proj must refold)
+        deps = [self.time_embedding.linear_1.weight, self.time_embedding.linear_1.bias, self.time_embedding.linear_2.weight,
+                self.time_embedding.linear_2.bias]
+        for r in self._resnets():
+            deps += [r.time_emb_proj.weight, r.time_emb_proj.bias, r.conv1.bias]
+        key = (t, _key(*deps))
         if key not in self._temb_cache:
             dev = self.conv_in.weight.device
             with torch.no_grad():
@@ -256,7 +270,7 @@ class UNet2DConditionModel(ModelMixin):
 
     # ---- NHWC executor ---------------------------------------------------------------------
     def nhwc(self, x: torch.Tensor, timestep, ehs: torch.Tensor) -> torch.Tensor:
-        """x [B,h,w,8] (4 latent channels + zero pad) -> eps [B,h,w,8] bf16 (4 channels + zero pad)."""
+        """x [B,h,w,8] stream (4 latent channels + zero pad) -> eps [B,h,w,8] stream (4 channels + zero pad)."""
         fb = self._folded_biases(timestep)
         g = self.config.norm_num_groups       # producers leave the statistics of the GroupNorm that reads them next
         h = self.conv_in.nhwc(x, gn_groups=g)
@@ -282,7 +296,7 @@ class UNet2DConditionModel(ModelMixin):
                     h = blk.attentions[j].nhwc(h, ehs)
             if blk.upsamplers is not None:
                 h = blk.upsamplers[0].nhwc(h)
-        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU)
+        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU, split=self.conv_out.in_split())
         return self.conv_out.nhwc(h)
 
     # ---- diffusers API ---------------------------------------------------------------------

@@ -2,7 +2,8 @@
 and PEFT-style weight merging work unchanged) whose compute runs through the HIP kernels.
 
 Two ways in:
-  * `.nhwc(x, ...)`  — fast path used by the model executors: bf16 channels-last in and out
+  * `.nhwc(x, ...)`  — fast path used by the model executors: channels-last; stream tensors in and out by default
+                       (ops.py: the compute type in the fast tiers, fp32 in the accurate tier), MFMA operands in between
   * `.forward(x)`    — diffusers/torch calling convention (NCHW for convs/GroupNorm) so code that
                        duck-types the modules op by op (the reference's infer/vaehook.py:248-276)
                        still works; it converts layout around the same kernels.
@@ -19,7 +20,28 @@ from . import ops
 
 
 def _key(*tensors) -> tuple:
-    return (ops.act_dtype(),) + tuple((t.data_ptr(), t._version, str(t.device), t.dtype) if t is not None else None for t in tensors)
+    """Identity of PARAMETER tensors (held alive by their module, so an address names one tensor) under the current tier.
+    Not for per-call inputs: see input_key()."""
+    return ops.mode_key() + tuple((t.data_ptr(), t._version, str(t.device), t.dtype, tuple(t.shape)) if torch.is_tensor(t) else t for t in tensors)
+
+
+class InputCache:
+    """One-slot cache keyed on per-call INPUT tensors (prompt embeddings, ids, pooled projections). The caching allocator
+    reuses addresses, so an address is not an identity: the slot keeps a strong reference to every keyed tensor and
+    compares with `is` + `_version` (+ the weights' parameter key)."""
+
+    def __init__(self):
+        self._inputs, self._versions, self._wkey, self._value = None, None, None, None
+
+    def get(self, inputs: tuple, wkey: tuple, builder):
+        same = (self._inputs is not None and len(self._inputs) == len(inputs) and self._wkey == wkey and
+                all(a is b for a, b in zip(self._inputs, inputs)) and
+                self._versions == tuple(None if t is None else t._version for t in inputs))
+        if not same:
+            self._value = builder()
+            self._inputs, self._wkey = tuple(inputs), wkey
+            self._versions = tuple(None if t is None else t._version for t in inputs)
+        return self._value
 
 
 class _Packed:
@@ -33,19 +55,31 @@ class _Packed:
         return self._pk
 
 
-class Conv2d(nn.Conv2d, _Packed):
+class _Operand:
+    """`op_split`: 1, or 2 when this layer's INPUT arrives as a two-term split operand (accurate tier, set per layer by a
+    precision policy: omgsr_amd.precision). The producer of the input (norm / cast / GEMM epilogue) asks the consumer."""
+    op_split = 1
+
+    def in_split(self) -> int:
+        return self.op_split if ops.precise() else 1
+
+
+class Conv2d(nn.Conv2d, _Packed, _Operand):
     def packed(self) -> ops.PackedWeight:
         # logical Cout widened to a multiple of 8 (zero rows): 3/4-channel heads write 16-byte NHWC rows
-        return self._packed(lambda: ops.pack_conv_weight(self.weight, self.bias, cout_multiple=8), self.weight, self.bias)
+        sp = self.in_split()
+        return self._packed(lambda: ops.pack_conv_weight(self.weight, self.bias, cout_multiple=8, split=sp), self.weight, self.bias, sp)
 
-    def nhwc(self, x, *, pad=None, upsample=False, act=ops.ACT_NONE, residual=None, bias_override=None, stride=None, gn_groups=0):
-        """x [N,H,W,Cin8] -> [N,Ho,Wo,Cout8]; channels beyond out_channels are exact zeros."""
+    def nhwc(self, x, *, pad=None, upsample=False, act=ops.ACT_NONE, residual=None, bias_override=None, stride=None, gn_groups=0,
+             out_dtype=ops.OUT_STREAM, out_split=1):
+        """x [N,H,W,Cin8] (operand, or a stream tensor that is cast / split here) -> [N,Ho,Wo,Cout8]; channels beyond
+        out_channels are exact zeros."""
         pw = self.packed()
         if bias_override is not None:
-            pw = ops.PackedWeight(pw.w, bias_override, pw.cout, pw.cin, pw.R, pw.S, w_cm=pw.w_cm)
+            pw = ops.PackedWeight(pw.w, bias_override, pw.cout, pw.cin, pw.R, pw.S, w_cm=pw.w_cm, split=pw.split)
         p = self.padding[0] if pad is None else pad
         return ops.conv2d(x, pw, stride=stride or self.stride[0], pad=p, upsample=upsample, act=act, residual=residual,
-                          gn_groups=gn_groups)
+                          gn_groups=gn_groups, out_dtype=out_dtype, out_split=out_split)
 
     def forward(self, x):  # NCHW compat
         y = self.nhwc(ops.nchw_to_nhwc(x.contiguous(), ops._round_up(self.in_channels, 8)))
@@ -53,15 +87,17 @@ class Conv2d(nn.Conv2d, _Packed):
                                 dtype=ops.io_dtype(x))
 
 
-class Linear(nn.Linear, _Packed):
+class Linear(nn.Linear, _Packed, _Operand):
     def packed(self) -> ops.PackedWeight:
-        return self._packed(lambda: ops.pack_linear_weight(self.weight, self.bias), self.weight, self.bias)
+        sp = self.in_split()
+        return self._packed(lambda: ops.pack_linear_weight(self.weight, self.bias, split=sp), self.weight, self.bias, sp)
 
-    def nhwc(self, x, *, act=ops.ACT_NONE, residual=None, gate=None, out_dtype=ops.OUT_BF16, gn_groups=0):
-        return ops.linear(x, self.packed(), act=act, residual=residual, gate=gate, out_dtype=out_dtype, gn_groups=gn_groups)
+    def nhwc(self, x, *, act=ops.ACT_NONE, residual=None, gate=None, out_dtype=ops.OUT_STREAM, gn_groups=0, out_split=1):
+        return ops.linear(x, self.packed(), act=act, residual=residual, gate=gate, out_dtype=out_dtype, gn_groups=gn_groups,
+                          out_split=out_split)
 
     def forward(self, x):
-        y = self.nhwc(x.to(ops.act_dtype()).contiguous())
+        y = self.nhwc(x.to(ops.stream_dtype()).contiguous())
         return y.to(x.dtype)
 
 
@@ -70,25 +106,26 @@ class GroupNorm(nn.GroupNorm, _Packed):
         return self._packed(lambda: (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous()),
                             self.weight, self.bias)
 
-    def nhwc(self, x, act=ops.ACT_NONE):
+    def nhwc(self, x, act=ops.ACT_NONE, split=1):
+        """Stream tensor -> normalised (+SiLU) MFMA operand; split 2: as the two-term split its consumer asked for."""
         g, b = self._affine()
-        return ops.group_norm(x, g, b, self.num_groups, self.eps, act)
+        return ops.group_norm(x, g, b, self.num_groups, self.eps, act, split=split)
 
     def stats(self, x):
         return ops.group_norm_stats(x, self.num_groups, self.eps)
 
-    def apply_stats(self, x, mean, rstd, act=ops.ACT_NONE):
+    def apply_stats(self, x, mean, rstd, act=ops.ACT_NONE, split=1):
         """Normalise with externally supplied per-(n, group) statistics (tiled VAE)."""
         g, b = self._affine()
         if mean.shape[0] != x.shape[0]:       # tile-major rows sharing their image's statistics
-            return ops.group_norm_apply_shared(x, mean, rstd, g, b, self.num_groups, act)
-        return ops.group_norm_apply(x, mean, rstd, g, b, self.num_groups, act)
+            return ops.group_norm_apply_shared(x, mean, rstd, g, b, self.num_groups, act, split=split)
+        return ops.group_norm_apply(x, mean, rstd, g, b, self.num_groups, act, split=split)
 
     def forward(self, x):  # NCHW (or [B, C, L]) compat
         shp = x.shape
         x4 = x.reshape(shp[0], shp[1], -1, 1) if x.dim() == 3 else x
         y = self.nhwc(ops.nchw_to_nhwc(x4.contiguous()))
-        return ops.nhwc_to_nchw(y, dtype=x.dtype).reshape(shp)
+        return ops.nhwc_to_nchw(y, dtype=ops.io_dtype(x)).to(x.dtype).reshape(shp)
 
 
 class LayerNorm(nn.LayerNorm, _Packed):
@@ -98,13 +135,13 @@ class LayerNorm(nn.LayerNorm, _Packed):
         return self._packed(lambda: (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous()),
                             self.weight, self.bias)
 
-    def nhwc(self, x, a=None, b=None):
+    def nhwc(self, x, a=None, b=None, split=1):
         if a is None and b is None:
             a, b = self._affine()
-        return ops.layer_norm(x, a, b, self.eps)
+        return ops.layer_norm(x, a, b, self.eps, split=split)
 
     def forward(self, x):
-        return self.nhwc(x.to(ops.act_dtype()).contiguous()).to(x.dtype)
+        return self.nhwc(x.to(ops.stream_dtype()).contiguous()).to(x.dtype)
 
 
 class RMSNormWeight(nn.Module):

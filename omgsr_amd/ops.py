@@ -2,7 +2,15 @@
 
 torch is used for device memory and streams only: every function here validates shapes, allocates
 the output with torch.empty and launches a hand-written gfx950 kernel on torch's current stream.
-Activations are bf16, channels-last ([N, H, W, C]; token matrices are [B, L, C]).
+Activations are channels-last ([N, H, W, C]; token matrices are [B, L, C]).
+
+Two tensor classes (include/omgsr_hip.h, OMGSR_EL_*):
+  operand tensors  feed an MFMA: the 16-bit compute type `act_dtype()`; optionally the two-term split
+                   x = hi + lo stored as [hi (C) | lo (C)] per row (`split=2`), consumed by a weight packed with
+                   duplicated input channels, so the fp32 accumulator receives hi*W + lo*W
+  stream tensors   everything between two GEMMs: `stream_dtype()` = the compute type in the fast tiers
+                   (--weight_dtype bf16 | fp16), fp32 in the accurate tier (--weight_dtype fp32)
+Every function dispatches on the dtype of the tensors it is handed.
 """
 from __future__ import annotations
 
@@ -16,30 +24,68 @@ from . import _lib
 from ._lib import AttnArgs, IgemmArgs, check
 
 ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_GEGLU = 0, 1, 2, 3
-OUT_BF16, OUT_F32 = 0, 1
+OUT_STREAM, OUT_BF16, OUT_F32 = -1, 0, 1      # conv / linear outputs: stream tensor (default) | 16-bit operand | fp32
 LAYOUT_NHWC, LAYOUT_T = 0, 1
+EL_16, EL_F32, EL_SPLIT = 0, 1, 2
 
 
 _ACT = torch.bfloat16
+_PRECISE = False
 
 
 def act_dtype() -> torch.dtype:
-    """The 16-bit element type of every activation / packed weight (bf16 default, fp16 optional)."""
+    """The 16-bit element type of every MFMA operand / packed weight (bf16 default, fp16 optional)."""
     return _ACT
 
 
+def stream_dtype() -> torch.dtype:
+    """Element type of the tensors between GEMMs: the compute type, or fp32 in the accurate tier."""
+    return torch.float32 if _PRECISE else _ACT
+
+
+def precise() -> bool:
+    return _PRECISE
+
+
+def mode_key() -> tuple:
+    """Cache key of anything derived from weights under the current tier."""
+    return (_ACT, _PRECISE)
+
+
 def set_compute_dtype(dtype: torch.dtype) -> None:
-    """Process-wide switch (omgsr_set_compute_dtype): packed-weight caches are keyed on it and rebuild lazily."""
-    global _ACT
-    if dtype not in (torch.bfloat16, torch.float16):
-        raise TypeError(f"compute dtype must be act_dtype() or torch.float16, got {dtype}")
-    check(_lib.load().omgsr_set_compute_dtype(0 if dtype == torch.bfloat16 else 1), "set_compute_dtype")
-    _ACT = dtype
+    """Process-wide tier switch; packed-weight caches are keyed on it and rebuild lazily. Mirrors the reference's
+    --weight_dtype (infer/infer_omgsr_s.py:134-149):
+      bf16 / fp16  fast tiers: operands AND stream tensors in that 16-bit type (omgsr_set_compute_dtype)
+      fp32         accurate tier: fp32 stream tensors, fp16 MFMA operands with fp32 accumulation, two-term split
+                   operands on the layers a precision policy names (omgsr_amd.precision)"""
+    global _ACT, _PRECISE
+    if dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise TypeError(f"compute dtype must be bfloat16, float16 or float32, got {dtype}")
+    act = torch.bfloat16 if dtype == torch.bfloat16 else torch.float16
+    check(_lib.load().omgsr_set_compute_dtype(0 if act == torch.bfloat16 else 1), "set_compute_dtype")
+    _ACT, _PRECISE = act, dtype == torch.float32
+
+
+def compute_dtype_name() -> str:
+    return "fp32" if _PRECISE else ("bf16" if _ACT == torch.bfloat16 else "fp16")
 
 
 def io_dtype(x: torch.Tensor) -> torch.dtype:
     """Boundary dtype the kernels can write directly for a caller holding `x`: f32 stays f32, else the compute dtype."""
     return torch.float32 if x.dtype == torch.float32 else _ACT
+
+
+def _el(t: torch.Tensor, name: str) -> int:
+    """Element kind of a stream-or-operand tensor argument."""
+    if not t.is_cuda:
+        raise _lib.OmgsrError(f"{name}: tensor is on {t.device}; the OMGSR HIP path runs on an MI355X only")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if t.dtype == torch.float32:
+        return EL_F32
+    if t.dtype != _ACT:
+        raise TypeError(f"{name}: expected {_ACT} or float32, got {t.dtype}")
+    return EL_16
 
 
 def _stream() -> int:
@@ -89,6 +135,7 @@ class PackedWeight:
     S: int
     geglu: bool = False
     w_cm: Optional[torch.Tensor] = None   # chunk-major second packing (3x3, Cin % 32 == 0): halo-tile kernel
+    split: int = 1     # 2: the input is a two-term split operand; `cin` counts both halves (every input channel packed twice)
 
     @property
     def cout_pad(self) -> int:
@@ -99,7 +146,8 @@ class PackedWeight:
         return self.w.shape[1]
 
 
-def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, cout_multiple: int = 1) -> PackedWeight:
+def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, cout_multiple: int = 1,
+                     split: int = 1) -> PackedWeight:
     """[Cout, Cin, R, S] (torch conv layout) -> [Cout_pad, roundup(R*S*Cin8, 32)] bf16, k = (r*S+s)*Cin8 + c.
     cout_multiple=8 widens the LOGICAL output to a multiple of 8 channels (zero weights, zero bias) so a
     3/4-channel conv writes 16-byte rows that the next kernel can consume directly."""
@@ -115,6 +163,9 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
     w = weight.detach().to(device=dev, dtype=torch.float32).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
     if cin8 != cin:
         w = torch.nn.functional.pad(w, (0, cin8 - cin))
+    if split == 2:          # [hi (cin8) | lo (cin8)] operand rows: both halves meet the same weights
+        w = torch.cat([w, w], dim=-1)
+        cin8 *= 2
     w = w.reshape(cout, R * S * cin8)
     k_pad = _round_up(w.shape[1], 32)
     cout_pad = _round_up(cout, 256 if cout >= 256 else 128)   # 256-row padding lets the 256x256 GEMM tile run
@@ -126,15 +177,15 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
         # slice-major: [Cin/32][9 taps][Cout_pad][32] - the 128 x 32 weight slice of one (chunk, tap) K-step is one
         # contiguous 8 KB run, so every LDS-DMA wave instruction reads 8 full 128-B lines
         w_cm = out.view(cout_pad, 9, cin8 // 32, 32).permute(2, 1, 0, 3).contiguous()
-    return PackedWeight(out, b, cout, cin8, R, S, w_cm=w_cm)
+    return PackedWeight(out, b, cout, cin8, R, S, w_cm=w_cm, split=split)
 
 
-def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None) -> PackedWeight:
+def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, split: int = 1) -> PackedWeight:
     """[out, in] -> 1x1 'conv' weight."""
-    return pack_conv_weight(weight[:, :, None, None], bias, device)
+    return pack_conv_weight(weight[:, :, None, None], bias, device, split=split)
 
 
-def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None) -> PackedWeight:
+def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, split: int = 1) -> PackedWeight:
     """GEGLU projection [2*inner, in] (rows [a | gate], diffusers `chunk(2, -1)`) -> rows interleaved in
     blocks of 32: [a_0..31, g_0..31, a_32..63, g_32..63, ...] so one 64-wide wave tile holds both halves."""
     two_inner, cin = weight.shape
@@ -143,7 +194,7 @@ def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device
         raise ValueError("GEGLU inner dim must be a multiple of 32")
     a, g = weight[:inner], weight[inner:]
     w = torch.stack([a.reshape(inner // 32, 32, cin), g.reshape(inner // 32, 32, cin)], dim=1).reshape(two_inner, cin)
-    pw = pack_linear_weight(w, None, device)
+    pw = pack_linear_weight(w, None, device, split=split)
     if bias is not None:
         ba, bg = bias[:inner], bias[inner:]
         b = torch.stack([ba.reshape(-1, 32), bg.reshape(-1, 32)], dim=1).reshape(two_inner)
@@ -156,13 +207,51 @@ def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device
 # --------------------------------------------------------------------------------------------
 # K1-K3, K5, K6: implicit-GEMM conv / linear / bmm
 
+def to_operand(x: torch.Tensor, split: int = 1) -> torch.Tensor:
+    """Stream tensor -> MFMA operand [..., split*C]: a no-op for a tensor already in the compute type (fast tiers),
+    one rounding (split 1) or the two-term split [hi | lo] (split 2) of an fp32 stream tensor."""
+    if x.dtype == _ACT:
+        if split != 1:
+            raise ValueError("to_operand: a 16-bit tensor cannot be split (split operands exist in the accurate tier only)")
+        return x
+    _req(x, torch.float32, "x")
+    Cc = x.shape[-1]
+    y = torch.empty((*x.shape[:-1], split * Cc), device=x.device, dtype=_ACT)
+    check(_lib.load().omgsr_to_operand(x.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc, EL_SPLIT if split == 2 else EL_16, _stream()),
+          "omgsr_to_operand")
+    return y
+
+
+def _out_tensor(shape, cout: int, out_dtype: int, out_split: int, device) -> torch.Tensor:
+    if out_dtype == OUT_STREAM:
+        out_dtype = OUT_F32 if _PRECISE else OUT_BF16
+        if out_split != 1:
+            raise ValueError("out_split applies to operand outputs (out_dtype=OUT_BF16)")
+    if out_dtype == OUT_F32:
+        return torch.empty((*shape, cout), device=device, dtype=torch.float32)
+    return torch.empty((*shape, cout * out_split), device=device, dtype=_ACT)
+
+
+def _fill_out(a: IgemmArgs, out: torch.Tensor, out_split: int, residual: Optional[torch.Tensor], cout: int) -> None:
+    a.out = out.data_ptr()
+    a.out_dtype = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
+    a.out_lo_off = cout if out_split == 2 else 0
+    if residual is not None:
+        a.residual = residual.data_ptr()
+        a.res_el = _el(residual, "residual")
+
+
 def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, int, int] | int = 1,
            upsample: bool = False, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
-           gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_BF16, alpha: float = 1.0,
-           out: Optional[torch.Tensor] = None, gn_groups: int = 0) -> torch.Tensor:
-    """x [N,H,W,Cin] bf16 -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on the (virtual) input.
+           gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_STREAM, alpha: float = 1.0,
+           out: Optional[torch.Tensor] = None, gn_groups: int = 0, out_split: int = 1) -> torch.Tensor:
+    """x [N,H,W,Cin] operand (or a stream tensor: cast / split here) -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on
+    the (virtual) input. out_dtype: OUT_STREAM (a stream tensor: default), OUT_BF16 (a 16-bit operand for the next GEMM,
+    `out_split` 2 = written as the two-term split) or OUT_F32. residual: a stream tensor of the output's shape.
     gn_groups > 0: the caller will GroupNorm the result with that many groups; when the kernel can, it emits the
     (sum, sum of squares) partials from its epilogue and group_norm_stats() skips its read pass over the tensor."""
+    if x.dtype == torch.float32:
+        x = to_operand(x, pw.split)
     _req(x, act_dtype(), "x")
     N, H, W, Cin = x.shape
     if Cin != pw.cin:
@@ -176,26 +265,25 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     if pw.geglu:
         act = ACT_GEGLU
     if out is None:
-        out = torch.empty((N, Ho, Wo, pw.cout), device=x.device,
-                          dtype=act_dtype() if out_dtype == OUT_BF16 else torch.float32)
-    if residual is not None:
-        _req(residual, act_dtype(), "residual")
-        if residual.shape != out.shape:
-            raise ValueError(f"residual shape {tuple(residual.shape)} != output {tuple(out.shape)}")
+        out = _out_tensor((N, Ho, Wo), pw.cout, out_dtype, out_split, x.device)
+    if residual is not None and tuple(residual.shape) != (N, Ho, Wo, pw.cout):
+        raise ValueError(f"residual shape {tuple(residual.shape)} != output {(N, Ho, Wo, pw.cout)}")
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
-    a.residual, a.out = _ptr(residual), out.data_ptr()
+    _fill_out(a, out, out_split, residual, pw.cout)
     a.weight_cm = _ptr(pw.w_cm)
     a.N, a.H, a.W, a.Cin = N, H, W, Cin
     a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
     a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = pw.R, pw.S, stride, pt, pl, int(upsample)
     a.Ho, a.Wo = Ho, Wo
-    a.act, a.out_dtype, a.out_layout = act, out_dtype, LAYOUT_NHWC
+    a.act, a.out_layout = act, LAYOUT_NHWC
     a.t_rows, a.t_ld = 0, 0
+    a.out_ld = out.shape[-1] if out_split == 2 else 0
     a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
     a.alpha = alpha
+    a.in_split = int(pw.split == 2)
     partial = None
-    if gn_groups > 0:
+    if gn_groups > 0 and out_split == 1:
         a.gn_groups = gn_groups
         lib = _lib.load()
         # a problem that _igemm will split over K (it hands over the workspace) finishes in the reduce pass: no statistics there
@@ -211,8 +299,9 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
 
 
 def linear(x: torch.Tensor, pw: PackedWeight, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
-           gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_BF16, alpha: float = 1.0, gn_groups: int = 0) -> torch.Tensor:
-    """x [..., K] bf16 -> [..., Cout]. gn_groups > 0 (x [B, ..., K]): the result feeds a GroupNorm over each x[b]; the GEMM
+           gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_STREAM, alpha: float = 1.0, gn_groups: int = 0,
+           out_split: int = 1) -> torch.Tensor:
+    """x [..., K] -> [..., Cout]. gn_groups > 0 (x [B, ..., K]): the result feeds a GroupNorm over each x[b]; the GEMM
     then runs as B images of prod(...) rows so its epilogue can leave the per-image statistics (see conv2d)."""
     lead = x.shape[:-1]
     M = 1
@@ -221,8 +310,9 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, act: int = ACT_NONE, residual: 
     B = lead[0] if (gn_groups > 0 and len(lead) >= 2) else 1
     x2 = x.reshape(B, 1, M // B, x.shape[-1])
     r2 = None if residual is None else residual.reshape(B, 1, M // B, pw.cout)
-    y = conv2d(x2, pw, stride=1, pad=0, act=act, residual=r2, gate=gate, out_dtype=out_dtype, alpha=alpha, gn_groups=gn_groups)
-    out = y.reshape(*lead, pw.cout)
+    y = conv2d(x2, pw, stride=1, pad=0, act=act, residual=r2, gate=gate, out_dtype=out_dtype, alpha=alpha, gn_groups=gn_groups,
+               out_split=out_split)
+    out = y.reshape(*lead, y.shape[-1])
     carry_gn(y, out)
     return out
 
@@ -236,37 +326,49 @@ def carry_gn(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
 
 
 def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int, col0: int, *, act: int = ACT_NONE,
-                residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None) -> None:
+                residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, out_split: int = 1,
+                lo_col0: Optional[int] = None) -> None:
     """out[row0:row0+M, col0:col0+Cout] = epilogue(x @ W^T): writes a projection straight into a slice of a
-    larger 2-D token buffer `out` [rows, ld] (joint text+image sequences, [attn | mlp] concat)."""
+    larger 2-D operand buffer `out` [rows, ld] (joint text+image sequences, [attn | mlp] concat). out_split 2: the low
+    halves of the two-term split go to columns lo_col0 ... lo_col0+Cout of the same rows (default col0 + Cout)."""
+    if x.dtype == torch.float32:
+        x = to_operand(x, pw.split)
     _req(x, act_dtype(), "x"); _req(out, act_dtype(), "out")
     M, K = x.numel() // x.shape[-1], x.shape[-1]
     ld = out.shape[-1]
     if K != pw.cin or out.dim() != 2 or row0 + M > out.shape[0] or col0 + pw.cout > ld or (col0 & 7):
         raise ValueError("linear_into: slice does not fit")
-    if residual is not None:
-        _req(residual, act_dtype(), "residual")
-        if residual.numel() != M * pw.cout:
-            raise ValueError("linear_into: residual must be a dense [M, Cout]")
+    if residual is not None and residual.numel() != M * pw.cout:
+        raise ValueError("linear_into: residual must be a dense [M, Cout]")
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
-    a.residual, a.out = _ptr(residual), out.data_ptr() + 2 * (row0 * ld + col0)
+    a.out = out.data_ptr() + 2 * (row0 * ld + col0)
+    a.out_dtype = OUT_BF16
+    if out_split == 2:
+        a.out_lo_off = (lo_col0 - col0) if lo_col0 is not None else pw.cout
+        if a.out_lo_off < pw.cout or col0 + a.out_lo_off + pw.cout > ld:
+            raise ValueError("linear_into: the low halves do not fit the row")
+    if residual is not None:
+        a.residual, a.res_el = residual.data_ptr(), _el(residual, "residual")
     a.N, a.H, a.W, a.Cin = 1, 1, M, K
     a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
     a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
     a.Ho, a.Wo = 1, M
-    a.act, a.out_dtype, a.out_layout = act, OUT_BF16, LAYOUT_NHWC
+    a.act, a.out_layout = act, LAYOUT_NHWC
     a.out_ld = ld
     a.batch, a.alpha = 1, 1.0
+    a.in_split = int(pw.split == 2)
     _igemm(a, x.device, "omgsr_igemm(linear_into)")
 
 
 def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: int) -> None:
     """out_t[n, key0 + l] = (x W^T + b)[l, n] for x [L, K]: transposed projection into a slice of a joint
     V^T buffer [Cout, ld]."""
+    if x.dtype == torch.float32:
+        x = to_operand(x, pw.split)
     _req(x, act_dtype(), "x"); _req(out_t, act_dtype(), "out_t")
     L, K = x.numel() // x.shape[-1], x.shape[-1]
-    if out_t.dim() != 2 or out_t.shape[0] != pw.cout or key0 + L > out_t.shape[1]:
+    if out_t.dim() != 2 or out_t.shape[0] != pw.cout or key0 + L > out_t.shape[1] or K != pw.cin:
         raise ValueError("linear_t_into: slice does not fit")
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.out = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), out_t.data_ptr() + 2 * key0
@@ -277,16 +379,19 @@ def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: 
     a.act, a.out_dtype, a.out_layout = ACT_NONE, OUT_BF16, LAYOUT_T
     a.t_rows, a.t_ld = L, out_t.shape[1]
     a.batch, a.alpha = 1, 1.0
+    a.in_split = int(pw.split == 2)
     check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_t_into)")
 
 
 def linear_t(x: torch.Tensor, pw: PackedWeight, rows_per_batch: int, ld: Optional[int] = None) -> torch.Tensor:
     """Transposed-output projection: x [B, L, K] -> out [B, Cout, ld] with out[b, n, l] = (x W^T + bias)[b, l, n].
     This is how V reaches omgsr_attention (key index contiguous). Columns l >= L are zero."""
+    if x.dtype == torch.float32:
+        x = to_operand(x, pw.split)
     _req(x, act_dtype(), "x")
     B, L, K = x.shape
-    if L != rows_per_batch:
-        raise ValueError("rows_per_batch mismatch")
+    if L != rows_per_batch or K != pw.cin:
+        raise ValueError("linear_t: shape mismatch")
     ld = ld or _round_up(L, 8)
     out = torch.zeros((B, pw.cout, ld), device=x.device, dtype=act_dtype()) if ld != L else \
         torch.empty((B, pw.cout, ld), device=x.device, dtype=act_dtype())
@@ -300,13 +405,15 @@ def linear_t(x: torch.Tensor, pw: PackedWeight, rows_per_batch: int, ld: Optiona
     a.t_rows, a.t_ld = L, ld
     a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
     a.alpha = 1.0
+    a.in_split = int(pw.split == 2)
     check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_t)")
     return out
 
 
-def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_dtype: int = OUT_BF16) -> torch.Tensor:
-    """out[b] = alpha * a[b] @ b[b]^T ; a [B, M, K], b [B, Npad, K] bf16 with Npad % 128 == 0, K % 32 == 0.
-    Returns [B, M, Npad]. (d=512 VAE attention scores / PV product.)"""
+def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_dtype: int = OUT_BF16, out_split: int = 1) -> torch.Tensor:
+    """out[b] = alpha * a[b] @ b[b]^T ; a [B, M, K], b [B, Npad, K] operands with Npad % 128 == 0, K % 32 == 0.
+    Returns [B, M, Npad] (OUT_F32: fp32; OUT_BF16: a 16-bit operand, [B, M, 2*Npad] as a two-term split when out_split 2).
+    (d=512 VAE attention scores / PV product.)"""
     _req(a_mat, act_dtype(), "a")
     _req(b_mat, act_dtype(), "b")
     B, M, K = a_mat.shape
@@ -316,8 +423,13 @@ def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_
     if Np % 128:    # reduced test configs only (the real VAE has 512 channels / 128-padded key counts)
         bp = torch.zeros((B, _round_up(Np, 128), K), device=b_mat.device, dtype=act_dtype())
         bp[:, :Np] = b_mat
-        return bmm_nt(a_mat, bp, alpha=alpha, out_dtype=out_dtype)[:, :, :Np].contiguous()
-    out = torch.empty((B, M, Np), device=a_mat.device, dtype=act_dtype() if out_dtype == OUT_BF16 else torch.float32)
+        full = bmm_nt(a_mat, bp, alpha=alpha, out_dtype=out_dtype, out_split=out_split)
+        Npp = bp.shape[1]
+        if out_split == 2 and out_dtype == OUT_BF16:
+            return torch.cat([full[:, :, :Np], full[:, :, Npp:Npp + Np]], dim=-1).contiguous()
+        return full[:, :, :Np].contiguous()
+    split = out_split if out_dtype == OUT_BF16 else 1
+    out = torch.empty((B, M, Np * split), device=a_mat.device, dtype=act_dtype() if out_dtype == OUT_BF16 else torch.float32)
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate, a.residual, a.out = a_mat.data_ptr(), b_mat.data_ptr(), None, None, None, out.data_ptr()
     a.N, a.H, a.W, a.Cin = 1, 1, M, K
@@ -326,7 +438,9 @@ def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_
     a.Ho, a.Wo = 1, M
     a.act, a.out_dtype, a.out_layout = ACT_NONE, out_dtype, LAYOUT_NHWC
     a.t_rows, a.t_ld = 0, 0
-    a.batch, a.in_bstride, a.w_bstride, a.out_bstride = B, M * K, Np * K, M * Np
+    a.out_lo_off = Np if split == 2 else 0
+    a.out_ld = Np * split if split == 2 else 0
+    a.batch, a.in_bstride, a.w_bstride, a.out_bstride = B, M * K, Np * K, M * Np * split
     a.alpha = alpha
     check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(bmm_nt)")
     return out
@@ -335,42 +449,48 @@ def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_
 # --------------------------------------------------------------------------------------------
 # K4: GroupNorm
 
+def _fused_gn(x: torch.Tensor, groups: int, N: int):
+    fused = getattr(x, "_omgsr_gn", None)
+    if fused is not None and fused[1] == groups and fused[2] == x.data_ptr() and fused[3] == x._version and fused[0].shape[0] == N:
+        return fused[0]
+    return None
+
+
 def group_norm_stats(x: torch.Tensor, groups: int, eps: float):
-    """x [N, ..., C] bf16 -> (mean [N,G], rstd [N,G], var [N,G]) f32 (biased variance)."""
-    _req(x, act_dtype(), "x")
+    """x [N, ..., C] stream tensor -> (mean [N,G], rstd [N,G], var [N,G]) f32 (biased variance)."""
+    xel = _el(x, "x")
     N, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * Cc)
     lib = _lib.load()
     mean = torch.empty((N, groups), device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     var = torch.empty_like(mean)
-    fused = getattr(x, "_omgsr_gn", None)
-    if fused is not None and fused[1] == groups and fused[2] == x.data_ptr() and fused[3] == x._version \
-            and fused[0].shape[0] == N:
+    fused = _fused_gn(x, groups, N)
+    if fused is not None:
         # the producing conv already reduced this tensor (omgsr_igemm gn_partial): fold its partials only
-        check(lib.omgsr_groupnorm_finalize(fused[0].data_ptr(), mean.data_ptr(), rstd.data_ptr(), var.data_ptr(), N,
-                                           fused[0].shape[1], groups, fused[0].shape[2], float(HW) * (Cc // groups), eps, _stream()),
+        check(lib.omgsr_groupnorm_finalize(fused.data_ptr(), mean.data_ptr(), rstd.data_ptr(), var.data_ptr(), N,
+                                           fused.shape[1], groups, fused.shape[2], float(HW) * (Cc // groups), eps, _stream()),
               "omgsr_groupnorm_finalize")
         return mean, rstd, var
     nchunk = lib.omgsr_groupnorm_nchunk(HW)
     partial = torch.empty((N, nchunk, groups, 2), device=x.device, dtype=torch.float32)
     check(lib.omgsr_groupnorm_stats(x.data_ptr(), partial.data_ptr(), mean.data_ptr(), rstd.data_ptr(), var.data_ptr(),
-                                    N, HW, Cc, groups, eps, _stream()), "omgsr_groupnorm_stats")
+                                    N, HW, Cc, groups, eps, xel, _stream()), "omgsr_groupnorm_stats")
     return mean, rstd, var
 
 
 def group_norm_partial(x: torch.Tensor, groups: int) -> torch.Tensor:
     """(sum, sum of squares) partials [N, nslot, G, 2] of x: the producing conv's fused ones when it left them
     (conv2d gn_groups), else one read pass over x."""
-    _req(x, act_dtype(), "x")
+    xel = _el(x, "x")
     N, Cc = x.shape[0], x.shape[-1]
-    fused = getattr(x, "_omgsr_gn", None)
-    if fused is not None and fused[1] == groups and fused[2] == x.data_ptr() and fused[3] == x._version and fused[0].shape[0] == N:
-        return fused[0]
+    fused = _fused_gn(x, groups, N)
+    if fused is not None:
+        return fused
     HW = x.numel() // (N * Cc)
     lib = _lib.load()
     partial = torch.empty((N, lib.omgsr_groupnorm_nchunk(HW), groups, 2), device=x.device, dtype=torch.float32)
-    check(lib.omgsr_groupnorm_partial(x.data_ptr(), partial.data_ptr(), N, HW, Cc, groups, _stream()), "omgsr_groupnorm_partial")
+    check(lib.omgsr_groupnorm_partial(x.data_ptr(), partial.data_ptr(), N, HW, Cc, groups, xel, _stream()), "omgsr_groupnorm_partial")
     return partial
 
 
@@ -401,44 +521,55 @@ def group_norm_stats_merged(tensors, tiles, N: int, groups: int, eps: float):
     return mean, rstd, var
 
 
+def _operand_like(x: torch.Tensor, split: int) -> torch.Tensor:
+    if split not in (1, 2):
+        raise ValueError("split must be 1 or 2")
+    return torch.empty((*x.shape[:-1], x.shape[-1] * split), device=x.device, dtype=_ACT)
+
+
 def group_norm_apply_shared(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma, beta, groups: int,
-                            act: int = ACT_NONE) -> torch.Tensor:
+                            act: int = ACT_NONE, split: int = 1) -> torch.Tensor:
     """x [T*N, ..., C] tile-major; mean / rstd [N, G]: row r is normalised with the statistics of image r % N."""
-    _req(x, act_dtype(), "x")
+    xel = _el(x, "x")
     rows, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (rows * Cc)
-    y = torch.empty_like(x)
+    y = _operand_like(x, split)
     check(_lib.load().omgsr_groupnorm_apply_shared(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
-                                                   _ptr(beta), rows, HW, Cc, groups, act, mean.shape[0], _stream()),
+                                                   _ptr(beta), rows, HW, Cc, groups, act, mean.shape[0], xel,
+                                                   EL_SPLIT if split == 2 else EL_16, _stream()),
           "omgsr_groupnorm_apply_shared")
     return y
 
 
 def group_norm_apply(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: Optional[torch.Tensor],
-                     beta: Optional[torch.Tensor], groups: int, act: int = ACT_NONE, inplace: bool = False) -> torch.Tensor:
-    _req(x, act_dtype(), "x")
+                     beta: Optional[torch.Tensor], groups: int, act: int = ACT_NONE, inplace: bool = False, split: int = 1) -> torch.Tensor:
+    """Stream tensor -> normalised (+SiLU) MFMA operand [..., split*C]."""
+    xel = _el(x, "x")
     N, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * Cc)
-    y = x if inplace else torch.empty_like(x)
+    y = x if (inplace and xel == EL_16 and split == 1) else _operand_like(x, split)
     check(_lib.load().omgsr_groupnorm_apply(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
-                                            _ptr(beta), N, HW, Cc, groups, act, _stream()), "omgsr_groupnorm_apply")
+                                            _ptr(beta), N, HW, Cc, groups, act, xel, EL_SPLIT if split == 2 else EL_16, _stream()),
+          "omgsr_groupnorm_apply")
     return y
 
 
-def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, act: int = ACT_NONE) -> torch.Tensor:
+def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, act: int = ACT_NONE, split: int = 1) -> torch.Tensor:
     mean, rstd, _ = group_norm_stats(x, groups, eps)
-    return group_norm_apply(x, mean, rstd, gamma, beta, groups, act)
+    return group_norm_apply(x, mean, rstd, gamma, beta, groups, act, split=split)
 
 
 # --------------------------------------------------------------------------------------------
 # K9/K10: LayerNorm (affine or AdaLN-modulated)
 
-def layer_norm(x: torch.Tensor, a: Optional[torch.Tensor], b: Optional[torch.Tensor], eps: float) -> torch.Tensor:
-    _req(x, act_dtype(), "x")
+def layer_norm(x: torch.Tensor, a: Optional[torch.Tensor], b: Optional[torch.Tensor], eps: float, split: int = 1) -> torch.Tensor:
+    """Stream tensor rows -> normalised MFMA operand [..., split*C]."""
+    xel = _el(x, "x")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
-    y = torch.empty_like(x)
-    check(_lib.load().omgsr_layernorm(x.data_ptr(), y.data_ptr(), _ptr(a), _ptr(b), rows, Cc, eps, _stream()), "omgsr_layernorm")
+    y = _operand_like(x, split)
+    check(_lib.load().omgsr_layernorm(x.data_ptr(), y.data_ptr(), _ptr(a), _ptr(b), rows, Cc, eps, xel,
+                                      EL_SPLIT if split == 2 else EL_16, _stream()), "omgsr_layernorm")
     return y
 
 
@@ -447,8 +578,9 @@ def layer_norm(x: torch.Tensor, a: Optional[torch.Tensor], b: Optional[torch.Ten
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, head_dim: int, scale: float,
               *, q_col: int = 0, k_col: int = 0, Lk: Optional[int] = None, out: Optional[torch.Tensor] = None,
-              o_col: int = 0) -> torch.Tensor:
-    """q [B, Lq, *] (heads at columns q_col + h*D), k [Bk, Lk, *], vt [Bk, heads*D, ld] -> o [B, Lq, heads*D].
+              o_col: int = 0, out_split: int = 1, o_lo_col: Optional[int] = None) -> torch.Tensor:
+    """q [B, Lq, *] (heads at columns q_col + h*D), k [Bk, Lk, *], vt [Bk, heads*D, ld] -> o [B, Lq, heads*D]
+    (an operand for the output projection; out_split 2: [B, Lq, 2*heads*D] as the two-term split).
     Bk == 1 broadcasts one K/V over the batch (constant cross-attention context)."""
     _req(q, act_dtype(), "q"); _req(k, act_dtype(), "k"); _req(vt, act_dtype(), "vt")
     B, Lq = q.shape[0], q.shape[1]
@@ -456,7 +588,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, he
     Lk = Lk if Lk is not None else k.shape[1]
     inner = heads * head_dim
     if out is None:
-        out = torch.empty((B, Lq, inner), device=q.device, dtype=act_dtype())
+        out = torch.empty((B, Lq, inner * out_split), device=q.device, dtype=act_dtype())
     a = AttnArgs()
     esz = 2
     a.q = q.data_ptr() + q_col * esz
@@ -470,6 +602,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, he
     a.vt_bstride = 0 if Bk == 1 and B > 1 else vt.shape[1] * vt.shape[-1]
     a.o_bstride = Lq * out.shape[-1]
     a.scale = scale
+    a.o_lo_off = 0 if out_split != 2 else ((o_lo_col - o_col) if o_lo_col is not None else inner)
     check(_lib.load().omgsr_attention(C.byref(a), _stream()), "omgsr_attention")
     return out
 
@@ -492,6 +625,8 @@ def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos: Optional[torch.Tensor],
     B, L, ld = x.shape
     if tuple(w.shape) != (heads, head_dim):
         raise ValueError(f"rmsnorm_rope_: w must be [{heads}, {head_dim}], got {tuple(w.shape)}")
+    if cos is not None and (cos.shape[0] < pos0 + L or sin.shape[0] < pos0 + L or cos.shape[-1] != head_dim):
+        raise ValueError(f"rmsnorm_rope_: rope tables {tuple(cos.shape)} do not cover positions {pos0}..{pos0 + L - 1} x {head_dim}")
     check(_lib.load().omgsr_rmsnorm_rope(x.data_ptr(), w.data_ptr(), _ptr(cos), _ptr(sin), B, L, heads, head_dim, ld,
                                          col0, pos0, eps, _stream()), "omgsr_rmsnorm_rope")
     return x
@@ -500,22 +635,24 @@ def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos: Optional[torch.Tensor],
 # --------------------------------------------------------------------------------------------
 # K14: layout + latent algebra
 
-def nchw_to_nhwc(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+def nchw_to_nhwc(x: torch.Tensor, cpad: Optional[int] = None, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """NCHW (f32 or the compute type) -> NHWC stream tensor (channels zero-padded to cpad); dtype overrides stream_dtype()."""
     if x.dtype not in (torch.float32, act_dtype()):
-        x = x.to(act_dtype())          # the other 16-bit type / f64: one conversion at the boundary
+        x = x.to(act_dtype() if not _PRECISE else torch.float32)          # the other 16-bit type / f64: one conversion at the boundary
     _req(x, x.dtype, "x")
     N, Cc, H, W = x.shape
     cpad = cpad or _round_up(Cc, 8)
-    y = torch.empty((N, H, W, cpad), device=x.device, dtype=act_dtype())
-    check(_lib.load().omgsr_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), N, Cc, H, W, cpad, int(x.dtype == torch.float32), _stream()),
-          "omgsr_nchw_to_nhwc")
+    dtype = dtype or stream_dtype()
+    y = torch.empty((N, H, W, cpad), device=x.device, dtype=dtype)
+    check(_lib.load().omgsr_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), N, Cc, H, W, cpad, int(x.dtype == torch.float32),
+                                         EL_F32 if dtype == torch.float32 else EL_16, _stream()), "omgsr_nchw_to_nhwc")
     return y
 
 
 def nhwc_to_nchw(x: torch.Tensor, channels: Optional[int] = None, dtype=None,
                  clamp: Optional[tuple[float, float]] = None) -> torch.Tensor:
-    _req(x, act_dtype(), "x")
-    dtype = dtype or act_dtype()
+    xel = _el(x, "x")
+    dtype = dtype or (torch.float32 if xel == EL_F32 else act_dtype())
     if dtype not in (torch.float32, act_dtype()):
         raise TypeError(f"nhwc_to_nchw: output dtype must be float32 or {act_dtype()}, got {dtype}")
     N, H, W, ld = x.shape
@@ -523,39 +660,43 @@ def nhwc_to_nchw(x: torch.Tensor, channels: Optional[int] = None, dtype=None,
     y = torch.empty((N, Cc, H, W), device=x.device, dtype=dtype)
     lo, hi = clamp if clamp else (0.0, 0.0)
     check(_lib.load().omgsr_nhwc_to_nchw(x.data_ptr(), y.data_ptr(), N, Cc, H, W, ld, int(dtype == torch.float32),
-                                         int(clamp is not None), lo, hi, _stream()), "omgsr_nhwc_to_nchw")
+                                         int(clamp is not None), lo, hi, xel, _stream()), "omgsr_nhwc_to_nchw")
     return y
 
 
 def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """torch.cat([a, b], dim=channel) for NHWC bf16."""
-    _req(a, act_dtype(), "a"); _req(b, act_dtype(), "b")
+    """torch.cat([a, b], dim=channel) for two NHWC stream tensors of one element kind."""
+    el = _el(a, "a")
+    if _el(b, "b") != el:
+        raise TypeError("concat_channels: element kinds differ")
     Ca, Cb = a.shape[-1], b.shape[-1]
     rows = a.numel() // Ca
-    out = torch.empty((*a.shape[:-1], Ca + Cb), device=a.device, dtype=act_dtype())
+    out = torch.empty((*a.shape[:-1], Ca + Cb), device=a.device, dtype=a.dtype)
     lib = _lib.load()
-    check(lib.omgsr_copy_channels(a.data_ptr(), out.data_ptr(), rows, Ca, Ca, Ca + Cb, 0, _stream()), "omgsr_copy_channels")
-    check(lib.omgsr_copy_channels(b.data_ptr(), out.data_ptr(), rows, Cb, Cb, Ca + Cb, Ca, _stream()), "omgsr_copy_channels")
+    check(lib.omgsr_copy_channels(a.data_ptr(), out.data_ptr(), rows, Ca, Ca, Ca + Cb, 0, el, _stream()), "omgsr_copy_channels")
+    check(lib.omgsr_copy_channels(b.data_ptr(), out.data_ptr(), rows, Cb, Cb, Ca + Cb, Ca, el, _stream()), "omgsr_copy_channels")
     return out
 
 
 def vae_sample(moments: torch.Tensor, eps: torch.Tensor, latent_channels: int, shift: float, scale: float,
                ld_out: Optional[int] = None) -> torch.Tensor:
-    """moments [N,h,w,2C] bf16, eps [N,h,w,C] f32 -> z [N,h,w,ld_out] bf16 (zero padded channels)."""
-    _req(moments, act_dtype(), "moments"); _req(eps, torch.float32, "eps")
+    """moments [N,h,w,2C] stream, eps [N,h,w,C] f32 -> z [N,h,w,ld_out] stream of the same kind (zero padded channels)."""
+    el = _el(moments, "moments"); _req(eps, torch.float32, "eps")
     N, h, w, _ = moments.shape
     ld_out = ld_out or _round_up(latent_channels, 8)
-    z = torch.empty((N, h, w, ld_out), device=moments.device, dtype=act_dtype())
+    z = torch.empty((N, h, w, ld_out), device=moments.device, dtype=moments.dtype)
     check(_lib.load().omgsr_vae_sample(moments.data_ptr(), eps.data_ptr(), z.data_ptr(), N * h * w, latent_channels, ld_out,
-                                       shift, scale, _stream()), "omgsr_vae_sample")
+                                       shift, scale, el, _stream()), "omgsr_vae_sample")
     return z
 
 
 def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float, c: float = 0.0, d: float = 1.0,
           bf16_steps: bool = False) -> torch.Tensor:
-    _req(x, act_dtype(), "x")
+    el = _el(x, "x")
+    if y is not None and _el(y, "y") != el:
+        raise TypeError("axpby: element kinds differ")
     out = torch.empty_like(x)
-    check(_lib.load().omgsr_axpby(x.data_ptr(), _ptr(y), out.data_ptr(), x.numel(), a, b, c, d, int(bf16_steps), _stream()),
+    check(_lib.load().omgsr_axpby(x.data_ptr(), _ptr(y), out.data_ptr(), x.numel(), a, b, c, d, int(bf16_steps), el, _stream()),
           "omgsr_axpby")
     return out
 
@@ -566,56 +707,59 @@ def tile_accumulate(tile: Optional[torch.Tensor], w: torch.Tensor, acc: torch.Te
     _req(w, torch.float32, "w"); _req(acc, torch.float32, "acc")
     N, H, W, Cc = acc.shape
     th, tw = w.shape
-    tile_ld = 0
+    tile_ld, el = 0, EL_16
     if tile is not None:
-        _req(tile, act_dtype(), "tile")
+        el = _el(tile, "tile")
         tile_ld = tile.shape[-1]
     check(_lib.load().omgsr_tile_accumulate(_ptr(tile), w.data_ptr(), acc.data_ptr(), N, Cc, th, tw, tile_ld, H, W, y0, x0,
-                                            _stream()), "omgsr_tile_accumulate")
+                                            el, _stream()), "omgsr_tile_accumulate")
 
 
-def tile_normalise(acc: torch.Tensor, wsum: torch.Tensor, ld: Optional[int] = None) -> torch.Tensor:
+def tile_normalise(acc: torch.Tensor, wsum: torch.Tensor, ld: Optional[int] = None, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     N, H, W, Cc = acc.shape
     ld = ld or _round_up(Cc, 8)
-    out = torch.empty((N, H, W, ld), device=acc.device, dtype=act_dtype())
-    check(_lib.load().omgsr_tile_normalise(acc.data_ptr(), wsum.data_ptr(), out.data_ptr(), N, H * W, Cc, ld, _stream()),
-          "omgsr_tile_normalise")
+    dtype = dtype or stream_dtype()
+    out = torch.empty((N, H, W, ld), device=acc.device, dtype=dtype)
+    check(_lib.load().omgsr_tile_normalise(acc.data_ptr(), wsum.data_ptr(), out.data_ptr(), N, H * W, Cc, ld,
+                                           EL_F32 if dtype == torch.float32 else EL_16, _stream()), "omgsr_tile_normalise")
     return out
 
 
 def crop_nhwc(x: torch.Tensor, y0: int, x0: int, th: int, tw: int) -> torch.Tensor:
-    _req(x, act_dtype(), "x")
+    el = _el(x, "x")
     N, H, W, Cc = x.shape
-    out = torch.empty((N, th, tw, Cc), device=x.device, dtype=act_dtype())
-    check(_lib.load().omgsr_crop_nhwc(x.data_ptr(), out.data_ptr(), N, H, W, Cc, y0, x0, th, tw, _stream()), "omgsr_crop_nhwc")
+    out = torch.empty((N, th, tw, Cc), device=x.device, dtype=x.dtype)
+    check(_lib.load().omgsr_crop_nhwc(x.data_ptr(), out.data_ptr(), N, H, W, Cc, y0, x0, th, tw, el, _stream()), "omgsr_crop_nhwc")
     return out
 
 
 def paste_nhwc(src: torch.Tensor, dst: torch.Tensor, sy0: int, sx0: int, dy0: int, dx0: int, th: int, tw: int) -> None:
-    """dst[:, dy0:dy0+th, dx0:dx0+tw, :] = src[:, sy0:sy0+th, sx0:sx0+tw, :] (bf16 NHWC, same N and C)."""
-    _req(src, act_dtype(), "src"); _req(dst, act_dtype(), "dst")
+    """dst[:, dy0:dy0+th, dx0:dx0+tw, :] = src[:, sy0:sy0+th, sx0:sx0+tw, :] (NHWC, same N, C and element kind)."""
+    el = _el(src, "src")
+    if _el(dst, "dst") != el:
+        raise TypeError("paste_nhwc: element kinds differ")
     N, sH, sW, Cc = src.shape
     if dst.shape[0] != N or dst.shape[3] != Cc:
         raise ValueError("paste_nhwc: batch/channel mismatch")
     check(_lib.load().omgsr_paste_nhwc(src.data_ptr(), dst.data_ptr(), N, Cc, sH, sW, sy0, sx0, dst.shape[1], dst.shape[2],
-                                       dy0, dx0, th, tw, _stream()), "omgsr_paste_nhwc")
+                                       dy0, dx0, th, tw, el, _stream()), "omgsr_paste_nhwc")
 
 
 def flux_pack(x: torch.Tensor, channels: int) -> torch.Tensor:
     """NHWC [N,H,W,ld] (first `channels`) -> tokens [N, (H/2)(W/2), 4*channels]."""
-    _req(x, act_dtype(), "x")
+    el = _el(x, "x")
     N, H, W, ld = x.shape
-    out = torch.empty((N, (H // 2) * (W // 2), 4 * channels), device=x.device, dtype=act_dtype())
-    check(_lib.load().omgsr_flux_pack(x.data_ptr(), out.data_ptr(), N, H, W, channels, ld, 0, _stream()), "omgsr_flux_pack")
+    out = torch.empty((N, (H // 2) * (W // 2), 4 * channels), device=x.device, dtype=x.dtype)
+    check(_lib.load().omgsr_flux_pack(x.data_ptr(), out.data_ptr(), N, H, W, channels, ld, 0, el, _stream()), "omgsr_flux_pack")
     return out
 
 
 def flux_unpack(tok: torch.Tensor, H: int, W: int, ld: Optional[int] = None) -> torch.Tensor:
-    _req(tok, act_dtype(), "tok")
+    el = _el(tok, "tok")
     N, _, c4 = tok.shape
     Cc = c4 // 4
     ld = ld or _round_up(Cc, 8)
-    out = torch.zeros((N, H, W, ld), device=tok.device, dtype=act_dtype()) if ld != Cc else \
-        torch.empty((N, H, W, ld), device=tok.device, dtype=act_dtype())
-    check(_lib.load().omgsr_flux_pack(tok.data_ptr(), out.data_ptr(), N, H, W, Cc, ld, 1, _stream()), "omgsr_flux_pack")
+    out = torch.zeros((N, H, W, ld), device=tok.device, dtype=tok.dtype) if ld != Cc else \
+        torch.empty((N, H, W, ld), device=tok.device, dtype=tok.dtype)
+    check(_lib.load().omgsr_flux_pack(tok.data_ptr(), out.data_ptr(), N, H, W, Cc, ld, 1, el, _stream()), "omgsr_flux_pack")
     return out

@@ -52,8 +52,8 @@ def tile_grid(h: int, w: int, tile_size: int, tile_overlap: int) -> Tuple[int, L
 
 def tiled_denoise(latent_nhwc: torch.Tensor, channels: int, tile_size: int, tile_overlap: int,
                   denoise: Callable[[torch.Tensor], torch.Tensor], tiles_per_call: int = 16) -> torch.Tensor:
-    """latent_nhwc [B,h,w,C8] bf16; `denoise(tiles [n*B,t,t,C8]) -> [n*B,t,t,>=channels]`. Returns the
-    Gaussian-blended prediction [B,h,w,C8] bf16 (channels >= `channels` zero).
+    """latent_nhwc [B,h,w,C8] stream tensor; `denoise(tiles [n*B,t,t,C8]) -> [n*B,t,t,>=channels]`. Returns the
+    Gaussian-blended prediction [B,h,w,C8] of the same element kind (channels >= `channels` zero).
 
     The reference runs one denoiser call per tile (its "batching" never batches, SURVEY C-4). Tiles are
     independent samples, so here up to `tiles_per_call` tiles ride in ONE call along the batch axis — the
@@ -71,4 +71,4 @@ def tiled_denoise(latent_nhwc: torch.Tensor, channels: int, tile_size: int, tile
         for j, (oy, ox) in enumerate(group):
             ops.tile_accumulate(preds[j * B:(j + 1) * B].contiguous(), wts, acc, oy, ox)
             ops.tile_accumulate(None, wts, wsum, oy, ox)
-    return ops.tile_normalise(acc, wsum, ld=ld)
+    return ops.tile_normalise(acc, wsum, ld=ld, dtype=latent_nhwc.dtype)

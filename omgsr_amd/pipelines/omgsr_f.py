@@ -44,8 +44,7 @@ class OMGSR_F_Infer(torch.nn.Module):
                  mid_timestep: int = 244, guidance_scale: float = 1.0, vae: Optional[AutoencoderKL] = None,
                  flux_transformer: Optional[FluxTransformer2DModel] = None, verbose: bool = False):
         super().__init__()
-        if weight_dtype in (torch.bfloat16, torch.float16):       # --weight_dtype picks the kernels' 16-bit type
-            ops.set_compute_dtype(weight_dtype)
+        ops.set_compute_dtype(weight_dtype)       # --weight_dtype picks the tier (bf16 | fp16 fast, fp32 accurate: see OMGSR_S_Infer)
         if vae is None:
             vae = AutoencoderKL.from_pretrained(flux_path, subfolder="vae")
         if flux_transformer is None:
@@ -68,6 +67,9 @@ class OMGSR_F_Infer(torch.nn.Module):
         self.flux_transformer = flux_transformer.eval()
         self.device = device
         self.verbose = verbose
+        if weight_dtype == torch.float32:
+            from ..precision import apply_default_policy
+            apply_default_policy(vae=self.vae, flux=self.flux_transformer)
 
     def _init_tiled_vae(self, encoder_tile_size=256, decoder_tile_size=256, fast_decoder=False, fast_encoder=False,
                         color_fix=False, vae_to_gpu=True):
@@ -94,7 +96,7 @@ class OMGSR_F_Infer(torch.nn.Module):
         C = self.vae.config.latent_channels
         dt = self.t_prev - self.t_curr
         moments = self.vae.encode_moments_nhwc(lq_nhwc8)
-        post = DiagonalGaussianDistribution(moments, C, self.vae.posterior_noise, ops.act_dtype())
+        post = DiagonalGaussianDistribution(moments, C, self.vae.posterior_noise, ops.stream_dtype())
         z = post.sample_nhwc(shift=sh, scale=sf)                                  # [B,h,w,16]
         _, h, w, _ = z.shape
         if h * w <= tile_size * tile_size:

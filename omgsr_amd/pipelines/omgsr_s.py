@@ -29,8 +29,9 @@ class OMGSR_S_Infer(torch.nn.Module):
         (infer/omgsr_s_infer_model.py:11-25); `vae=` / `unet=` inject already-built modules instead
         (synthetic-weight benchmarks and tests — there are no checkpoints on the GPU box)."""
         super().__init__()
-        if weight_dtype in (torch.bfloat16, torch.float16):       # --weight_dtype picks the kernels' 16-bit type
-            ops.set_compute_dtype(weight_dtype)
+        # --weight_dtype picks the tier: bf16 / fp16 = that 16-bit type end to end; fp32 = the accurate tier (fp32 stream
+        # tensors, fp16 MFMA operands, two-term split operands where the precision policy says so)
+        ops.set_compute_dtype(weight_dtype)
         self.mid_timestep = mid_timestep
         self.verbose = verbose
         if vae is None:
@@ -47,6 +48,9 @@ class OMGSR_S_Infer(torch.nn.Module):
         self.vae = vae.to(device=device, dtype=weight_dtype).eval()
         self.unet = unet.to(device=device, dtype=weight_dtype).eval()
         self.device = device
+        if weight_dtype == torch.float32:
+            from ..precision import apply_default_policy
+            apply_default_policy(vae=self.vae, unet=self.unet)
 
     def _init_tiled_vae(self, encoder_tile_size=256, decoder_tile_size=256, fast_decoder=False, fast_encoder=False,
                         color_fix=False, vae_to_gpu=True):
@@ -59,7 +63,7 @@ class OMGSR_S_Infer(torch.nn.Module):
     # ---- NHWC hot path ---------------------------------------------------------------------
     @torch.no_grad()
     def sr_nhwc(self, lq_nhwc8: torch.Tensor, prompt_embeds: torch.Tensor, tile_size: int, tile_overlap: int) -> torch.Tensor:
-        """lq [B,H,W,8] bf16 (RGB + zero pad) -> image NHWC [B,H,W,8] bf16, UNCLAMPED."""
+        """lq [B,H,W,8] stream tensor (RGB + zero pad) -> image NHWC [B,H,W,8] stream tensor, UNCLAMPED."""
         sf = float(self.vae.config.scaling_factor)
         moments = self.vae.encode_moments_nhwc(lq_nhwc8)
         post = self.vae_posterior(moments)
@@ -82,7 +86,7 @@ class OMGSR_S_Infer(torch.nn.Module):
 
     def vae_posterior(self, moments):
         from ..diffusers_api.autoencoder_kl import DiagonalGaussianDistribution
-        return DiagonalGaussianDistribution(moments, self.vae.config.latent_channels, self.vae.posterior_noise, ops.act_dtype())
+        return DiagonalGaussianDistribution(moments, self.vae.config.latent_channels, self.vae.posterior_noise, ops.stream_dtype())
 
     # ---- reference API ---------------------------------------------------------------------
     @torch.no_grad()

@@ -68,16 +68,18 @@ class VAEHook:
         net, dec = self.net, self.is_decoder
         seq = [("f", lambda x: net.conv_in.nhwc(x, gn_groups=net.conv_norm_out.num_groups))]
 
+        # ("gn", norm, act, consumer): the normalised tensor is the consumer's MFMA operand (its in_split() picks the plain /
+        # two-term split form in the accurate tier)
         def resblock(b):
             seq.append(("res_push", (lambda x, b=b: b.conv_shortcut.nhwc(x, pad=0)) if b.conv_shortcut is not None else None))
-            seq.append(("gn", b.norm1, ops.ACT_SILU))
+            seq.append(("gn", b.norm1, ops.ACT_SILU, b.conv1))
             seq.append(("f", lambda x, b=b: b.conv1.nhwc(x, gn_groups=b.norm2.num_groups)))
-            seq.append(("gn", b.norm2, ops.ACT_SILU))
+            seq.append(("gn", b.norm2, ops.ACT_SILU, b.conv2))
             seq.append(("conv_res", b.conv2, b.norm1.num_groups))  # conv2 + residual in the GEMM epilogue (+ next GN statistics)
 
         def attn(a):
             seq.append(("res_push", None))
-            seq.append(("gn", a.group_norm, ops.ACT_NONE))
+            seq.append(("gn", a.group_norm, ops.ACT_NONE, a.to_q))
             seq.append(("attn_res", a))
 
         def mid():
@@ -96,7 +98,7 @@ class VAEHook:
                 seq.append(("f", (lambda x, s=samp, g=blk.resnets[0].norm1.num_groups: s.nhwc(x, gn_groups=g))))
         if not dec:
             mid()
-        seq.append(("gn", net.conv_norm_out, ops.ACT_SILU))
+        seq.append(("gn", net.conv_norm_out, ops.ACT_SILU, net.conv_out))
         seq.append(("f", lambda x: net.conv_out.nhwc(x)))
         return seq
 
@@ -129,7 +131,7 @@ class VAEHook:
                     record.append((mean, var))
                 gi += 1
                 for k in groups:
-                    groups[k] = norm.apply_stats(groups[k], mean, rstd, act)   # rows (tile, image) share the image's statistics
+                    groups[k] = norm.apply_stats(groups[k], mean, rstd, act, split=op[3].in_split())   # rows (tile, image) share the image's statistics
             elif kind == "f":
                 for k in groups:
                     groups[k] = op[1](groups[k])
@@ -161,7 +163,7 @@ class VAEHook:
         groups = self._run(seq, groups, counts, N, fixed=fixed)
         Ho, Wo = (H * 8, W * 8) if self.is_decoder else (H // 8, W // 8)
         Cout = next(iter(groups.values())).shape[-1]
-        result = torch.zeros((N, Ho, Wo, Cout), device=x.device, dtype=ops.act_dtype())
+        result = torch.zeros((N, Ho, Wo, Cout), device=x.device, dtype=next(iter(groups.values())).dtype)
         for k, idx in order.items():
             t = groups[k]
             for j, i in enumerate(idx):
@@ -184,7 +186,7 @@ class VAEHook:
         std_n, mean_n = torch.std_mean(small, dim=[0, 2, 3], keepdim=True)
         std_n = torch.where(std_n == 0, torch.ones_like(std_n), std_n)      # zero-padded channels
         small = ((small - mean_n) / std_n * std_o + mean_o).clamp_(min=float(xc.min()), max=float(xc.max()))
-        small = small.permute(0, 2, 3, 1).to(ops.act_dtype()).contiguous()
+        small = small.permute(0, 2, 3, 1).to(ops.stream_dtype()).contiguous()
         record: list = []
         self._run(seq, {(small.shape[1], small.shape[2]): small}, {(small.shape[1], small.shape[2]): 1}, N, record=record)
         return record

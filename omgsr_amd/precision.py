@@ -1,0 +1,73 @@
+"""Precision policy of the accurate tier (`--weight_dtype fp32`, ops.set_compute_dtype(torch.float32)).
+
+The reference's `--weight_dtype fp32` (infer/infer_omgsr_s.py:134-149) runs every layer in fp32. gfx950 has no fast
+fp32 / TF32 matrix path (fp32 MFMA runs at 1/16 of the 16-bit rate), so the accurate tier keeps every tensor BETWEEN two
+GEMMs in fp32 and feeds the MFMAs fp16 operands with fp32 accumulation. What is left is one fp16 rounding of each GEMM
+input (2^-11 relative); tests/emulate_numerics.py measures what those roundings cost at the full SD2.1 shapes against the
+fp32 oracle (rel-L2 1.5e-3 in total) and how the total splits over the layers. The layers named here receive their input as
+the two-term split x = hi + lo (both fp16, the weights see both halves: twice the MFMA work of that layer, 2^-22
+relative error), which brings the pipeline under the north-star tolerance (rel-L2 <= 1e-3, PSNR >= 60 dB vs the fp32 oracle).
+
+A policy is a list of regular expressions over module names; every Conv2d / Linear (omgsr_amd.nn) whose qualified name
+matches gets `op_split = 2`. Producers (norm / cast kernels, GEMM and attention epilogues) ask their consumer which form to
+write, so a policy needs no other change.
+"""
+from __future__ import annotations
+
+import re
+from typing import Iterable, Optional
+
+import torch.nn as nn
+
+from .nn import Conv2d, Linear
+
+# Per-(layer group) share of the squared error, tests/emulate_numerics.py --budget f16_levels on OMGSR-S 128->512
+# (1e-8 units; total 224 = (1.5e-3)^2): UNet 64x64 level 36 (convs) + 30 (linears), 32x32 level 18 + 8, 16x16 level 7 + 2,
+# VAE encoder 18 / 11 / 8 / 6 by level (512 .. 64 px), decoder 9 / 7 / 13 / 11 (64 .. 512 px), latent-sized tensors
+# (conv_in / conv_out / quant convs / z / eps) 35. The UNet's fine levels cost the fewest FLOPs per unit of error removed.
+UNET_DEFAULT = [r"^conv_in$", r"^conv_out$", r"^down_blocks\.[01]\.", r"^up_blocks\.[23]\.", r"^down_blocks\.2\.", r"^up_blocks\.1\.",
+                r"^up_blocks\.0\.upsamplers"]
+VAE_DEFAULT = [r"^encoder\.conv_in$", r"^encoder\.conv_out$", r"^quant_conv$", r"^post_quant_conv$", r"^decoder\.conv_in$",
+               r"^encoder\.down_blocks\.0\."]
+FLUX_DEFAULT = [r"^x_embedder$", r"^proj_out$"]
+
+
+def set_operand_split(model: nn.Module, patterns: Iterable[str], split: int = 2) -> int:
+    """Mark the Conv2d / Linear layers whose qualified name matches any pattern; returns how many were marked."""
+    if split not in (1, 2):
+        raise ValueError("split must be 1 or 2")
+    regs = [re.compile(p) for p in patterns]
+    n = 0
+    for name, m in model.named_modules():
+        if isinstance(m, (Conv2d, Linear)):
+            hit = any(r.search(name) for r in regs)
+            m.op_split = split if hit else 1
+            n += int(hit)
+    check_policy(model)
+    return n
+
+
+def check_policy(model: nn.Module) -> None:
+    """Layers that read ONE shared operand must agree on its form: q / k / v (and Flux's proj_mlp) of a self-attention."""
+    for name, m in model.named_modules():
+        group = [getattr(m, a, None) for a in ("to_q", "to_k", "to_v")]
+        if all(isinstance(g, Linear) for g in group):
+            cross = getattr(m, "is_cross", False)
+            shared = group[:1] if cross else group
+            extra = getattr(m, "_shares_input_with", None)
+            if extra is not None:
+                shared = shared + list(extra)
+            splits = {g.op_split for g in shared}
+            if len(splits) > 1:
+                raise ValueError(f"precision policy: {name}.to_q / to_k / to_v read one operand but disagree on its split {splits}")
+            if cross and group[1].op_split != group[2].op_split:
+                raise ValueError(f"precision policy: {name}.to_k / to_v read one operand (the prompt) but disagree on its split")
+
+
+def apply_default_policy(vae: Optional[nn.Module] = None, unet: Optional[nn.Module] = None, flux: Optional[nn.Module] = None) -> None:
+    if vae is not None:
+        set_operand_split(vae, VAE_DEFAULT)
+    if unet is not None:
+        set_operand_split(unet, UNET_DEFAULT)
+    if flux is not None:
+        set_operand_split(flux, FLUX_DEFAULT)

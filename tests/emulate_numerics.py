@@ -1,0 +1,249 @@
+"""CPU emulation of where the HIP path rounds (test infrastructure, not collected by pytest).
+
+Runs the fp32 oracle modules (oracle/diffusers_ref.py) with explicit rounding points q_*() inserted where a
+storage / operand scheme of the GPU path would round, and reports rel-L2 / PSNR of the emulated OMGSR-S output
+against the un-rounded fp32 oracle at FULL SD2.1 shapes. Used to choose the accuracy tier before writing kernels:
+
+    python tests/emulate_numerics.py [--side 512] [--schemes all16,stream32,inner32]
+
+Rounding classes:
+  operand  every tensor that feeds an MFMA (conv / linear inputs, q, k, v, softmax probabilities)
+  inner    a conv / linear output that is only normalised and fed to the next conv (resnet conv1 output, FF hidden ...)
+  stream   the residual stream (resnet outputs, transformer residual sums, skip tensors)
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from omgsr_amd.testing import psnr, rel_l2, seeded_init_, synthetic_lq  # noqa: E402
+from oracle import diffusers_ref as R  # noqa: E402
+from oracle.pipeline_ref import OmgsrSRef, stitch, tile_offsets  # noqa: E402
+
+
+class Scheme:
+    """only: optional set of (stage, kind) pairs whose OPERAND roundings are kept (all others exact) - error budget runs.
+    stage in {enc, unet, dec, lat}; kind in {conv, lin, attn, lat}."""
+
+    def __init__(self, operand, inner, stream, only=None, hilo=None):
+        self.operand, self.inner, self.stream = operand, inner, stream
+        self.only, self.hilo = only, hilo or set()
+        self.stage = "lat"
+        self.seen = set()
+
+    @staticmethod
+    def _q(x, dt):
+        return x if dt is None else x.to(dt).float()
+
+    def op(self, x, kind="conv"):
+        key = (self.stage, kind)
+        res = x.shape[-1] if x.dim() == 4 else int(round((x.shape[-2]) ** 0.5))    # spatial side ([B,C,H,W] or [B,L,C] tokens)
+        key3 = (self.stage, kind, res)
+        self.seen.add(key3)
+        if self.only is not None and key not in self.only and key3 not in self.only:
+            return x
+        if key in self.hilo or key3 in self.hilo or (self.stage, "*") in self.hilo:      # two-term split: hi + lo, both in the operand type
+            hi = self._q(x, self.operand)
+            return hi + self._q(x - hi, self.operand)
+        return self._q(x, self.operand)
+
+    def inn(self, x):
+        return self._q(x, self.inner)
+
+    def st(self, x):
+        return self._q(x, self.stream)
+
+
+def resnet(S: Scheme, r, x, temb=None):
+    a = S.op(F.silu(r.norm1(x)))
+    h = r.conv1(a)
+    if r.time_emb_proj is not None:
+        h = h + r.time_emb_proj(F.silu(temb))[:, :, None, None]
+    h = S.inn(h)
+    b = S.op(F.silu(r.norm2(h)))
+    sc = x if r.conv_shortcut is None else r.conv_shortcut(S.op(x))
+    return S.st(sc + r.conv2(b))
+
+
+def attn_unet(S: Scheme, at, n, ctx=None):
+    c = n if ctx is None else S.op(ctx, "lin")
+    q, k, v = S.op(at.to_q(n), "attn"), S.op(at.to_k(c), "attn"), S.op(at.to_v(c), "attn")
+    q, k, v = at._heads(q), at._heads(k), at._heads(v)
+    p = S.op((torch.matmul(q, k.transpose(-1, -2)) * at.scale).softmax(dim=-1), "attn")
+    o = torch.matmul(p, v).transpose(1, 2).reshape(n.shape[0], -1, at.heads * at.dim_head)
+    return at.to_out[0](S.op(o, "lin"))
+
+
+def transformer2d(S: Scheme, t, x, ehs):
+    B, Cc, H, W = x.shape
+    y = S.op(t.norm(x), "lin").permute(0, 2, 3, 1).reshape(B, H * W, Cc)
+    y = S.st(t.proj_in(y))
+    for blk in t.transformer_blocks:
+        y = S.st(y + attn_unet(S, blk.attn1, S.op(blk.norm1(y), "lin")))
+        y = S.st(y + attn_unet(S, blk.attn2, S.op(blk.norm2(y), "lin"), ehs))
+        n = S.op(blk.norm3(y), "lin")
+        hg, gate = blk.ff.net[0].proj(n).chunk(2, dim=-1)
+        y = S.st(y + blk.ff.net[2](S.op(hg * F.gelu(gate), "lin")))
+    y = t.proj_out(S.op(y, "lin")).reshape(B, H, W, Cc).permute(0, 3, 1, 2)
+    return S.st(y + x)
+
+
+def unet(S: Scheme, u, sample, timestep, ehs):
+    B = sample.shape[0]
+    t = torch.as_tensor([timestep], dtype=torch.int64).reshape(-1).expand(B)
+    emb = u.time_embedding(R.timestep_sinusoid(t, u.config.block_out_channels[0]))
+    if ehs.shape[0] != B:
+        ehs = ehs.expand(B, -1, -1)
+    h = S.st(u.conv_in(S.op(sample, "lat")))
+    skips = [h]
+    for blk in u.down_blocks:
+        for j, r in enumerate(blk.resnets):
+            h = resnet(S, r, h, emb)
+            if blk.attentions is not None:
+                h = transformer2d(S, blk.attentions[j], h, ehs)
+            skips.append(h)
+        if blk.downsamplers is not None:
+            h = S.st(blk.downsamplers[0](S.op(h)))
+            skips.append(h)
+    m = u.mid_block
+    h = resnet(S, m.resnets[0], h, emb)
+    h = transformer2d(S, m.attentions[0], h, ehs)
+    h = resnet(S, m.resnets[1], h, emb)
+    for blk in u.up_blocks:
+        for j, r in enumerate(blk.resnets):
+            h = torch.cat([h, skips.pop()], dim=1)
+            h = resnet(S, r, h, emb)
+            if blk.attentions is not None:
+                h = transformer2d(S, blk.attentions[j], h, ehs)
+        if blk.upsamplers is not None:
+            h = S.st(blk.upsamplers[0](S.op(h)))
+    return S.op(u.conv_out(S.op(F.silu(u.conv_norm_out(h)))), "lat")
+
+
+def vae_attn(S: Scheme, at, x):
+    B, Cc, H, W = x.shape
+    g = S.op(at.group_norm(x.view(B, Cc, H * W)), "lin").transpose(1, 2)
+    q, k, v = S.op(at.to_q(g), "attn"), S.op(at.to_k(g), "attn"), S.op(at.to_v(g), "attn")
+    p = S.op((torch.matmul(q, k.transpose(-1, -2)) * at.scale).softmax(dim=-1), "attn")
+    o = at.to_out[0](S.op(torch.matmul(p, v), "lin"))
+    return S.st(o.transpose(-1, -2).reshape(B, Cc, H, W) + x)
+
+
+def vae_mid(S, m, h):
+    h = resnet(S, m.resnets[0], h)
+    h = vae_attn(S, m.attentions[0], h)
+    return resnet(S, m.resnets[1], h)
+
+
+def encoder(S: Scheme, e, x):
+    h = S.st(e.conv_in(S.op(x, "lat")))
+    for b in e.down_blocks:
+        for r in b.resnets:
+            h = resnet(S, r, h)
+        if b.downsamplers is not None:
+            h = S.st(b.downsamplers[0](S.op(h)))
+    h = vae_mid(S, e.mid_block, h)
+    return S.op(e.conv_out(S.op(F.silu(e.conv_norm_out(h)))), "lat")
+
+
+def decoder(S: Scheme, d, z):
+    h = S.st(d.conv_in(S.op(z, "lat")))
+    h = vae_mid(S, d.mid_block, h)
+    for b in d.up_blocks:
+        for r in b.resnets:
+            h = resnet(S, r, h)
+        if b.upsamplers is not None:
+            h = S.st(b.upsamplers[0](S.op(h)))
+    return S.op(d.conv_out(S.op(F.silu(d.conv_norm_out(h)))), "lat")
+
+
+def omgsr_s(S: Scheme, vae, u, alpha_t, x, ehs, eps, tile, overlap):
+    sf = vae.config.scaling_factor
+    S.stage = "enc"
+    m = vae.quant_conv(encoder(S, vae.encoder, x))
+    S.stage = "lat"
+    mean, logvar = m.chunk(2, dim=1)
+    z = S.op((mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * eps) * sf, "lat")
+    S.stage = "unet"
+    _, c, h, w = z.shape
+    if h * w <= tile * tile:
+        pred = unet(S, u, z, 273, ehs)
+    else:
+        ts, _, _, offs = tile_offsets(h, w, tile, overlap)
+        preds = [unet(S, u, z[:, :, oy:oy + ts, ox:ox + ts], 273, ehs) for (oy, ox) in offs]
+        pred = S.op(stitch(z.shape, preds, offs, ts, c), "lat")
+    S.stage = "lat"
+    z0 = S.op((z - (1 - alpha_t).sqrt() * pred) / alpha_t.sqrt() / sf, "lat")
+    S.stage = "dec"
+    return decoder(S, vae.decoder, vae.post_quant_conv(z0)).clamp(-1, 1)
+
+
+SCHEMES = {
+    "bf16_all": (torch.bfloat16,) * 3,
+    "f16_all": (torch.float16,) * 3,
+    "bf16_stream32": (torch.bfloat16, torch.bfloat16, None),
+    "f16_stream32": (torch.float16, torch.float16, None),
+    "bf16_inner32": (torch.bfloat16, None, None),
+    "f16_inner32": (torch.float16, None, None),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--side", type=int, default=512)
+    ap.add_argument("--schemes", default="f16_all,f16_stream32,f16_inner32,bf16_inner32")
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--budget", default="", help="f16 | bf16: per (stage, kind) contribution of the operand roundings")
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    vae, u = seeded_init_(R.AutoencoderKL(), 101).eval(), seeded_init_(R.UNet2DConditionModel(), 202).eval()
+    x = synthetic_lq(1, a.side, a.side, seed=1234)
+    eps = torch.randn(1, 4, a.side // 8, a.side // 8, generator=torch.Generator().manual_seed(99))
+    ehs = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(4321)).to(torch.bfloat16).float()
+    alpha_t = R.DDPMScheduler().alphas_cumprod[273]
+    with torch.no_grad():
+        t0 = time.time()
+        vae.posterior_noise = eps
+        ref = OmgsrSRef(vae, u, alpha_t, 273)(x, ehs, 64, 32)
+        print(f"oracle: {time.time() - t0:.1f} s, rms {ref.pow(2).mean().sqrt():.3f}", flush=True)
+        same = omgsr_s(Scheme(None, None, None), vae, u, alpha_t, x, ehs, eps, 64, 32)
+        print(f"emulator with no rounding vs oracle: rel-L2 {rel_l2(same, ref):.2e}", flush=True)
+        if a.budget.endswith("_levels"):
+            dt = torch.float16 if a.budget.startswith("f16") else torch.bfloat16
+            probe = Scheme(dt, None, None)
+            omgsr_s(probe, vae, u, alpha_t, x, ehs, eps, 64, 32)
+            tot = 0.0
+            for key3 in sorted(k for k in probe.seen if k[1] in ("conv", "lin")):
+                got = omgsr_s(Scheme(dt, None, None, only={key3}), vae, u, alpha_t, x, ehs, eps, 64, 32)
+                e = rel_l2(got, ref)
+                tot += e * e
+                print(f"only {key3} operand roundings: rel-L2 {e:.3e}  var {e * e * 1e8:.1f}", flush=True)
+            print(f"quadrature sum {tot ** 0.5:.3e}")
+            return
+        if a.budget:
+            dt = torch.float16 if a.budget == "f16" else torch.bfloat16
+            tot = 0.0
+            for stage in ("enc", "unet", "dec", "lat"):
+                for kind in ("conv", "lin", "attn", "lat"):
+                    got = omgsr_s(Scheme(dt, None, None, only={(stage, kind)}), vae, u, alpha_t, x, ehs, eps, 64, 32)
+                    e = rel_l2(got, ref)
+                    tot += e * e
+                    if e > 0:
+                        print(f"only ({stage:4s},{kind:4s}) operand roundings: rel-L2 {e:.3e}", flush=True)
+            print(f"quadrature sum {tot ** 0.5:.3e}")
+            return
+        for name in a.schemes.split(","):
+            got = omgsr_s(Scheme(*SCHEMES[name]), vae, u, alpha_t, x, ehs, eps, 64, 32)
+            print(f"{name:16s} rel-L2 {rel_l2(got, ref):.3e}  PSNR {psnr(got, ref):.1f} dB", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -34,14 +34,39 @@ def test_library_exports_every_declared_symbol():
     assert lib.omgsr_groupnorm_nchunk(4096) == 16 and lib.omgsr_groupnorm_nchunk(1) == 1
 
 
-def test_struct_layout_matches_header():
-    """ctypes mirrors of the argument structs: field order/size agree with the C declaration."""
+def test_struct_layout_matches_header(tmp_path):
+    """ctypes mirrors of the argument structs: size and EVERY field offset agree with what a C compiler makes of
+    include/omgsr_hip.h (gcc compiles a probe that prints sizeof / offsetof)."""
+    import shutil
+    import subprocess
     from omgsr_amd._lib import AttnArgs, GnMergeArgs, IgemmArgs, TimingEntry
-    # 6 ptrs, 22 int32, 3 int64, float (+pad), 3 ptrs, 2 int32
-    assert ctypes.sizeof(IgemmArgs) == 6 * 8 + 22 * 4 + 3 * 8 + 8 + 3 * 8 + 8
-    assert ctypes.sizeof(AttnArgs) == 4 * 8 + 5 * 4 + 4 + 8 * 8 + 8
-    assert ctypes.sizeof(TimingEntry) == 4 + 4 + 8 + 8 + 3 * 8
-    assert ctypes.sizeof(GnMergeArgs) == 8 * 8 + 8 * 8 + 8 * 4 + 8 * 4 + 8 * 4 + 8 * 4 + 8     # 8 groups; int32 + tail padding
+    structs = {"omgsr_igemm_args": IgemmArgs, "omgsr_attn_args": AttnArgs, "omgsr_gn_merge_args": GnMergeArgs,
+               "omgsr_timing_entry": TimingEntry}
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "omgsr_hip.h")}"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname.rstrip("_")}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run([gcc, "-std=c11", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for ln in out:
+        if not ln.strip():
+            continue
+        cname, field, val = ln.split()
+        cls = structs[cname]
+        if field == "size":
+            assert ctypes.sizeof(cls) == int(val), f"sizeof({cname}): C {val}, ctypes {ctypes.sizeof(cls)}"
+        else:
+            assert getattr(cls, field).offset == int(val), f"offsetof({cname}, {field}): C {val}, ctypes {getattr(cls, field).offset}"
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in structs.values())
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
@@ -49,7 +74,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     lib = _lib.load()
     assert lib.omgsr_igemm(None, None) == -1
     assert lib.omgsr_attention(None, None) == -1
-    assert lib.omgsr_layernorm(None, None, None, None, 4, 320, 1e-5, None) == -1
+    assert lib.omgsr_layernorm(None, None, None, None, 4, 320, 1e-5, 0, 0, None) == -1
     a = _lib.IgemmArgs()
     a.in_, a.weight, a.out = 8, 8, 8
     a.N = a.H = a.W = a.Ho = a.Wo = a.R = a.S = a.stride = a.batch = 1

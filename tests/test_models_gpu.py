@@ -138,6 +138,7 @@ def test_flux_transformer_forward():
     from omgsr_amd.diffusers_api import FluxTransformer2DModel
     from oracle import diffusers_ref as R
     p, o = _pair(FluxTransformer2DModel, R.FluxTransformer2DModel, SMALL_FLUX, 21)
+    p.round_timestep_to_weight_dtype = False        # the fp32 oracle conditions on the exact timestep (tests/test_loading_cpu.py pins the 16-bit rounding)
     B, h, w, Lc = 2, 16, 24, 40
     pe, pooled, tids, iids = _flux_inputs(B, h, w, Lc, 22)
     x = torch.randn(B, (h // 2) * (w // 2), 64, generator=torch.Generator().manual_seed(23)).to(torch.bfloat16).float()
@@ -162,6 +163,7 @@ def test_omgsr_f_pipeline(h, w, tile, overlap):
     from oracle.pipeline_ref import OmgsrFRef
     pv, ov = _pair(AutoencoderKL, R.AutoencoderKL, SMALL_FLUX_VAE, 31)
     pf, of = _pair(FluxTransformer2DModel, R.FluxTransformer2DModel, SMALL_FLUX, 32)
+    pf.round_timestep_to_weight_dtype = False
     B, Lc = 2, 24
     pe, pooled, tids, iids = _flux_inputs(B, tile, tile, Lc, 33)       # ids cover one (tile x tile) latent
     x = synthetic_lq(B, h * 8, w * 8)
