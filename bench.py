@@ -1,46 +1,55 @@
 #!/usr/bin/env python
 """bench.py — OMGSR single-mid-timestep SR throughput on MI355X (see BASELINE.json / BASELINE.md).
 
-    python bench.py --gpus N --steps K --warmup W [--workload s512|s1024|f1024] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--workload s1024|s512|f1024] [--batch B] [--weight-dtype fp32|fp16|bf16]
 
-One process per GPU (torchrun env for N > 1). A "step" is one pass of the hot path (VAE encode ->
-UNet/Flux at t* -> latent step -> VAE decode, the reference's timed region
-infer/omgsr_s_infer_model.py:171-183) over one batch of synthetic LQ images already resident in HBM.
+One process per GPU. With the torchrun env (RANK / WORLD_SIZE ...) this process IS a rank; without it and N > 1 the
+parent launches `python -m torch.distributed.run --nproc-per-node N ...` on itself as a child BEFORE anything touches the
+GPU and relays its output (never re-execs a GPU process). A "step" is one call of the reference's timed region
+(`OMGSR_S_Infer.forward`, infer/omgsr_s_infer_model.py:171-183: NCHW image in the weight dtype already resident in HBM ->
+VAE encode -> UNet/Flux at t* -> latent step -> VAE decode -> clamp -> NCHW image) over one batch of synthetic LQ images.
 Rank 0 prints ONE JSON line; `value` is whole-job images/s (all ranks' images / max-over-ranks time).
 
+Tiers (`--weight-dtype`, the reference's `--weight_dtype`): fp32 = the accurate tier (fp32 tensors between GEMMs, fp16 MFMA
+operands with fp32 accumulation, two-term split operands on the layers omgsr_amd/precision.py names) — the tier that meets the
+north-star tolerance (rel-L2 <= 1e-3, PSNR >= 60 dB vs the fp32 reference path) and therefore the default; bf16 (the
+reference's default dtype) and fp16 are the fast tiers, reported in `fast_tiers` with their own parity.
+
 Extra legs (rank 0, N == 1):
-  roofline      one additional, untimed step with per-launch HIP events on the launch stream
-                (omgsr_timing_*): algorithmic FLOPs of every implicit-GEMM launch / their summed duration
-  cpu_baseline  the fp32 CPU oracle (oracle/, "port") on ONE image of the same workload, all host cores;
-                also yields PSNR / rel-L2 of the HIP output vs the oracle's output for that image
+  roofline      one additional, untimed step with per-launch HIP events on the launch stream (omgsr_timing_*): per kernel
+                (igemm_halo_kernel / igemm_dma_kernel / igemm_kernel / attn_kernel) algorithmic FLOPs / summed duration,
+                the §8(d) algorithmic figure of the whole workload, and a measured MFMA micro-benchmark peak
+  cpu_baseline  the fp32 CPU oracle (oracle/, "port") on ONE image of the same workload; also yields PSNR / rel-L2 of the
+                HIP output vs the oracle's output for that image
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
 import json
-import math
 import os
+import platform
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WDTYPE = torch.bfloat16          # --weight-dtype (the reference's --weight_dtype): bf16 (default) or fp16, same MFMA rate
-PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: 2.5 PF, measured 2495 TF)
+PEAK_DENSE_TFLOPS = 2500.0   # MI355X dense 16-bit MFMA (MI355X_MICROARCH.md: 2.5 PF spec, 2495 TF measured by its micro-benchmark)
 
 WORKLOADS = {
-    # name: (family, image side, default batch, latent tile, overlap, algorithmic TFLOP per image [BASELINE.md §3])
+    # name: (family, image side, default batch, latent tile, overlap, algorithmic TFLOP per image [BASELINE.md §3 / SURVEY §8(d)])
     "s512": ("S", 512, 8, 64, 32, 4.436),          # BASELINE.json configs[1]
     "s1024": ("S", 1024, 4, 64, 32, 22.59),        # configs[2]: 1k output, tiled VAE (encoder tile 256, decoder tile 64)
-    "f1024": ("F", 1024, 1, 128, 64, 89.8),
+    "f1024": ("F", 1024, 1, 128, 64, 89.8),        # configs[3]
 }
+DTYPES = {"fp32": "float32", "fp16": "float16", "bf16": "bfloat16"}
+IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -48,89 +57,170 @@ def parse():
     # default = the first "1k out" configuration of BASELINE.json's metric that fits one GPU (configs[2])
     ap.add_argument("--workload", default=os.environ.get("OMGSR_BENCH_WORKLOAD", "s1024"), choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = workload default)")
-    ap.add_argument("--weight-dtype", default="bf16", choices=["bf16", "fp16"], help="the kernels' 16-bit element type")
+    ap.add_argument("--weight-dtype", default=os.environ.get("OMGSR_BENCH_DTYPE", "fp32"), choices=sorted(DTYPES),
+                    help="tier: fp32 = accurate (meets the north-star tolerance; default), bf16 / fp16 = fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fast-tiers", action="store_true", help="skip the short bf16 / fp16 legs")
     ap.add_argument("--no-tiled-vae", action="store_true", help="s1024 only: run the VAE untiled (the reference's shipped default)")
-    return ap.parse_args()
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="exercise the N-rank launch / RCCL-shaped broadcast / reporting path on CPU (gloo, reduced models, no kernels)")
+    return ap.parse_args(argv)
 
 
-def build_s(device, rank, world):
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` makes N ranks itself
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_spawn_ranks(args) -> int | None:
+    """When asked for N > 1 GPUs outside a torchrun environment: run N ranks as CHILD processes (fresh interpreters, spawned
+    before this process imports torch.cuda or the HIP library) and return the child's exit code; None = this process is a rank."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return None
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------------------------
+
+def build_s(device, rank, world, wdtype, reduced=False):
+    import torch
     from omgsr_amd import dist as D
     from omgsr_amd.diffusers_api import AutoencoderKL, UNet2DConditionModel
     from omgsr_amd.pipelines.omgsr_s import OMGSR_S_Infer
     from omgsr_amd.testing import seeded_init_
+    vcfg = dict(block_out_channels=[32, 64, 128, 128], layers_per_block=1) if reduced else {}
+    ucfg = dict(block_out_channels=[64, 128, 256, 256], attention_head_dim=[1, 2, 4, 4], cross_attention_dim=128) if reduced else {}
     if rank == 0 or world == 1:
-        vae, unet = seeded_init_(AutoencoderKL(), 101), seeded_init_(UNet2DConditionModel(), 202)
-    else:   # peers allocate uninitialised HBM and receive rank 0's weights over RCCL
+        vae, unet = seeded_init_(AutoencoderKL(**vcfg), 101), seeded_init_(UNet2DConditionModel(**ucfg), 202)
+    else:   # peers allocate uninitialised memory and receive rank 0's weights over RCCL
         with torch.device("meta"):
-            vae, unet = AutoencoderKL(), UNet2DConditionModel()
-        vae, unet = vae.to_empty(device=device).to(WDTYPE), unet.to_empty(device=device).to(WDTYPE)
-    pipe = OMGSR_S_Infer(None, None, 273, device, WDTYPE, vae=vae, unet=unet)
+            vae, unet = AutoencoderKL(**vcfg), UNet2DConditionModel(**ucfg)
+        vae, unet = vae.to_empty(device=device).to(wdtype), unet.to_empty(device=device).to(wdtype)
+    if reduced:     # dry run: no HIP library on this host; the pipeline object is not needed to broadcast / checksum
+        pipe = type("DryPipe", (), {})()
+        pipe.vae, pipe.unet = vae.to(device=device, dtype=wdtype), unet.to(device=device, dtype=wdtype)
+    else:
+        pipe = OMGSR_S_Infer(None, None, 273, device, wdtype, vae=vae, unet=unet)
     moved = D.broadcast_module_(pipe.vae) + D.broadcast_module_(pipe.unet)   # RCCL over xGMI (no-op at N=1)
     if not (D.replicas_identical(pipe.vae) and D.replicas_identical(pipe.unet)):
         raise RuntimeError("weight replicas differ after broadcast")
     return pipe, moved
 
 
-def build_f(device, rank, world):
+def build_f(device, rank, world, wdtype):
     """OMGSR-F: FLUX.1-dev-shaped DiT (11.9 B params) + FLUX VAE, seeded random weights generated on the GPU."""
+    import torch
     from omgsr_amd import dist as D
     from omgsr_amd.diffusers_api import AutoencoderKL, FLUX_VAE_CONFIG, FluxTransformer2DModel
     from omgsr_amd.pipelines.omgsr_f import OMGSR_F_Infer
     from omgsr_amd.testing import seeded_init_, seeded_init_device_
     with torch.device("meta"):
         flux = FluxTransformer2DModel()
-    flux = flux.to_empty(device=device).to(WDTYPE)
+    flux = flux.to_empty(device=device).to(wdtype)
     if rank == 0 or world == 1:
         vae = seeded_init_(AutoencoderKL(**FLUX_VAE_CONFIG), 303)
         seeded_init_device_(flux, 404)
     else:
         with torch.device("meta"):
             vae = AutoencoderKL(**FLUX_VAE_CONFIG)
-        vae = vae.to_empty(device=device).to(WDTYPE)
-    pipe = OMGSR_F_Infer(None, None, device, WDTYPE, 244, 1.0, vae=vae, flux_transformer=flux)
+        vae = vae.to_empty(device=device).to(wdtype)
+    pipe = OMGSR_F_Infer(None, None, device, wdtype, 244, 1.0, vae=vae, flux_transformer=flux)
     moved = D.broadcast_module_(pipe.vae) + D.broadcast_module_(pipe.flux_transformer)
     if not (D.replicas_identical(pipe.vae) and D.replicas_identical(pipe.flux_transformer)):
         raise RuntimeError("weight replicas differ after broadcast")
     return pipe, moved
 
 
-def collect_roofline(lib_mod):
+def collect_timing(lib_mod):
     from omgsr_amd._lib import TimingEntry
     lib = lib_mod.load()
     n = lib.omgsr_timing_collect(None, 0)
     buf = (TimingEntry * max(n, 1))()
     n = lib.omgsr_timing_collect(buf, n)
-    kinds, shapes = {}, {}
+    kinds, kernels, shapes = {}, {}, {}
     for i in range(n):
         e = buf[i]
         k = kinds.setdefault(int(e.kind), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
         k["launches"] += 1; k["ms"] += e.ms; k["flops"] += e.flops; k["bytes"] += e.bytes
         if e.kind in (1, 2):
-            s = shapes.setdefault((int(e.kind), int(e.m), int(e.n), int(e.k)), dict(launches=0, ms=0.0, flops=0.0))
+            name = IGEMM_VARIANTS.get(int(e.variant), "igemm?") if e.kind == 1 else "attn_kernel"
+            kk = kernels.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            kk["launches"] += 1; kk["ms"] += e.ms; kk["flops"] += e.flops; kk["bytes"] += e.bytes
+            s = shapes.setdefault((name, int(e.m), int(e.n), int(e.k)), dict(launches=0, ms=0.0, flops=0.0))
             s["launches"] += 1; s["ms"] += e.ms; s["flops"] += e.flops
     table = os.environ.get("OMGSR_KERNEL_TABLE")
     if table:   # per-shape breakdown for DESIGN.md / profiles/
         with open(table, "w") as f:
-            f.write("| kind | M | N | K | launches | total ms | TFLOP/s |\n|---|---|---|---|---|---|---|\n")
-            for (kind, m, nn, kk), s in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
+            f.write("| kernel | M | N | K | launches | total ms | TFLOP/s |\n|---|---|---|---|---|---|---|\n")
+            for (name, m, nn, kk), s in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
                 tf = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
-                f.write(f"| {'igemm' if kind == 1 else 'attn'} | {m} | {nn} | {kk} | {s['launches']} | {s['ms']:.3f} | {tf:.1f} |\n")
-    return kinds
+                f.write(f"| {name} | {m} | {nn} | {kk} | {s['launches']} | {s['ms']:.3f} | {tf:.1f} |\n")
+    return kinds, kernels
+
+
+def cpu_info() -> dict:
+    model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count()}
+
+
+def dry_run_cpu(args) -> None:
+    """CPU / gloo rehearsal of the N-rank path: rendezvous, per-rank shard, weight broadcast in buckets, checksum all-reduce,
+    barrier-bracketed timing, max-over-ranks, rank-0 JSON. No kernels run (there is no CPU fallback of the product path)."""
+    import torch
+    from omgsr_amd import dist as D
+    rank, _, world = D.init(backend="gloo")
+    pipe, moved = build_s(torch.device("cpu"), rank, world, torch.float32, reduced=True)
+    B = args.batch or 2
+    lo, hi = D.shard_range(B * world, rank, world)
+    D.barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (hi - lo))          # stand-in for the step
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t1, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "SR images/sec", "value": round(B * world * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "dry_run": True, "config": {"workload": "dry run (CPU, gloo, reduced models, no kernels)", "global_batch": B * world,
+                                                      "images_rank0": [lo, hi],
+                                                      "parallelism": f"dp{world} (images sharded, weight broadcast {moved / 2**20:.2f} MiB over {'gloo' if world > 1 else 'nothing'})",
+                                                      "broadcast_bytes": moved, "world_size": world}}))
 
 
 def main():
     args = parse()
-    global WDTYPE
-    WDTYPE = torch.bfloat16 if args.weight_dtype == "bf16" else torch.float16
-    from omgsr_amd import _lib, dist as D
-    from omgsr_amd.testing import psnr, rel_l2, synthetic_lq
+    rc = maybe_spawn_ranks(args)
+    if rc is not None:
+        raise SystemExit(rc)
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
+
+    import torch
+    from omgsr_amd import _lib, dist as D, ops
+    from omgsr_amd.testing import synthetic_lq
+    wdtype = getattr(torch, DTYPES[args.weight_dtype])
 
     rank, local_rank, world = D.init()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -139,34 +229,17 @@ def main():
 
     family, side, dbatch, tile, overlap, tflop_per_img = WORKLOADS[args.workload]
     B = args.batch or dbatch
-    t0 = time.time()
-    pipe, moved = (build_s if family == "S" else build_f)(device, rank, world)
     tiled_vae = args.workload == "s1024" and not args.no_tiled_vae
+    t0 = time.time()
+    pipe, moved = (build_s if family == "S" else build_f)(device, rank, world, wdtype)
     if tiled_vae:
         pipe._init_tiled_vae(encoder_tile_size=256, decoder_tile_size=64)
-    build_s_secs = time.time() - t0
+    build_secs = time.time() - t0
 
-    # synthetic inputs, resident in HBM before the timed region (per-rank seed: every rank has its own images)
-    g = torch.Generator().manual_seed(4321)
-    lq_cpu = synthetic_lq(B, side, side, seed=1234 + rank)
-    lq = ops_nhwc(lq_cpu.to(device))
-    lat_c = 4 if family == "S" else 16
-    eps_cpu = torch.randn(B, lat_c, side // 8, side // 8, generator=torch.Generator().manual_seed(99 + rank))
-    pipe.vae.posterior_noise = eps_cpu.to(device)
-    if family == "S":
-        prompt = torch.randn(1, 77, 1024, generator=g).to(WDTYPE).to(device)
-
-        def step():
-            return pipe.sr_nhwc(lq, prompt, tile, overlap)
-    else:
-        from omgsr_amd.pipelines.omgsr_f import prepare_latent_image_ids
-        prompt = torch.randn(1, 512, 4096, generator=g).to(WDTYPE).to(device)
-        pooled = torch.randn(1, 768, generator=g).to(WDTYPE).to(device)
-        text_ids = torch.zeros(512, 3, device=device, dtype=WDTYPE)
-        image_ids = prepare_latent_image_ids(tile // 2, tile // 2, device, WDTYPE)
-
-        def step():
-            return pipe.sr_nhwc(lq, prompt, pooled, text_ids, image_ids, tile, overlap)
+    # synthetic inputs, resident in HBM in the weight dtype before the timed region (infer/infer_omgsr_s.py:92); per-rank seed
+    inp = make_inputs(family, side, B, tile, rank, device, wdtype)
+    pipe.vae.posterior_noise = inp["eps"].to(device)
+    step = make_step(pipe, family, inp, tile, overlap)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -186,64 +259,119 @@ def main():
 
     roofline, extra = None, {}
     if rank == 0 and not args.no_roofline:
-        lib = _lib.load()
-        lib.omgsr_timing_reset(); lib.omgsr_timing_enable(1)
-        with torch.no_grad():
-            step()
-        kinds = collect_roofline(_lib)
-        lib.omgsr_timing_enable(0); lib.omgsr_timing_reset()
-        ig = kinds.get(1)
-        if ig and ig["ms"] > 0:
-            ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all launches of one step)",
-                        "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
-                        "launches": ig["launches"], "kernel_ms": round(ig["ms"], 3),
-                        "algorithmic_tflop": round(ig["flops"] / 1e12, 3),
-                        "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"])}
-            # HBM bytes per launch of the same kernel family, from the committed rocprofv3 PMC passes of THIS workload
-            # (FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction; tools/traffic_summary.py)
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if args.workload == "s1024" and tiled_vae and WDTYPE == torch.bfloat16 and B == 4 and os.path.isfile(tpath):
-                fam = json.load(open(tpath))["families"].get("igemm")
-                if fam:
-                    roofline["traffic"] = round(fam["hbm_bytes_per_launch"])
-                    roofline["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
-        names = {1: "igemm", 2: "attention", 3: "groupnorm", 4: "layernorm", 5: "elementwise", 6: "softmax"}
-        extra["kernel_ms_by_family"] = {names.get(k, str(k)): round(v["ms"], 3) for k, v in sorted(kinds.items())}
-        extra["pipeline_frac_of_mfma_peak"] = round(tflop_per_img * B * args.steps / elapsed / PEAK_BF16_DENSE_TFLOPS, 4) if world == 1 else None
+        roofline, extra = roofline_leg(_lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, wdtype)
 
     cpu_baseline, parity = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and family == "S":
-        cpu_baseline, parity, oracle_img = cpu_leg(lq_cpu[:1], eps_cpu[:1], prompt.float().cpu(), out[:1], tile, overlap, side, tiled_vae)
-        if WDTYPE == torch.bfloat16:
-            # the same workload in the reference's other 16-bit --weight_dtype: same kernels (templates on the element type),
-            # 8x finer mantissa; a short timed leg + parity of image 0 against the same oracle output
-            extra["fp16_mode"] = fp16_leg(device, rank, world, tiled_vae, lq_cpu, eps_cpu, prompt, tile, overlap, oracle_img, B)
+    if rank == 0 and world == 1 and family == "S":
+        oracle_img = None
+        if not args.no_cpu_baseline:
+            cpu_baseline, parity, oracle_img = cpu_leg(inp, out[:1], tile, overlap, side, tiled_vae)
+        if not args.no_fast_tiers:
+            others = {}
+            for name in ("fp32", "fp16", "bf16"):
+                if name != args.weight_dtype:
+                    others[name] = tier_leg(getattr(torch, DTYPES[name]), device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img)
+            extra["other_tiers"] = others
+            ops.set_compute_dtype(wdtype)
 
     if rank == 0:
+        tier = {"fp32": "accurate tier: fp32 tensors between GEMMs, fp16 MFMA operands (two-term split on the layers of omgsr_amd/precision.py), fp32 accumulation",
+                "fp16": "fast tier fp16", "bf16": "fast tier bf16 (the reference's default --weight_dtype)"}[args.weight_dtype]
         line = {
             "metric": "SR images/sec", "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if WDTYPE == torch.bfloat16 else "fp16", "data": "synthetic",
-            "config": {"workload": f"OMGSR-{family} {side // 4}->{side}, batch={B}/GPU, {'bf16' if WDTYPE == torch.bfloat16 else 'fp16'}, seeded random weights at {'SD2.1-base' if family == 'S' else 'FLUX.1-dev'} shapes"
-                                   + (", tiled VAE (VAEHook enc 256 / dec 64)" if tiled_vae else ""),
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if args.weight_dtype == "fp32" else args.weight_dtype, "data": "synthetic",
+            "config": {"workload": f"OMGSR-{family} {side // 4}->{side}, batch={B}/GPU, --weight_dtype {args.weight_dtype} ({tier}), seeded random weights at "
+                                   f"{'SD2.1-base' if family == 'S' else 'FLUX.1-dev'} shapes" + (", tiled VAE (VAEHook enc 256 / dec 64)" if tiled_vae else ""),
                        "global_batch": B * world, "latent_tile": tile, "tile_overlap": overlap, "mid_timestep": 273 if family == "S" else 244,
-                       "parallelism": f"dp{world} (images sharded, RCCL weight broadcast {moved >> 20} MiB)"},
+                       "timed_region": "pipe.forward: NCHW image in HBM -> NCHW image (clamped), the reference's own region",
+                       "parallelism": f"dp{world} (images sharded, RCCL weight broadcast {moved / 2**20:.1f} MiB)", "world_size": world},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
-            "setup_s": round(build_s_secs, 1), **extra,
+            "setup_s": round(build_secs, 1), **extra,
         }
         print(json.dumps(line))
 
 
-def ops_nhwc(x_nchw):
-    from omgsr_amd import ops
-    return ops.nchw_to_nhwc(x_nchw.contiguous(), 8)
+def make_inputs(family, side, B, tile, rank, device, wdtype):
+    import torch
+    from omgsr_amd.testing import synthetic_lq
+    g = torch.Generator().manual_seed(4321)
+    lq_cpu = synthetic_lq(B, side, side, seed=1234 + rank)
+    lat_c = 4 if family == "S" else 16
+    inp = {"lq_cpu": lq_cpu, "lq": lq_cpu.to(device=device, dtype=wdtype),
+           "eps": torch.randn(B, lat_c, side // 8, side // 8, generator=torch.Generator().manual_seed(99 + rank))}
+    if family == "S":
+        inp["prompt_cpu"] = torch.randn(1, 77, 1024, generator=g).to(torch.bfloat16).float()
+        inp["prompt"] = inp["prompt_cpu"].to(device=device, dtype=wdtype)
+    else:
+        from omgsr_amd.pipelines.omgsr_f import prepare_latent_image_ids
+        inp["prompt"] = torch.randn(1, 512, 4096, generator=g).to(device=device, dtype=wdtype)
+        inp["pooled"] = torch.randn(1, 768, generator=g).to(device=device, dtype=wdtype)
+        inp["text_ids"] = torch.zeros(512, 3, device=device, dtype=wdtype)
+        inp["image_ids"] = prepare_latent_image_ids(tile // 2, tile // 2, device, wdtype)
+    return inp
 
 
-def cpu_leg(lq1, eps1, prompt, hip_out_nhwc, tile, overlap, side, tiled_vae=False):
+def make_step(pipe, family, inp, tile, overlap):
+    if family == "S":
+        return lambda: pipe(inp["lq"], inp["prompt"], tile, overlap)[0]
+    return lambda: pipe(inp["lq"], inp["prompt"], inp["pooled"], inp["text_ids"], inp["image_ids"], tile, overlap)[0]
+
+
+def roofline_leg(_lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, wdtype):
+    import torch
+    lib = _lib.load()
+    lib.omgsr_timing_reset(); lib.omgsr_timing_enable(1)
+    with torch.no_grad():
+        step()
+    kinds, kernels = collect_timing(_lib)
+    lib.omgsr_timing_enable(0); lib.omgsr_timing_reset()
+    peak_meas = C.c_float(0.0)
+    _lib.check(lib.omgsr_mfma_peak(4096, C.byref(peak_meas), torch.cuda.current_stream().cuda_stream), "omgsr_mfma_peak")
+    per_kernel = {}
+    for name, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
+        ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        per_kernel[name] = {"launches": k["launches"], "total_ms": round(k["ms"], 3), "avg_us": round(k["ms"] * 1e3 / k["launches"], 2),
+                            "executed_tflop": round(k["flops"] / 1e12, 3), "achieved_tflops": round(ach, 1),
+                            "frac": round(ach / PEAK_DENSE_TFLOPS, 4), "bytes_per_launch": round(k["bytes"] / k["launches"])}
+    roofline = None
+    ig, at = kinds.get(1), kinds.get(2)
+    if ig and ig["ms"] > 0 and per_kernel:
+        dom = next(iter(per_kernel))
+        attn_tflop = (at["flops"] / 1e12) if at else 0.0
+        # §8(d): the algorithmic figure of the workload (untiled VAE) - the tiled VAE's overlap recompute and the
+        # two-term split's duplicated channels are overhead, not useful work. MFMA kernels = igemm family + attention.
+        alg_igemm = tflop_per_img * B - attn_tflop
+        mfma_ms = ig["ms"] + (at["ms"] if at else 0.0)
+        ach = alg_igemm * 1e12 / (ig["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": f"igemm family (dominant: {dom}); per-kernel rows in `kernels`",
+                    "achieved": round(ach, 2), "peak": PEAK_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_DENSE_TFLOPS, 4),
+                    "peak_measured_mfma_microbench": round(float(peak_meas.value), 1),
+                    "frac_of_measured_peak": round(ach / max(float(peak_meas.value), 1.0), 4),
+                    "traffic": None,
+                    "launches": ig["launches"], "kernel_ms": round(ig["ms"], 3),
+                    "algorithmic_tflop": round(alg_igemm, 3), "executed_tflop": round(ig["flops"] / 1e12, 3),
+                    "algorithmic_basis": f"{tflop_per_img} TFLOP/image x {B} images (SURVEY 8(d), untiled VAE) minus {attn_tflop:.3f} TFLOP run by attn_kernel",
+                    "achieved_all_mfma_kernels": round(tflop_per_img * B / (mfma_ms * 1e-3), 2),
+                    "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"]),
+                    "kernels": per_kernel}
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        if os.path.isfile(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and tj.get("weight_dtype") == args.weight_dtype and tj.get("batch") == B:
+                fam = tj["families"].get("igemm")
+                if fam:
+                    roofline["traffic"] = round(fam["hbm_bytes_per_launch"])
+                    roofline["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)"
+    names = {1: "igemm", 2: "attention", 3: "groupnorm", 4: "layernorm", 5: "elementwise", 6: "softmax"}
+    extra = {"kernel_ms_by_family": {names.get(k, str(k)): round(v["ms"], 3) for k, v in sorted(kinds.items())},
+             "pipeline_frac_of_mfma_peak": round(tflop_per_img * B * args.steps / elapsed / PEAK_DENSE_TFLOPS, 4) if world == 1 else None}
+    return roofline, extra
+
+
+def cpu_leg(inp, hip_out_nchw, tile, overlap, side, tiled_vae=False):
     """fp32 CPU oracle on ONE image of the workload (bounded sample), and parity of the HIP output vs it."""
-    from omgsr_amd import ops
+    import torch
     from omgsr_amd.testing import psnr, rel_l2, seeded_init_
     from oracle import diffusers_ref as R
     from oracle.pipeline_ref import OmgsrSRef, TiledVaeRef
@@ -252,48 +380,47 @@ def cpu_leg(lq1, eps1, prompt, hip_out_nhwc, tile, overlap, side, tiled_vae=Fals
     cores = int(os.environ.get("OMGSR_CPU_THREADS", min(16, os.cpu_count() or 1)))
     torch.set_num_threads(cores)
     vae, unet = seeded_init_(R.AutoencoderKL(), 101).eval(), seeded_init_(R.UNet2DConditionModel(), 202).eval()
-    vae.posterior_noise = eps1
+    vae.posterior_noise = inp["eps"][:1]
     ref = OmgsrSRef(TiledVaeRef(vae, 256, 64) if tiled_vae else vae, unet, R.DDPMScheduler().alphas_cumprod[273], 273)
     with torch.no_grad():
         t0 = time.perf_counter()
-        img = ref(lq1, prompt, tile, overlap)
+        img = ref(inp["lq_cpu"][:1], inp["prompt_cpu"], tile, overlap)
         secs = time.perf_counter() - t0
-    got = ops.nhwc_to_nchw(hip_out_nhwc.contiguous(), channels=3, dtype=torch.float32, clamp=(-1.0, 1.0)).cpu()
-    parity = {"vs": "fp32 CPU oracle, same weights/inputs/eps, image 0", "rel_l2": round(rel_l2(got, img), 5),
-              "psnr_db": round(psnr(got, img), 2)}
+    got = hip_out_nchw.float().cpu()
+    parity = {"vs": "fp32 CPU oracle, same weights/inputs/eps, image 0", "rel_l2": round(rel_l2(got, img), 6),
+              "psnr_db": round(psnr(got, img), 2), "north_star": "rel_l2 <= 1e-3 and psnr >= 60 dB",
+              "meets_north_star": bool(rel_l2(got, img) <= 1e-3 and psnr(got, img) >= 60.0)}
     base = {"value": round(1.0 / secs, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 image {side // 4}->{side}, fp32 eager PyTorch oracle, {secs:.1f} s, torch threads={torch.get_num_threads()}"}
+            "sample": f"1 image {side // 4}->{side}, fp32 eager PyTorch oracle, {secs:.1f} s, torch threads={torch.get_num_threads()}",
+            **cpu_info(), "torch": torch.__version__}
     return base, parity, img
 
 
-def fp16_leg(device, rank, world, tiled_vae, lq_cpu, eps_cpu, prompt, tile, overlap, oracle_img, B):
-    global WDTYPE
-    from omgsr_amd import ops
+def tier_leg(wdtype, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img):
+    """The same workload in another --weight_dtype tier: a short timed run + parity of image 0 against the same oracle output."""
+    import torch
     from omgsr_amd.testing import psnr, rel_l2
-    keep = WDTYPE
-    try:
-        WDTYPE = torch.float16
-        ops.set_compute_dtype(torch.float16)
-        pipe, _ = build_s(device, rank, world)
-        if tiled_vae:
-            pipe._init_tiled_vae(encoder_tile_size=256, decoder_tile_size=64)
-        pipe.vae.posterior_noise = eps_cpu.to(device)
-        lq = ops_nhwc(lq_cpu.to(device))
-        pr = prompt.to(torch.float16)
-        with torch.no_grad():
-            out = pipe.sr_nhwc(lq, pr, tile, overlap)
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(2):
-                out = pipe.sr_nhwc(lq, pr, tile, overlap)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t) / 2
-        got = ops.nhwc_to_nchw(out[:1].contiguous(), channels=3, dtype=torch.float32, clamp=(-1.0, 1.0)).cpu()
-        return {"images_per_s": round(B / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": 2,
-                "rel_l2": round(rel_l2(got, oracle_img), 5), "psnr_db": round(psnr(got, oracle_img), 2)}
-    finally:
-        WDTYPE = keep
-        ops.set_compute_dtype(keep)
+    pipe, _ = build_s(device, 0, 1, wdtype)
+    if tiled_vae:
+        pipe._init_tiled_vae(encoder_tile_size=256, decoder_tile_size=64)
+    pipe.vae.posterior_noise = inp["eps"].to(device)
+    inp2 = dict(inp, lq=inp["lq_cpu"].to(device=device, dtype=wdtype), prompt=inp["prompt_cpu"].to(device=device, dtype=wdtype))
+    step = make_step(pipe, family, inp2, tile, overlap)
+    with torch.no_grad():
+        out = step()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            out = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / 3
+    leg = {"images_per_s": round(B / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": 3}
+    if oracle_img is not None:
+        got = out[:1].float().cpu()
+        leg.update(rel_l2=round(rel_l2(got, oracle_img), 6), psnr_db=round(psnr(got, oracle_img), 2))
+    del pipe
+    torch.cuda.empty_cache()
+    return leg
 
 
 if __name__ == "__main__":

@@ -278,8 +278,15 @@ int omgsr_colorfix(const void* sr_nhwc, int32_t sr_ld, const uint8_t* src_hwc3, 
 int omgsr_timing_enable(int on);
 int omgsr_timing_reset(void);
 /* Synchronises, then fills up to `cap` entries; returns the number of recorded launches. */
-typedef struct omgsr_timing_entry { int32_t kind; float ms; double flops; double bytes; int64_t m, n, k; } omgsr_timing_entry;
+/* kind: 1 igemm, 2 attention, 3 groupnorm, 4 layernorm, 5 elementwise, 6 softmax. variant (igemm only): which kernel
+ * the dispatcher launched - 1 igemm_kernel (register staged), 2 igemm_dma_kernel, 3 igemm_halo_kernel, 4 igemm_dma_kernel
+ * split-K + splitk_reduce_kernel. flops / bytes: ALGORITHMIC work of the launch (a two-term split operand's duplicated
+ * channels count once). */
+typedef struct omgsr_timing_entry { int32_t kind; float ms; double flops; double bytes; int64_t m, n, k; int32_t variant; int32_t reserved; } omgsr_timing_entry;
 int omgsr_timing_collect(omgsr_timing_entry* out, int cap);
+/* Dense 16-bit MFMA micro-benchmark (compute dtype) on the current device: measured TFLOP/s through the HOST pointer.
+ * Synchronises `stream`; a benchmarking utility (bench.py records it beside the roofline fractions). */
+int omgsr_mfma_peak(int32_t iters, float* tflops, void* stream);
 
 #ifdef __cplusplus
 }

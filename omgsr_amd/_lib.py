@@ -61,7 +61,7 @@ class AttnArgs(C.Structure):
 
 class TimingEntry(C.Structure):
     _fields_ = [("kind", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double),
-                ("m", C.c_int64), ("n", C.c_int64), ("k", C.c_int64)]
+                ("m", C.c_int64), ("n", C.c_int64), ("k", C.c_int64), ("variant", C.c_int32), ("reserved", C.c_int32)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -105,6 +105,7 @@ SIGNATURES = {
     "omgsr_timing_enable": (C.c_int, [C.c_int]),
     "omgsr_timing_reset": (C.c_int, []),
     "omgsr_timing_collect": (C.c_int, [C.POINTER(TimingEntry), C.c_int]),
+    "omgsr_mfma_peak": (C.c_int, [_I, C.POINTER(C.c_float), _P]),
 }
 
 _lib = None

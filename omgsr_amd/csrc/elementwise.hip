@@ -360,7 +360,7 @@ extern "C" int omgsr_timing_collect(omgsr_timing_entry* out, int cap) {
             float ms = 0.0f;
             (void)hipEventElapsedTime(&ms, r.e0, r.e1);
             out[n].kind = r.kind; out[n].ms = ms; out[n].flops = r.flops; out[n].bytes = r.bytes;
-            out[n].m = r.m; out[n].n = r.n; out[n].k = r.k;
+            out[n].m = r.m; out[n].n = r.n; out[n].k = r.k; out[n].variant = r.variant; out[n].reserved = 0;
         }
         ++n;
     }

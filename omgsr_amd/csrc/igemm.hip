@@ -364,6 +364,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         if (splits > 1) {
             if (a.gn_partial) return OMGSR_E_BADARG;        // the reduce pass does not emit GroupNorm statistics (omgsr_igemm_gn_slots says so)
             g.splits = splits;
+            ts.rec.variant = 4;
             const int rc = omgsr::igemm_dma_launch(a, g, st);
             if (rc != 0) return rc;
             const int ldw = ((logical_cols + 127) / 128) * 128;
@@ -379,10 +380,13 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         gn_plan(a, &nslot, &entries);
         if (nslot <= 0 || a.gn_entries != entries) return OMGSR_E_BADARG;
     }
-    if (use_halo(a)) return omgsr::igemm_halo_launch(a, g, st);
+    if (use_halo(a)) { ts.rec.variant = 3; return omgsr::igemm_halo_launch(a, g, st); }
     const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0;   // the DMA kernel's K-steps never straddle taps
-    if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192)))
+    if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192))) {
+        ts.rec.variant = 2;
         return omgsr::igemm_dma_launch(a, g, st);
+    }
+    ts.rec.variant = 1;
     if (a.act == OMGSR_ACT_GEGLU) return launch<128, 128, 2, 2>(a, g, st);   // needs a 64-wide wave tile
     if (logical_cols <= 32) return launch<128, 32, 4, 1>(a, g, st);
     if (logical_cols <= 64 || tiles128 < 192) return launch<64, 64, 2, 2>(a, g, st);

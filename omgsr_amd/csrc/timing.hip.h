@@ -7,7 +7,7 @@
 enum { OMGSR_TK_IGEMM = 1, OMGSR_TK_ATTN = 2, OMGSR_TK_GN = 3, OMGSR_TK_LN = 4, OMGSR_TK_ELT = 5, OMGSR_TK_SOFTMAX = 6 };
 
 namespace omgsr {
-struct TimingRec { int kind; double flops, bytes; long long m, n, k; hipEvent_t e0, e1; };
+struct TimingRec { int kind; double flops, bytes; long long m, n, k; hipEvent_t e0, e1; int variant = 0; };
 struct TimingState {
     bool on = false;
     std::vector<TimingRec> recs;

@@ -7,6 +7,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_shard_range_partitions_exactly():
     from omgsr_amd.dist import shard_range
@@ -64,3 +66,20 @@ def test_broadcast_and_checksum_world2():
     for r, w, same_before, moved, same_after, equal, t in res:
         assert w == 2 and not same_before and same_after and equal
         assert moved == nbytes and t == 2.0
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` outside a torchrun environment launches 2 ranks itself (child torchrun, parent never touches a
+    GPU) and rank 0 reports n_gpus 2, dp2 and the bytes the weight broadcast moved. CPU rehearsal: gloo, reduced models."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--dry-run-cpu"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["world_size"] == 2 and j["config"]["parallelism"].startswith("dp2")
+    assert j["config"]["broadcast_bytes"] > 1 << 20 and j["config"]["global_batch"] == 4 and j["scaling"] == "weak"

@@ -177,7 +177,7 @@ def _report(name, got, ref, tol=1e-3):
 def test_models_accurate_tier(policy):
     """Small VAE + UNet through the reference-shaped pipeline in the accurate tier. With no split operand what is left is one
     fp16 rounding per GEMM input (1.7e-3 on these narrow random-weight nets, which amplify more than the SD2.1 shapes:
-    tests/test_fullsize_parity_gpu.py); the default policy brings it under the north-star 1e-3, splitting everything to 1e-4."""
+    tests/test_fullsize_parity_gpu.py); the default policy brings it under the north-star 1e-3, splitting everything to 2e-4 (what is left: softmax probabilities and q, k, v are single fp16 operands)."""
     from omgsr_amd import precision
     from omgsr_amd.diffusers_api import AutoencoderKL, UNet2DConditionModel
     from omgsr_amd.pipelines.omgsr_s import OMGSR_S_Infer
@@ -201,7 +201,7 @@ def test_models_accurate_tier(policy):
         ref = OmgsrSRef(ov, ou, R.DDPMScheduler().alphas_cumprod[273], 273)(x, ehs, 16, 8)
         got, _ = pipe(x.to(DEV), ehs.to(DEV), 16, 8)
     assert got.dtype == torch.float32 and got.shape == ref.shape
-    _report(f"OMGSR-S small, accurate tier, policy {policy}", got, ref, {"none": 3e-3, "default": 1e-3, "all": 1.5e-4}[policy])
+    _report(f"OMGSR-S small, accurate tier, policy {policy}", got, ref, {"none": 3e-3, "default": 1e-3, "all": 4e-4}[policy])
 
 
 def test_flux_accurate_tier():
@@ -221,7 +221,7 @@ def test_flux_accurate_tier():
     with torch.no_grad():
         ref = o(hidden_states=x, timestep=t, guidance=gd, pooled_projections=pooled, encoder_hidden_states=pe, txt_ids=tids,
                 img_ids=iids, return_dict=False)[0]
-        for pats, tol in (([], 1e-3), ([r"."], 1.5e-4)):
+        for pats, tol in (([], 1e-3), ([r"."], 4e-4)):
             precision.set_operand_split(p, pats)
             got = p(hidden_states=x.to(DEV), timestep=t.to(DEV), guidance=gd.to(DEV), pooled_projections=pooled.to(DEV),
                     encoder_hidden_states=pe.to(DEV), txt_ids=tids.to(DEV), img_ids=iids.to(DEV), return_dict=False)[0]
