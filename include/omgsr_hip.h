@@ -274,6 +274,19 @@ int64_t omgsr_colorfix_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t 
 int omgsr_colorfix(const void* sr_nhwc, int32_t sr_ld, const uint8_t* src_hwc3, uint8_t* out_hwc3, void* workspace,
                    int32_t N, int32_t H, int32_t W, int32_t method, int32_t sr_el, void* stream);
 
+/*
+ * SURVEY §8(f) f2 — the driver's PRE-process on the device (replaces the PIL resizes of infer/infer_omgsr_s.py:71-84:
+ * `Image.resize` BICUBIC x upscale, then LANCZOS to width / height multiples of 8): ONE pass of Pillow's 8-bit resampler
+ * (libImaging/Resample.c ImagingResampleHorizontal / Vertical_8bpc), bit for bit.
+ *   src u8 [N,Hin,Win,3] (PIL memory order)  ->  dst u8 [N,Hout,Wout,3]; axis 1: horizontal (Wout = out_size, Hout = Hin),
+ *   axis 0: vertical (Hout = out_size, Wout = Win). Per output index o along the axis: bounds[2o] = first input index,
+ *   bounds[2o+1] = tap count (<= ksize), kk[o*ksize + t] = weight of tap t in 2^22 fixed point (device int32 tables, computed
+ *   on the host in float64 like Pillow: omgsr_amd/preprocess.py). dst = clip8((2^21 + sum(src * kk)) >> 22).
+ * Image.resize = the horizontal pass, then the vertical pass on its 8-bit result; a pass whose size does not change is skipped.
+ */
+int omgsr_resample_u8(const uint8_t* src, uint8_t* dst, const int32_t* bounds, const int32_t* kk, int32_t ksize,
+                      int32_t N, int32_t Hin, int32_t Win, int32_t out_size, int32_t axis, void* stream);
+
 /* Optional per-launch timing (HIP events on the launch stream) for bench.py's roofline leg. */
 int omgsr_timing_enable(int on);
 int omgsr_timing_reset(void);

@@ -102,6 +102,7 @@ SIGNATURES = {
     "omgsr_crop_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "omgsr_paste_nhwc": (C.c_int, [_P, _P] + [_I] * 13 + [_P]),
     "omgsr_flux_pack": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "omgsr_resample_u8": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "omgsr_timing_enable": (C.c_int, [C.c_int]),
     "omgsr_timing_reset": (C.c_int, []),
     "omgsr_timing_collect": (C.c_int, [C.POINTER(TimingEntry), C.c_int]),

@@ -51,6 +51,11 @@ class ResnetBlock2D(nn.Module):
         sc = self.conv_shortcut.nhwc(x, pad=0) if self.conv_shortcut is not None else x
         return self.conv2.nhwc(h, residual=sc, gn_groups=self.norm1.num_groups)             # ... and the next block's norm1
 
+    def forward(self, x, temb=None):  # NCHW (diffusers calling convention; the VAE variant has no temb)
+        if temb is not None or self.time_emb_proj is not None:
+            raise NotImplementedError("ResnetBlock2D.forward: the UNet folds the time embedding at fixed t* (UNet2DConditionModel.nhwc)")
+        return _nchw_call(self.nhwc, x, self.out_channels)
+
 
 class Downsample2D(nn.Module):
     def __init__(self, channels: int, padding: int):
@@ -63,6 +68,9 @@ class Downsample2D(nn.Module):
         pad = (0, 1, 0, 1) if self.padding == 0 else self.padding
         return self.conv.nhwc(x, pad=pad, gn_groups=gn_groups)
 
+    def forward(self, x):  # NCHW: what infer/vaehook.py:318-323 calls as `module[i_level].downsamplers[0]`
+        return _nchw_call(self.nhwc, x, self.conv.out_channels)
+
 
 class Upsample2D(nn.Module):
     def __init__(self, channels: int):
@@ -72,6 +80,11 @@ class Upsample2D(nn.Module):
     def nhwc(self, x, gn_groups: int = 0):
         """gn_groups: groups of the GroupNorm that consumes the result directly (VAE decoder: the next block's norm1)."""
         return self.conv.nhwc(x, upsample=True, gn_groups=gn_groups)
+
+    def forward(self, x, output_size=None):  # NCHW (`module[i_level].upsamplers[0]`)
+        if output_size is not None:
+            raise NotImplementedError("Upsample2D.forward: explicit output_size (odd latent shapes) is outside the hot path (SURVEY A.6)")
+        return _nchw_call(self.nhwc, x, self.conv.out_channels)
 
 
 class VaeAttention(nn.Module):
@@ -95,6 +108,11 @@ class VaeAttention(nn.Module):
 
     def nhwc(self, x):
         return self.attend(self.group_norm.nhwc(x, split=self.qkv_split()), x)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):  # NCHW, with the residual
+        if encoder_hidden_states is not None or attention_mask is not None:
+            raise NotImplementedError("VaeAttention is the VAE mid block's unmasked self-attention")
+        return _nchw_call(self.nhwc, hidden_states, hidden_states.shape[1])
 
     def attend(self, g, residual):
         """g: GroupNorm'ed operand [N,H,W,C*split] (the tiled VAE supplies cross-tile statistics); returns residual + attn."""
@@ -257,6 +275,12 @@ class Decoder(nn.Module):
 
 def _io_dtype(x):
     return ops.io_dtype(x)
+
+
+def _nchw_call(fn, x, channels):
+    """Run an NHWC executor on an NCHW tensor (leaf modules called op by op by diffusers-style code)."""
+    y = fn(ops.nchw_to_nhwc(x.contiguous(), ops._round_up(x.shape[1], 8)))
+    return ops.nhwc_to_nchw(y, channels=channels, dtype=_io_dtype(x)).to(x.dtype)
 
 
 class DiagonalGaussianDistribution:

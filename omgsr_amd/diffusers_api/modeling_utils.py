@@ -50,7 +50,7 @@ class ModelMixin(nn.Module):
         with open(os.path.join(root, cls.config_name)) as f:
             cfg = json.load(f)
         model = cls.from_config(cfg)
-        sd = load_safetensors_dir(root)
+        sd = convert_legacy_keys(load_safetensors_dir(root), model)
         missing, unexpected = model.load_state_dict(sd, strict=False)
         if missing or unexpected:
             raise RuntimeError(f"{cls.__name__}.from_pretrained({root}): missing keys {missing[:5]}..., unexpected {unexpected[:5]}...")
@@ -58,13 +58,61 @@ class ModelMixin(nn.Module):
             model = model.to(torch_dtype)
         return model.eval()
 
-    def save_pretrained(self, path: str, subfolder: str | None = None):
+    def save_pretrained(self, path: str, subfolder: str | None = None, max_shard_size: int | None = None):
+        """HF layout: one `diffusion_pytorch_model.safetensors`, or (max_shard_size bytes given and exceeded) numbered shards +
+        `diffusion_pytorch_model.safetensors.index.json` with the `weight_map` diffusers writes (FLUX.1-dev ships 3 shards)."""
         from safetensors.torch import save_file
         root = os.path.join(path, subfolder) if subfolder else path
         os.makedirs(root, exist_ok=True)
         with open(os.path.join(root, self.config_name), "w") as f:
             json.dump({"_class_name": type(self).__name__, **dict(self.config)}, f, indent=1)
-        save_file({k: v.contiguous() for k, v in self.state_dict().items()}, os.path.join(root, "diffusion_pytorch_model.safetensors"))
+        sd = {k: v.contiguous() for k, v in self.state_dict().items()}
+        total = sum(v.numel() * v.element_size() for v in sd.values())
+        if not max_shard_size or total <= max_shard_size:
+            save_file(sd, os.path.join(root, "diffusion_pytorch_model.safetensors"))
+            return
+        shards, cur, size = [], {}, 0
+        for k, v in sd.items():
+            n = v.numel() * v.element_size()
+            if cur and size + n > max_shard_size:
+                shards.append(cur)
+                cur, size = {}, 0
+            cur[k] = v
+            size += n
+        shards.append(cur)
+        weight_map = {}
+        for i, sh in enumerate(shards):
+            name = f"diffusion_pytorch_model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+            save_file(sh, os.path.join(root, name))
+            weight_map.update({k: name for k in sh})
+        with open(os.path.join(root, "diffusion_pytorch_model.safetensors.index.json"), "w") as f:
+            json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=1)
+
+
+_LEGACY_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def convert_legacy_keys(sd: dict, model: nn.Module) -> dict:
+    """Checkpoint key names older than the module tree, converted the way diffusers does at load time
+    (`_convert_deprecated_attention_blocks`): the SD2.1-base VAE stores its mid-block attention as
+    `mid_block.attentions.0.{query,key,value,proj_attn}.{weight,bias}`; some VAEs keep those projections as 1x1
+    convolution weights [C, C, 1, 1]. Keys the model already knows are left alone."""
+    want = model.state_dict()
+    out = {}
+    for k, v in sd.items():
+        nk = k
+        if k not in want:
+            parts = k.split(".")
+            for i, p in enumerate(parts):
+                if p in _LEGACY_ATTN and i > 0 and parts[i - 1].isdigit() and "attentions" in parts[:i]:
+                    cand = ".".join(parts[:i] + [_LEGACY_ATTN[p]] + parts[i + 1:])
+                    if cand in want:
+                        nk = cand
+                    break
+        if nk in want and v.dim() == 4 and want[nk].dim() == 2 and v.shape[2:] == (1, 1):
+            v = v[:, :, 0, 0]
+        out[nk] = v
+    return out
 
 
 def load_safetensors_dir(root: str) -> dict:

@@ -244,10 +244,8 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
         self.round_timestep_to_weight_dtype = True
 
     # ---- constant folding ------------------------------------------------------------------
-    @torch.no_grad()
-    def _modulation(self, timestep: torch.Tensor, guidance: Optional[torch.Tensor], pooled: torch.Tensor):
-        # diffusers: `timestep.to(hidden_states.dtype) * 1000` - a 16-bit model sees the timestep ROUNDED to its dtype before
-        # the scaling (bf16: 0.50511 -> 0.50390625 -> 503.9 -> bf16 504.0; SURVEY C-7), the fp32 model 505.11
+    def _mod_key(self, timestep, guidance) -> tuple:
+        """(scaled timestep, scaled guidance, identity of every parameter the modulation tables depend on)."""
         wd = self.x_embedder.weight.dtype
         rt = (lambda v: float((torch.tensor(v, dtype=torch.float32).to(wd) * 1000).float())) if (wd != torch.float32 and self.round_timestep_to_weight_dtype) \
             else (lambda v: v * 1000.0)
@@ -258,7 +256,14 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
             for nm in ("norm1", "norm1_context", "norm"):
                 if hasattr(b, nm):
                     deps += list(getattr(b, nm).parameters())
-        wkey = (t, g, _key(*deps))
+        return (t, g, _key(*deps))
+
+    @torch.no_grad()
+    def _modulation(self, timestep: torch.Tensor, guidance: Optional[torch.Tensor], pooled: torch.Tensor):
+        # diffusers: `timestep.to(hidden_states.dtype) * 1000` - a 16-bit model sees the timestep ROUNDED to its dtype before
+        # the scaling (bf16: 0.50511 -> 0.50390625 -> 503.9 -> bf16 504.0; SURVEY C-7), the fp32 model 505.11
+        wkey = self._mod_key(timestep, guidance)
+        t, g = wkey[0], wkey[1]
 
         def build():
             dev = self.x_embedder.weight.device
@@ -281,7 +286,10 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
         def build():
             e = ehs.float().contiguous() if ops.precise() else ehs.to(ops.act_dtype()).contiguous()
             return self.context_embedder.nhwc(e)
-        return self._ctx_cache.get((ehs,), _key(self.context_embedder.weight, self.context_embedder.bias, self.context_embedder.in_split()), build)
+        return self._ctx_cache.get((ehs,), self._ctx_key(), build)
+
+    def _ctx_key(self) -> tuple:
+        return _key(self.context_embedder.weight, self.context_embedder.bias, self.context_embedder.in_split())
 
     # ---- token executor --------------------------------------------------------------------
     def tokens(self, x_tok: torch.Tensor, timestep, guidance, pooled, ehs, txt_ids, img_ids) -> torch.Tensor:

@@ -108,7 +108,10 @@ class Attention(nn.Module):
             kk = ops.linear(e, self.to_k.packed(), out_dtype=ops.OUT_BF16)      # [Bc, 77, inner]
             vt = ops.linear_t(e, self.to_v.packed(), e.shape[1])                # [Bc, inner, 80]
             return kk, vt, e.shape[1]
-        return self._ctx_cache.get((ehs,), _key(self.to_k.weight, self.to_v.weight, self.to_k.in_split()), build)
+        return self._ctx_cache.get((ehs,), self._ctx_key(), build)
+
+    def _ctx_key(self) -> tuple:
+        return _key(self.to_k.weight, self.to_v.weight, self.to_k.in_split())
 
     def cross_nhwc(self, xn: torch.Tensor, ehs: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         kk, vt, Lk = self.context(ehs)
@@ -245,15 +248,19 @@ class UNet2DConditionModel(ModelMixin):
         for b in self.up_blocks:
             yield from b.resnets
 
-    def _folded_biases(self, timestep) -> dict:
-        """{id(resnet): conv1.bias + time_emb_proj(silu(time_embedding(sinusoid(t))))} in fp32."""
+    def _fold_key(self, timestep) -> tuple:
         t = int(timestep) if not torch.is_tensor(timestep) else int(timestep.reshape(-1)[0].item())
         # every parameter the folded biases depend on is in the key (a LoRA merge into one resnet's time_emb_proj must refold)
         deps = [self.time_embedding.linear_1.weight, self.time_embedding.linear_1.bias, self.time_embedding.linear_2.weight,
                 self.time_embedding.linear_2.bias]
         for r in self._resnets():
             deps += [r.time_emb_proj.weight, r.time_emb_proj.bias, r.conv1.bias]
-        key = (t, _key(*deps))
+        return (t, _key(*deps))
+
+    def _folded_biases(self, timestep) -> dict:
+        """{id(resnet): conv1.bias + time_emb_proj(silu(time_embedding(sinusoid(t))))} in fp32."""
+        key = self._fold_key(timestep)
+        t = key[0]
         if key not in self._temb_cache:
             dev = self.conv_in.weight.device
             with torch.no_grad():

@@ -33,6 +33,11 @@ class InputCache:
     def __init__(self):
         self._inputs, self._versions, self._wkey, self._value = None, None, None, None
 
+    def prime(self, inputs: tuple, wkey: tuple, value) -> None:
+        """Install a value computed elsewhere (omgsr_amd.constants: the serialised constant cache)."""
+        self._value, self._inputs, self._wkey = value, tuple(inputs), wkey
+        self._versions = tuple(None if t is None else t._version for t in inputs)
+
     def get(self, inputs: tuple, wkey: tuple, builder):
         same = (self._inputs is not None and len(self._inputs) == len(inputs) and self._wkey == wkey and
                 all(a is b for a, b in zip(self._inputs, inputs)) and

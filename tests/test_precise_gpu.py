@@ -237,6 +237,8 @@ def test_tiled_vae_accurate_tier(fast):
     from oracle import vaehook_ref as V
     cfg = dict(block_out_channels=[32, 32, 64, 64], layers_per_block=2, norm_num_groups=32)
     p, o = _pair(AutoencoderKL, R.AutoencoderKL, cfg, 9)
+    from omgsr_amd.precision import apply_default_policy
+    apply_default_policy(vae=p)                  # what OMGSR_{S,F}_Infer(weight_dtype=float32) installs
     g = _g(41)
     img = torch.randn(2, 3, 160, 224, generator=g).clamp(-2, 2)
     z = torch.randn(2, 4, 28, 36, generator=g)
