@@ -158,14 +158,17 @@ typedef struct omgsr_gn_merge_args {
 int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, float* mean, float* rstd, float* var_out,
                                     int32_t N, int32_t G, float eps, void* stream);
 /* y = act((x - mean[n,g]) * rstd[n,g] * gamma[c] + beta[c]);  act in {NONE, SILU}. x and y may alias when both are
- * OMGSR_EL_16. x_el: OMGSR_EL_16 | OMGSR_EL_F32; y_el: OMGSR_EL_16 | OMGSR_EL_SPLIT (y is an MFMA operand). */
+ * OMGSR_EL_16. x_el: OMGSR_EL_16 | OMGSR_EL_F32; y_el: OMGSR_EL_16 | OMGSR_EL_SPLIT (y is an MFMA operand).
+ * y2 (optional, x_el OMGSR_EL_F32 only): a second output, x ITSELF rounded to an operand of kind y2_el (OMGSR_EL_16 |
+ * OMGSR_EL_SPLIT) - the input of the ResnetBlock's 1x1 conv_shortcut, cast while the tensor streams by. */
 int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int32_t N, int64_t HW, int32_t C,
-                          int32_t G, int32_t act, int32_t x_el, int32_t y_el, void* stream);
+                          int32_t G, int32_t act, int32_t x_el, int32_t y_el, void* y2, int32_t y2_el, void* stream);
 /* Same with `rows` rows of x sharing `stat_rows` rows of statistics: row r uses mean[r % stat_rows] (tile-major tiles). */
 int omgsr_groupnorm_apply_shared(const void* x, void* y, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, int32_t rows, int64_t HW, int32_t C,
-                                 int32_t G, int32_t act, int32_t stat_rows, int32_t x_el, int32_t y_el, void* stream);
+                                 int32_t G, int32_t act, int32_t stat_rows, int32_t x_el, int32_t y_el, void* y2, int32_t y2_el,
+                                 void* stream);
 
 /*
  * K9/K10 — LayerNorm over the last dim (replaces F.layer_norm and the AdaLN-Zero modulate chain of

@@ -80,13 +80,13 @@ SIGNATURES = {
     "omgsr_groupnorm_finalize": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, C.c_double, _F, _P]),
     "omgsr_groupnorm_partial": (C.c_int, [_P, _P, _I, _L, _I, _I, _I, _P]),
     "omgsr_groupnorm_finalize_merged": (C.c_int, [C.POINTER(GnMergeArgs), _P, _P, _P, _I, _I, _F, _P]),
-    "omgsr_groupnorm_apply_shared": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "omgsr_groupnorm_apply_shared": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "omgsr_image_to_model_input": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "omgsr_colorfix_workspace_bytes": (C.c_int64, [_I, _I, _I, _I]),
     "omgsr_colorfix": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "omgsr_groupnorm_nchunk": (C.c_int, [_L]),
     "omgsr_groupnorm_stats": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P]),
-    "omgsr_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P]),
+    "omgsr_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _I, _P]),
     "omgsr_layernorm": (C.c_int, [_P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
     "omgsr_to_operand": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "omgsr_attention": (C.c_int, [C.POINTER(AttnArgs), _P]),

@@ -164,11 +164,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 // The same for the accurate tier's element kinds: fp32 stream input (XF32) and / or a two-term split operand output
 // (YEL = OMGSR_EL_SPLIT: hi at channel c, lo at channel C + c of a 2C-wide row). Chunk i of the block is (pixel, octet) =
 // (i / nch8, i % nch8), tracked incrementally.
-template <typename T, bool XF32, int YEL>
+// Y2EL >= 0: a second output y2 = x itself as an MFMA operand (plain or two-term split), no affine / activation: the block's
+// 1x1 shortcut conv reads the same tensor this kernel already streams, so its cast costs a write and no extra read.
+template <typename T, bool XF32, int YEL, int Y2EL = -1>
 __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            int64_t HW, int C, int G, int act, int64_t px_per_block, int stat_rows) {
+                                                            int64_t HW, int C, int G, int act, int64_t px_per_block, int stat_rows,
+                                                            void* __restrict__ y2 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float gn_lds[];
     float* sc = gn_lds;
     float* sh = gn_lds + C;
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
     for (int i = t; i < total; i += 256) {
         float f[8];
         load8<T, XF32>(x, (pix0 + px) * C + c8 * 8, f);
+        if constexpr (Y2EL >= 0) store8<T, Y2EL>(y2, (pix0 + px) * (Y2EL == 2 ? 2 * C : C) + c8 * 8, C, f);
         const f32x4_t* sa = reinterpret_cast<const f32x4_t*>(sc + c8 * 8);
         const f32x4_t* ha = reinterpret_cast<const f32x4_t*>(sh + c8 * 8);
         const f32x4_t sa0 = sa[0], sa1 = sa[1], ha0 = ha[0], ha1 = ha[1];
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(256) void gn_finalize_merged_kernel(const omgsr_gn_
 namespace {
 int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, int32_t x_el,
-                    int32_t y_el, void* stream);
+                    int32_t y_el, void* y2, int32_t y2_el, void* stream);
 }
 
 extern "C" int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t x_el, void* stream) {
@@ -544,23 +548,24 @@ extern "C" int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, flo
 
 extern "C" int omgsr_groupnorm_apply_shared(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                                             const float* beta, int32_t rows, int64_t HW, int32_t C, int32_t G, int32_t act,
-                                            int32_t stat_rows, int32_t x_el, int32_t y_el, void* stream) {
+                                            int32_t stat_rows, int32_t x_el, int32_t y_el, void* y2, int32_t y2_el, void* stream) {
     if (stat_rows <= 0 || rows % stat_rows) return OMGSR_E_BADARG;
-    return gn_apply_launch(x, y, mean, rstd, gamma, beta, rows, HW, C, G, act, stat_rows, x_el, y_el, stream);
+    return gn_apply_launch(x, y, mean, rstd, gamma, beta, rows, HW, C, G, act, stat_rows, x_el, y_el, y2, y2_el, stream);
 }
 
 extern "C" int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                                      const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act,
-                                     int32_t x_el, int32_t y_el, void* stream) {
-    return gn_apply_launch(x, y, mean, rstd, gamma, beta, N, HW, C, G, act, N, x_el, y_el, stream);
+                                     int32_t x_el, int32_t y_el, void* y2, int32_t y2_el, void* stream) {
+    return gn_apply_launch(x, y, mean, rstd, gamma, beta, N, HW, C, G, act, N, x_el, y_el, y2, y2_el, stream);
 }
 
 namespace {
 int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, int32_t x_el,
-                    int32_t y_el, void* stream) {
+                    int32_t y_el, void* y2, int32_t y2_el, void* stream) {
     if (!x || !y || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
     if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT)) return OMGSR_E_BADARG;
+    if (y2 && (x_el != OMGSR_EL_F32 || (y2_el != OMGSR_EL_16 && y2_el != OMGSR_EL_SPLIT))) return OMGSR_E_BADARG;
     if ((C & 7) || (C % G) || C > 8192) return OMGSR_E_SHAPE;
     if (act != OMGSR_ACT_NONE && act != OMGSR_ACT_SILU) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -570,16 +575,24 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
     int64_t ppb = (belems + C - 1) / C;      // ~32 KB of activations per block (5.6 TB/s; 64 KB 5.4, 128 KB 4.9, 256 KB 30 % slower)
     if (ppb < 1) ppb = 1;
     const int nblk = (int)((HW + ppb - 1) / ppb);
-    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, ((x_el == OMGSR_EL_F32 ? 4.0 : 2.0) + (y_el == OMGSR_EL_SPLIT ? 4.0 : 2.0)) * N * (double)HW * C, st);
+    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, ((x_el == OMGSR_EL_F32 ? 4.0 : 2.0) + (y_el == OMGSR_EL_SPLIT ? 4.0 : 2.0) +
+                                             (y2 ? (y2_el == OMGSR_EL_SPLIT ? 4.0 : 2.0) : 0.0)) * N * (double)HW * C, st);
     const size_t lds = 2 * C * sizeof(float);
     const dim3 grid(nblk, N);
+#define OMGSR_GN_ANY2(YE, Y2) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, true, YE, Y2>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2))
 #define OMGSR_GN_ANY(XF, YE) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, XF, YE>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows))
-    if (x_el == OMGSR_EL_F32 && y_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY(true, 2);
+    if (y2) {
+        if (y_el == OMGSR_EL_SPLIT && y2_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY2(2, 2);
+        else if (y_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY2(2, 0);
+        else if (y2_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY2(0, 2);
+        else OMGSR_GN_ANY2(0, 0);
+    } else if (x_el == OMGSR_EL_F32 && y_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY(true, 2);
     else if (x_el == OMGSR_EL_F32) OMGSR_GN_ANY(true, 0);
     else if (y_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY(false, 2);
     else OMGSR_DISPATCH_T(hipLaunchKernelGGL(gn_apply_kernel<T>, grid, dim3(256), lds, st, (const T*)x,
                                              (T*)y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows));
 #undef OMGSR_GN_ANY
+#undef OMGSR_GN_ANY2
     return (int)hipGetLastError();
 }
 }  // namespace

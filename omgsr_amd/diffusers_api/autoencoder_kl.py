@@ -43,12 +43,20 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = Conv2d(in_channels, out_channels, 1) if self.use_in_shortcut else None
         self.nonlinearity = nn.SiLU()
 
-    def nhwc(self, x, conv1_bias=None):
-        """conv1_bias: conv1.bias + time_emb_proj(silu(temb)) folded by the UNet (constant at fixed t*)."""
-        h = self.norm1.nhwc(x, ops.ACT_SILU, split=self.conv1.in_split())
+    def nhwc(self, x, conv1_bias=None, out_for=None):
+        """conv1_bias: conv1.bias + time_emb_proj(silu(temb)) folded by the UNet (constant at fixed t*).
+        out_for: the ONLY consumer of the result is that conv / linear (an up / down-sampling conv): the result is written
+        directly as its MFMA operand (no fp32 stream copy, no cast pass)."""
+        if self.conv_shortcut is not None:
+            # the 1x1 shortcut reads x itself: its operand copy is a second output of norm1's apply pass over x
+            h, xc = self.norm1.nhwc(x, ops.ACT_SILU, split=self.conv1.in_split(), also_cast=self.conv_shortcut.in_split())
+        else:
+            h, xc = self.norm1.nhwc(x, ops.ACT_SILU, split=self.conv1.in_split()), None
         h = self.conv1.nhwc(h, bias_override=conv1_bias, gn_groups=self.norm2.num_groups)     # norm2's statistics ride the epilogue
         h = self.norm2.nhwc(h, ops.ACT_SILU, split=self.conv2.in_split())
-        sc = self.conv_shortcut.nhwc(x, pad=0) if self.conv_shortcut is not None else x
+        sc = self.conv_shortcut.nhwc(xc, pad=0) if self.conv_shortcut is not None else x
+        if out_for is not None:
+            return self.conv2.nhwc(h, residual=sc, out_dtype=ops.OUT_BF16, out_split=out_for.in_split())
         return self.conv2.nhwc(h, residual=sc, gn_groups=self.norm1.num_groups)             # ... and the next block's norm1
 
     def forward(self, x, temb=None):  # NCHW (diffusers calling convention; the VAE variant has no temb)
@@ -183,10 +191,11 @@ class DownEncoderBlock2D(nn.Module):
         self.downsamplers = nn.ModuleList([Downsample2D(cout, 0)]) if add_down else None
 
     def nhwc(self, h):
-        for r in self.resnets:
-            h = r.nhwc(h)
-        if self.downsamplers is not None:
-            h = self.downsamplers[0].nhwc(h, gn_groups=self.resnets[0].norm1.num_groups)
+        samp = self.downsamplers[0] if self.downsamplers is not None else None
+        for j, r in enumerate(self.resnets):
+            h = r.nhwc(h, out_for=samp.conv if (samp is not None and j == len(self.resnets) - 1) else None)
+        if samp is not None:
+            h = samp.nhwc(h, gn_groups=self.resnets[0].norm1.num_groups)
         return h
 
 
@@ -197,10 +206,11 @@ class UpDecoderBlock2D(nn.Module):
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_up else None
 
     def nhwc(self, h):
-        for r in self.resnets:
-            h = r.nhwc(h)
-        if self.upsamplers is not None:
-            h = self.upsamplers[0].nhwc(h, gn_groups=self.resnets[0].norm1.num_groups)
+        samp = self.upsamplers[0] if self.upsamplers is not None else None
+        for j, r in enumerate(self.resnets):
+            h = r.nhwc(h, out_for=samp.conv if (samp is not None and j == len(self.resnets) - 1) else None)
+        if samp is not None:
+            h = samp.nhwc(h, gn_groups=self.resnets[0].norm1.num_groups)
         return h
 
 

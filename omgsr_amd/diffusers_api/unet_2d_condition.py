@@ -138,9 +138,11 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim)])
 
-    def nhwc(self, xn, residual):
+    def nhwc(self, xn, residual, out_for=None):
         # a * gelu(gate) in the GEMM epilogue; the hidden tensor is the operand of net[2]
         h = ops.linear(xn, self.net[0].packed(), out_dtype=ops.OUT_BF16, out_split=self.net[2].in_split())
+        if out_for is not None:       # the sum's only consumer is that linear (Transformer2DModel.proj_out): write its operand directly
+            return self.net[2].nhwc(h, residual=residual, out_dtype=ops.OUT_BF16, out_split=out_for.in_split())
         return self.net[2].nhwc(h, residual=residual)
 
 
@@ -154,10 +156,10 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim, eps=1e-5)
         self.ff = FeedForward(dim)
 
-    def nhwc(self, y, ehs):
+    def nhwc(self, y, ehs, out_for=None):
         y = self.attn1.self_nhwc(self.norm1.nhwc(y, split=self.attn1.in_split()), y)
         y = self.attn2.cross_nhwc(self.norm2.nhwc(y, split=self.attn2.in_split()), ehs, y)
-        return self.ff.nhwc(self.norm3.nhwc(y, split=self.ff.net[0].proj.in_split()), y)
+        return self.ff.nhwc(self.norm3.nhwc(y, split=self.ff.net[0].proj.in_split()), y, out_for=out_for)
 
 
 class Transformer2DModel(nn.Module):
@@ -168,12 +170,17 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(channels, heads, dim_head, cross_attention_dim)])
         self.proj_out = Linear(channels, channels)
 
-    def nhwc(self, x, ehs):
+    def nhwc(self, x, ehs, out_for=None):
+        """out_for: the result's only consumer is that conv (the up block's upsampler): written directly as its operand."""
         N, H, W, Cc = x.shape
         res = x.reshape(N, H * W, Cc)
         y = self.proj_in.nhwc(self.norm.nhwc(x, split=self.proj_in.in_split()).reshape(N, H * W, -1))
-        for blk in self.transformer_blocks:
-            y = blk.nhwc(y, ehs)
+        nb = len(self.transformer_blocks)
+        for i, blk in enumerate(self.transformer_blocks):
+            y = blk.nhwc(y, ehs, out_for=self.proj_out if i == nb - 1 else None)
+        if out_for is not None:
+            out = self.proj_out.nhwc(y, residual=res, out_dtype=ops.OUT_BF16, out_split=out_for.in_split())
+            return out.reshape(N, H, W, -1)
         out = self.proj_out.nhwc(y, residual=res, gn_groups=self.norm.num_groups)     # a resnet's GroupNorm usually consumes it
         return ops.carry_gn(out, out.reshape(N, H, W, Cc))
 
@@ -296,11 +303,13 @@ class UNet2DConditionModel(ModelMixin):
         h = m.attentions[0].nhwc(h, ehs)
         h = m.resnets[1].nhwc(h, fb[id(m.resnets[1])])
         for blk in self.up_blocks:
+            up = blk.upsamplers[0].conv if blk.upsamplers is not None else None
             for j, r in enumerate(blk.resnets):
+                last = up if j == len(blk.resnets) - 1 else None       # the block's last tensor feeds only the upsampling conv
                 h = ops.concat_channels(h, skips.pop())
-                h = r.nhwc(h, fb[id(r)])
+                h = r.nhwc(h, fb[id(r)], out_for=last if blk.attentions is None else None)
                 if blk.attentions is not None:
-                    h = blk.attentions[j].nhwc(h, ehs)
+                    h = blk.attentions[j].nhwc(h, ehs, out_for=last)
             if blk.upsamplers is not None:
                 h = blk.upsamplers[0].nhwc(h)
         h = self.conv_norm_out.nhwc(h, ops.ACT_SILU, split=self.conv_out.in_split())

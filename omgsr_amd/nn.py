@@ -111,20 +111,21 @@ class GroupNorm(nn.GroupNorm, _Packed):
         return self._packed(lambda: (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous()),
                             self.weight, self.bias)
 
-    def nhwc(self, x, act=ops.ACT_NONE, split=1):
-        """Stream tensor -> normalised (+SiLU) MFMA operand; split 2: as the two-term split its consumer asked for."""
+    def nhwc(self, x, act=ops.ACT_NONE, split=1, also_cast=0):
+        """Stream tensor -> normalised (+SiLU) MFMA operand; split 2: as the two-term split its consumer asked for.
+        also_cast 1 | 2: returns (operand, x itself as a plain / split operand) from the same pass over x."""
         g, b = self._affine()
-        return ops.group_norm(x, g, b, self.num_groups, self.eps, act, split=split)
+        return ops.group_norm(x, g, b, self.num_groups, self.eps, act, split=split, also_cast=also_cast)
 
     def stats(self, x):
         return ops.group_norm_stats(x, self.num_groups, self.eps)
 
-    def apply_stats(self, x, mean, rstd, act=ops.ACT_NONE, split=1):
+    def apply_stats(self, x, mean, rstd, act=ops.ACT_NONE, split=1, also_cast=0):
         """Normalise with externally supplied per-(n, group) statistics (tiled VAE)."""
         g, b = self._affine()
         if mean.shape[0] != x.shape[0]:       # tile-major rows sharing their image's statistics
-            return ops.group_norm_apply_shared(x, mean, rstd, g, b, self.num_groups, act, split=split)
-        return ops.group_norm_apply(x, mean, rstd, g, b, self.num_groups, act, split=split)
+            return ops.group_norm_apply_shared(x, mean, rstd, g, b, self.num_groups, act, split=split, also_cast=also_cast)
+        return ops.group_norm_apply(x, mean, rstd, g, b, self.num_groups, act, split=split, also_cast=also_cast)
 
     def forward(self, x):  # NCHW (or [B, C, L]) compat
         shp = x.shape

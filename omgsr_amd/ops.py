@@ -527,36 +527,57 @@ def _operand_like(x: torch.Tensor, split: int) -> torch.Tensor:
     return torch.empty((*x.shape[:-1], x.shape[-1] * split), device=x.device, dtype=_ACT)
 
 
+def _cast_twin(x: torch.Tensor, xel: int, also_cast: int):
+    """The optional second output of the GroupNorm apply kernels: x itself as an operand (a fp32 stream tensor only; a 16-bit
+    stream tensor IS its own operand)."""
+    if not also_cast:
+        return None
+    if xel != EL_F32:
+        if also_cast != 1:
+            raise ValueError("a 16-bit tensor cannot be split")
+        return x
+    return _operand_like(x, also_cast)
+
+
 def group_norm_apply_shared(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma, beta, groups: int,
-                            act: int = ACT_NONE, split: int = 1) -> torch.Tensor:
-    """x [T*N, ..., C] tile-major; mean / rstd [N, G]: row r is normalised with the statistics of image r % N."""
+                            act: int = ACT_NONE, split: int = 1, also_cast: int = 0):
+    """x [T*N, ..., C] tile-major; mean / rstd [N, G]: row r is normalised with the statistics of image r % N.
+    also_cast 1 | 2: returns (y, x as a plain / split operand) - see group_norm_apply."""
     xel = _el(x, "x")
     rows, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (rows * Cc)
     y = _operand_like(x, split)
+    y2 = _cast_twin(x, xel, also_cast)
+    fused = y2 is not None and y2 is not x
     check(_lib.load().omgsr_groupnorm_apply_shared(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
                                                    _ptr(beta), rows, HW, Cc, groups, act, mean.shape[0], xel,
-                                                   EL_SPLIT if split == 2 else EL_16, _stream()),
+                                                   EL_SPLIT if split == 2 else EL_16, y2.data_ptr() if fused else None,
+                                                   EL_SPLIT if also_cast == 2 else EL_16, _stream()),
           "omgsr_groupnorm_apply_shared")
-    return y
+    return (y, y2) if also_cast else y
 
 
 def group_norm_apply(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: Optional[torch.Tensor],
-                     beta: Optional[torch.Tensor], groups: int, act: int = ACT_NONE, inplace: bool = False, split: int = 1) -> torch.Tensor:
-    """Stream tensor -> normalised (+SiLU) MFMA operand [..., split*C]."""
+                     beta: Optional[torch.Tensor], groups: int, act: int = ACT_NONE, inplace: bool = False, split: int = 1,
+                     also_cast: int = 0):
+    """Stream tensor -> normalised (+SiLU) MFMA operand [..., split*C]. also_cast 1 | 2: additionally returns x itself as a
+    plain / two-term split operand (the input of a ResnetBlock's 1x1 shortcut conv), written by the same pass."""
     xel = _el(x, "x")
     N, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * Cc)
-    y = x if (inplace and xel == EL_16 and split == 1) else _operand_like(x, split)
+    y = x if (inplace and xel == EL_16 and split == 1 and not also_cast) else _operand_like(x, split)
+    y2 = _cast_twin(x, xel, also_cast)
+    fused = y2 is not None and y2 is not x
     check(_lib.load().omgsr_groupnorm_apply(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
-                                            _ptr(beta), N, HW, Cc, groups, act, xel, EL_SPLIT if split == 2 else EL_16, _stream()),
+                                            _ptr(beta), N, HW, Cc, groups, act, xel, EL_SPLIT if split == 2 else EL_16,
+                                            y2.data_ptr() if fused else None, EL_SPLIT if also_cast == 2 else EL_16, _stream()),
           "omgsr_groupnorm_apply")
-    return y
+    return (y, y2) if also_cast else y
 
 
-def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, act: int = ACT_NONE, split: int = 1) -> torch.Tensor:
+def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, act: int = ACT_NONE, split: int = 1, also_cast: int = 0):
     mean, rstd, _ = group_norm_stats(x, groups, eps)
-    return group_norm_apply(x, mean, rstd, gamma, beta, groups, act, split=split)
+    return group_norm_apply(x, mean, rstd, gamma, beta, groups, act, split=split, also_cast=also_cast)
 
 
 # --------------------------------------------------------------------------------------------

@@ -70,16 +70,21 @@ class VAEHook:
 
         # ("gn", norm, act, consumer): the normalised tensor is the consumer's MFMA operand (its in_split() picks the plain /
         # two-term split form in the accurate tier)
-        def resblock(b):
-            seq.append(("res_push", (lambda x, b=b: b.conv_shortcut.nhwc(x, pad=0)) if b.conv_shortcut is not None else None))
-            seq.append(("gn", b.norm1, ops.ACT_SILU, b.conv1))
+        # ("gn", ..., shortcut): the block's 1x1 conv_shortcut reads the same tensor norm1 normalises; its operand copy is a
+        # second output of the apply pass and the shortcut result is pushed as the residual (same values as infer/vaehook.py's
+        # ('store_res', conv_shortcut) -> ('pre_norm', norm1) order: neither op changes x)
+        # ("conv_res", conv2, gn_groups, out_for): out_for = the up / down-sampling conv that is the result's only consumer
+        def resblock(b, out_for=None):
+            if b.conv_shortcut is None:
+                seq.append(("res_push", None))
+            seq.append(("gn", b.norm1, ops.ACT_SILU, b.conv1, b.conv_shortcut))
             seq.append(("f", lambda x, b=b: b.conv1.nhwc(x, gn_groups=b.norm2.num_groups)))
-            seq.append(("gn", b.norm2, ops.ACT_SILU, b.conv2))
-            seq.append(("conv_res", b.conv2, b.norm1.num_groups))  # conv2 + residual in the GEMM epilogue (+ next GN statistics)
+            seq.append(("gn", b.norm2, ops.ACT_SILU, b.conv2, None))
+            seq.append(("conv_res", b.conv2, b.norm1.num_groups, out_for))  # conv2 + residual in the GEMM epilogue (+ next GN statistics)
 
         def attn(a):
             seq.append(("res_push", None))
-            seq.append(("gn", a.group_norm, ops.ACT_NONE, a.to_q))
+            seq.append(("gn", a.group_norm, ops.ACT_NONE, a.to_q, None))
             seq.append(("attn_res", a))
 
         def mid():
@@ -91,14 +96,14 @@ class VAEHook:
         else:
             blocks = net.down_blocks
         for i, blk in enumerate(blocks):
-            for r in blk.resnets:
-                resblock(r)
-            if i != len(blocks) - 1:
-                samp = blk.upsamplers[0] if dec else blk.downsamplers[0]
+            samp = None if i == len(blocks) - 1 else (blk.upsamplers[0] if dec else blk.downsamplers[0])
+            for j, r in enumerate(blk.resnets):
+                resblock(r, out_for=samp.conv if (samp is not None and j == len(blk.resnets) - 1) else None)
+            if samp is not None:
                 seq.append(("f", (lambda x, s=samp, g=blk.resnets[0].norm1.num_groups: s.nhwc(x, gn_groups=g))))
         if not dec:
             mid()
-        seq.append(("gn", net.conv_norm_out, ops.ACT_SILU, net.conv_out))
+        seq.append(("gn", net.conv_norm_out, ops.ACT_SILU, net.conv_out, None))
         seq.append(("f", lambda x: net.conv_out.nhwc(x)))
         return seq
 
@@ -130,8 +135,12 @@ class VAEHook:
                 if record is not None:
                     record.append((mean, var))
                 gi += 1
-                for k in groups:
-                    groups[k] = norm.apply_stats(groups[k], mean, rstd, act, split=op[3].in_split())   # rows (tile, image) share the image's statistics
+                for k in groups:       # rows (tile, image) share the image's statistics
+                    if op[4] is not None:
+                        groups[k], xc = norm.apply_stats(groups[k], mean, rstd, act, split=op[3].in_split(), also_cast=op[4].in_split())
+                        res[k].append(op[4].nhwc(xc, pad=0))
+                    else:
+                        groups[k] = norm.apply_stats(groups[k], mean, rstd, act, split=op[3].in_split())
             elif kind == "f":
                 for k in groups:
                     groups[k] = op[1](groups[k])
@@ -140,7 +149,10 @@ class VAEHook:
                     res[k].append(op[1](groups[k]) if op[1] is not None else groups[k])
             elif kind == "conv_res":
                 for k in groups:
-                    groups[k] = op[1].nhwc(groups[k], residual=res[k].pop(), gn_groups=op[2])
+                    if op[3] is not None:
+                        groups[k] = op[1].nhwc(groups[k], residual=res[k].pop(), out_dtype=ops.OUT_BF16, out_split=op[3].in_split())
+                    else:
+                        groups[k] = op[1].nhwc(groups[k], residual=res[k].pop(), gn_groups=op[2])
             elif kind == "attn_res":
                 for k in groups:
                     groups[k] = op[1].attend(groups[k], residual=res[k].pop())

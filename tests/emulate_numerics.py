@@ -38,19 +38,22 @@ class Scheme:
         self.only, self.hilo = only, hilo or set()
         self.stage = "lat"
         self.seen = set()
+        self.seen4 = set()
 
     @staticmethod
     def _q(x, dt):
         return x if dt is None else x.to(dt).float()
 
-    def op(self, x, kind="conv"):
+    def op(self, x, kind="conv", sub=""):
         key = (self.stage, kind)
         res = x.shape[-1] if x.dim() == 4 else int(round((x.shape[-2]) ** 0.5))    # spatial side ([B,C,H,W] or [B,L,C] tokens)
         key3 = (self.stage, kind, res)
+        key4 = (self.stage, kind, res, sub)
         self.seen.add(key3)
-        if self.only is not None and key not in self.only and key3 not in self.only:
+        self.seen4.add(key4)
+        if self.only is not None and key not in self.only and key3 not in self.only and key4 not in self.only:
             return x
-        if key in self.hilo or key3 in self.hilo or (self.stage, "*") in self.hilo:      # two-term split: hi + lo, both in the operand type
+        if key in self.hilo or key3 in self.hilo or key4 in self.hilo or (self.stage, "*") in self.hilo:      # two-term split: hi + lo, both in the operand type
             hi = self._q(x, self.operand)
             return hi + self._q(x - hi, self.operand)
         return self._q(x, self.operand)
@@ -63,36 +66,36 @@ class Scheme:
 
 
 def resnet(S: Scheme, r, x, temb=None):
-    a = S.op(F.silu(r.norm1(x)))
+    a = S.op(F.silu(r.norm1(x)), "conv", "n1")
     h = r.conv1(a)
     if r.time_emb_proj is not None:
         h = h + r.time_emb_proj(F.silu(temb))[:, :, None, None]
     h = S.inn(h)
-    b = S.op(F.silu(r.norm2(h)))
-    sc = x if r.conv_shortcut is None else r.conv_shortcut(S.op(x))
+    b = S.op(F.silu(r.norm2(h)), "conv", "n2")
+    sc = x if r.conv_shortcut is None else r.conv_shortcut(S.op(x, "conv", "sc"))
     return S.st(sc + r.conv2(b))
 
 
 def attn_unet(S: Scheme, at, n, ctx=None):
-    c = n if ctx is None else S.op(ctx, "lin")
+    c = n if ctx is None else S.op(ctx, "lin", "ctx")
     q, k, v = S.op(at.to_q(n), "attn"), S.op(at.to_k(c), "attn"), S.op(at.to_v(c), "attn")
     q, k, v = at._heads(q), at._heads(k), at._heads(v)
     p = S.op((torch.matmul(q, k.transpose(-1, -2)) * at.scale).softmax(dim=-1), "attn")
     o = torch.matmul(p, v).transpose(1, 2).reshape(n.shape[0], -1, at.heads * at.dim_head)
-    return at.to_out[0](S.op(o, "lin"))
+    return at.to_out[0](S.op(o, "lin", "o"))
 
 
 def transformer2d(S: Scheme, t, x, ehs):
     B, Cc, H, W = x.shape
-    y = S.op(t.norm(x), "lin").permute(0, 2, 3, 1).reshape(B, H * W, Cc)
+    y = S.op(t.norm(x), "lin", "gn").permute(0, 2, 3, 1).reshape(B, H * W, Cc)
     y = S.st(t.proj_in(y))
     for blk in t.transformer_blocks:
-        y = S.st(y + attn_unet(S, blk.attn1, S.op(blk.norm1(y), "lin")))
-        y = S.st(y + attn_unet(S, blk.attn2, S.op(blk.norm2(y), "lin"), ehs))
-        n = S.op(blk.norm3(y), "lin")
+        y = S.st(y + attn_unet(S, blk.attn1, S.op(blk.norm1(y), "lin", "ln1")))
+        y = S.st(y + attn_unet(S, blk.attn2, S.op(blk.norm2(y), "lin", "ln2"), ehs))
+        n = S.op(blk.norm3(y), "lin", "ln3")
         hg, gate = blk.ff.net[0].proj(n).chunk(2, dim=-1)
-        y = S.st(y + blk.ff.net[2](S.op(hg * F.gelu(gate), "lin")))
-    y = t.proj_out(S.op(y, "lin")).reshape(B, H, W, Cc).permute(0, 3, 1, 2)
+        y = S.st(y + blk.ff.net[2](S.op(hg * F.gelu(gate), "lin", "ffh")))
+    y = t.proj_out(S.op(y, "lin", "y")).reshape(B, H, W, Cc).permute(0, 3, 1, 2)
     return S.st(y + x)
 
 
@@ -111,7 +114,7 @@ def unet(S: Scheme, u, sample, timestep, ehs):
                 h = transformer2d(S, blk.attentions[j], h, ehs)
             skips.append(h)
         if blk.downsamplers is not None:
-            h = S.st(blk.downsamplers[0](S.op(h)))
+            h = S.st(blk.downsamplers[0](S.op(h, "conv", "samp")))
             skips.append(h)
     m = u.mid_block
     h = resnet(S, m.resnets[0], h, emb)
@@ -124,7 +127,7 @@ def unet(S: Scheme, u, sample, timestep, ehs):
             if blk.attentions is not None:
                 h = transformer2d(S, blk.attentions[j], h, ehs)
         if blk.upsamplers is not None:
-            h = S.st(blk.upsamplers[0](S.op(h)))
+            h = S.st(blk.upsamplers[0](S.op(h, "conv", "samp")))
     return S.op(u.conv_out(S.op(F.silu(u.conv_norm_out(h)))), "lat")
 
 
@@ -149,7 +152,7 @@ def encoder(S: Scheme, e, x):
         for r in b.resnets:
             h = resnet(S, r, h)
         if b.downsamplers is not None:
-            h = S.st(b.downsamplers[0](S.op(h)))
+            h = S.st(b.downsamplers[0](S.op(h, "conv", "samp")))
     h = vae_mid(S, e.mid_block, h)
     return S.op(e.conv_out(S.op(F.silu(e.conv_norm_out(h)))), "lat")
 
@@ -161,7 +164,7 @@ def decoder(S: Scheme, d, z):
         for r in b.resnets:
             h = resnet(S, r, h)
         if b.upsamplers is not None:
-            h = S.st(b.upsamplers[0](S.op(h)))
+            h = S.st(b.upsamplers[0](S.op(h, "conv", "samp")))
     return S.op(d.conv_out(S.op(F.silu(d.conv_norm_out(h)))), "lat")
 
 
@@ -201,6 +204,7 @@ def main():
     ap.add_argument("--side", type=int, default=512)
     ap.add_argument("--schemes", default="f16_all,f16_stream32,f16_inner32,bf16_inner32")
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--budget-stage", default="unet")
     ap.add_argument("--budget", default="", help="f16 | bf16: per (stage, kind) contribution of the operand roundings")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -216,6 +220,16 @@ def main():
         print(f"oracle: {time.time() - t0:.1f} s, rms {ref.pow(2).mean().sqrt():.3f}", flush=True)
         same = omgsr_s(Scheme(None, None, None), vae, u, alpha_t, x, ehs, eps, 64, 32)
         print(f"emulator with no rounding vs oracle: rel-L2 {rel_l2(same, ref):.2e}", flush=True)
+        if a.budget.endswith("_subs"):
+            dt = torch.float16 if a.budget.startswith("f16") else torch.bfloat16
+            probe = Scheme(dt, None, None)
+            omgsr_s(probe, vae, u, alpha_t, x, ehs, eps, 64, 32)
+            want = (lambda k: k[0] == "unet" and k[2] in (64, 32)) if a.budget_stage == "unet" else (lambda k: k[0] == a.budget_stage)
+            for key4 in sorted(k for k in probe.seen4 if want(k) and k[1] in ("conv", "lin")):
+                got = omgsr_s(Scheme(dt, None, None, only={key4}), vae, u, alpha_t, x, ehs, eps, 64, 32)
+                e = rel_l2(got, ref)
+                print(f"only {key4} operand roundings: rel-L2 {e:.3e}  var {e * e * 1e8:.1f}", flush=True)
+            return
         if a.budget.endswith("_levels"):
             dt = torch.float16 if a.budget.startswith("f16") else torch.bfloat16
             probe = Scheme(dt, None, None)
