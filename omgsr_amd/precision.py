@@ -21,14 +21,20 @@ import torch.nn as nn
 
 from .nn import Conv2d, Linear
 
-# Per-(layer group) share of the squared error, tests/emulate_numerics.py --budget f16_levels on OMGSR-S 128->512
-# (1e-8 units; total 224 = (1.5e-3)^2): UNet 64x64 level 36 (convs) + 30 (linears), 32x32 level 18 + 8, 16x16 level 7 + 2,
-# VAE encoder 18 / 11 / 8 / 6 by level (512 .. 64 px), decoder 9 / 7 / 13 / 11 (64 .. 512 px), latent-sized tensors
-# (conv_in / conv_out / quant convs / z / eps) 35. The UNet's fine levels cost the fewest FLOPs per unit of error removed.
-UNET_DEFAULT = [r"^conv_in$", r"^conv_out$", r"^down_blocks\.[01]\.", r"^up_blocks\.[23]\.", r"^down_blocks\.2\.", r"^up_blocks\.1\.",
-                r"^up_blocks\.0\.upsamplers"]
+# Where the error comes from (tests/emulate_numerics.py --budget f16_levels / f16_subs on OMGSR-S 128->512, squared rel-L2 in 1e-8
+# units; everything unsplit: 224 = (1.5e-3)^2). An operand rounding hurts in proportion to how much of the SIGNAL passes through
+# it: inside a residual branch (ResnetBlock conv1 / conv2, attention and feed-forward linears) it perturbs only the branch, while
+# the input of a 1x1 shortcut, of an up / down-sampling conv, of proj_in / proj_out, of conv_in / conv_out carries the whole
+# tensor. Shares: latent-sized tensors 35; UNet shortcuts 27, proj_in / proj_out 24, up / down-samplers 9, conv_out 5, the
+# 64 x 64 level's resnet convs 13 and linears 10 (32 x 32 level: 1.3 + 3, 16 x 16: less); VAE decoder shortcuts 11, conv_out 4,
+# upsampling convs 17.5 (28 % of the decoder's FLOPs: left unsplit), resnet convs 6; encoder downsampling convs 11 (5 % of its
+# FLOPs), shortcuts 5, conv_out 3, resnet convs 24 (unsplit). The lists below split the full-signal operands (a few % of the
+# FLOPs) and the UNet's 64 x 64 level: emulated 7.6e-4, and ~40 % of the extra MFMA work of splitting whole UNet levels
+# (the first policy of this round: every UNet level but 8 x 8 plus the encoder's 512-px level, 8.2e-4 emulated / 8.0e-4 measured).
+UNET_DEFAULT = [r"^conv_in$", r"^conv_out$", r"\.conv_shortcut$", r"\.attentions\.\d+\.proj_(in|out)$", r"samplers\.0\.conv$",
+                r"^down_blocks\.0\.", r"^up_blocks\.3\."]
 VAE_DEFAULT = [r"^encoder\.conv_in$", r"^encoder\.conv_out$", r"^quant_conv$", r"^post_quant_conv$", r"^decoder\.conv_in$",
-               r"^encoder\.down_blocks\.0\."]
+               r"^decoder\.conv_out$", r"\.conv_shortcut$", r"^encoder\..*downsamplers\.0\.conv$"]
 FLUX_DEFAULT = [r"^x_embedder$", r"^proj_out$"]
 
 

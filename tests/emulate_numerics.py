@@ -33,9 +33,9 @@ class Scheme:
     """only: optional set of (stage, kind) pairs whose OPERAND roundings are kept (all others exact) - error budget runs.
     stage in {enc, unet, dec, lat}; kind in {conv, lin, attn, lat}."""
 
-    def __init__(self, operand, inner, stream, only=None, hilo=None):
+    def __init__(self, operand, inner, stream, only=None, hilo=None, hilo_fn=None):
         self.operand, self.inner, self.stream = operand, inner, stream
-        self.only, self.hilo = only, hilo or set()
+        self.only, self.hilo, self.hilo_fn = only, hilo or set(), hilo_fn
         self.stage = "lat"
         self.seen = set()
         self.seen4 = set()
@@ -53,7 +53,7 @@ class Scheme:
         self.seen4.add(key4)
         if self.only is not None and key not in self.only and key3 not in self.only and key4 not in self.only:
             return x
-        if key in self.hilo or key3 in self.hilo or key4 in self.hilo or (self.stage, "*") in self.hilo:      # two-term split: hi + lo, both in the operand type
+        if key in self.hilo or key3 in self.hilo or key4 in self.hilo or (self.stage, "*") in self.hilo or (self.hilo_fn and self.hilo_fn(*key4)):      # two-term split: hi + lo, both in the operand type
             hi = self._q(x, self.operand)
             return hi + self._q(x - hi, self.operand)
         return self._q(x, self.operand)
@@ -189,6 +189,29 @@ def omgsr_s(S: Scheme, vae, u, alpha_t, x, ehs, eps, tile, overlap):
     return decoder(S, vae.decoder, vae.post_quant_conv(z0)).clamp(-1, 1)
 
 
+def policy_r2_first(stage, kind, res, sub):
+    """The first accurate-tier policy: every UNet level but the 8 x 8 one, the encoder's 512-px level, latent-sized tensors."""
+    if kind == "lat":
+        return True
+    if stage == "unet":
+        return res >= 16 and kind in ("conv", "lin")
+    return stage == "enc" and kind == "conv" and res == 512
+
+
+def policy_full_signal(stage, kind, res, sub):
+    """Split where the WHOLE signal passes through one operand rounding (1x1 shortcuts, up / down-sampling convs of the encoder
+    and the UNet, proj_in / proj_out, conv_in / conv_out, latents) plus the UNet's 64 x 64 level."""
+    if kind == "lat" or sub == "sc" or (kind == "conv" and sub == ""):
+        return True
+    if sub == "samp":
+        return stage in ("enc", "unet")
+    if stage == "unet":
+        return sub in ("gn", "y") or res == 64
+    return False
+
+
+POLICIES = {"r2_first": policy_r2_first, "full_signal": policy_full_signal}
+
 SCHEMES = {
     "bf16_all": (torch.bfloat16,) * 3,
     "f16_all": (torch.float16,) * 3,
@@ -255,6 +278,10 @@ def main():
             print(f"quadrature sum {tot ** 0.5:.3e}")
             return
         for name in a.schemes.split(","):
+            if name.startswith("policy:"):
+                got = omgsr_s(Scheme(torch.float16, None, None, hilo_fn=POLICIES[name[7:]]), vae, u, alpha_t, x, ehs, eps, 64, 32)
+                print(f"{name:16s} rel-L2 {rel_l2(got, ref):.3e}  PSNR {psnr(got, ref):.1f} dB", flush=True)
+                continue
             got = omgsr_s(Scheme(*SCHEMES[name]), vae, u, alpha_t, x, ehs, eps, 64, 32)
             print(f"{name:16s} rel-L2 {rel_l2(got, ref):.3e}  PSNR {psnr(got, ref):.1f} dB", flush=True)
 
