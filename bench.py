@@ -365,6 +365,9 @@ def roofline_leg(_lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, 
                     roofline["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)"
     names = {1: "igemm", 2: "attention", 3: "groupnorm", 4: "layernorm", 5: "elementwise", 6: "softmax"}
     extra = {"kernel_ms_by_family": {names.get(k, str(k)): round(v["ms"], 3) for k, v in sorted(kinds.items())},
+             # HBM-bound families: algorithmic bytes (each tensor read / written once) over their summed HIP-event time, vs 8 TB/s peak
+             "hbm_gbps_by_family": {names.get(k, str(k)): round(v["bytes"] / (v["ms"] * 1e-3) / 1e9) for k, v in sorted(kinds.items())
+                                    if k in (3, 4, 5, 6) and v["ms"] > 0},
              "pipeline_frac_of_mfma_peak": round(tflop_per_img * B * args.steps / elapsed / PEAK_DENSE_TFLOPS, 4) if world == 1 else None}
     return roofline, extra
 

@@ -98,13 +98,20 @@ template <typename T, bool F32> OMGSR_DEVINL void load8(const void* base, const 
     }
 }
 // the two-term split of 8 values: hi = round(v), lo = round(v - hi), both in the compute type
+template <typename T> OMGSR_DEVINL float lo_of(unsigned int h2, int which);
+template <> OMGSR_DEVINL float lo_of<bf16_t>(unsigned int h2, int which) { return which ? __uint_as_float(h2 & 0xffff0000u) : __uint_as_float(h2 << 16); }
+template <> OMGSR_DEVINL float lo_of<f16_t>(unsigned int h2, int which) {
+    const f16x2_t h = *reinterpret_cast<const f16x2_t*>(&h2);
+    return (float)h[which];
+}
 template <typename T> OMGSR_DEVINL void split8(const float (&v)[8], u32x4_t& hi, u32x4_t& lo) {
-    hi = pack8<T>(v);
-    float back[8], d[8];
-    unpack8<T>(hi, back);
+    // pair by pair (two live temporaries instead of sixteen: the igemm epilogue calls this with ~250 registers in use)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) d[e] = v[e] - back[e];
-    lo = pack8<T>(d);
+    for (int i = 0; i < 4; ++i) {
+        const unsigned int h2 = pack2<T>(v[2 * i], v[2 * i + 1]);
+        hi[i] = h2;
+        lo[i] = pack2<T>(v[2 * i] - lo_of<T>(h2, 0), v[2 * i + 1] - lo_of<T>(h2, 1));
+    }
 }
 // store: EL 0 = 16-bit at base[idx]; 1 = fp32 at base[idx]; 2 = split, hi at base[idx], lo at base[idx + lo_off]
 template <typename T, int EL> OMGSR_DEVINL void store8(void* base, const int64_t idx, const int64_t lo_off, const float (&f)[8]) {

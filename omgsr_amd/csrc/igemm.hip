@@ -335,6 +335,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     if (a.out_layout == OMGSR_LAYOUT_T && (a.t_rows <= 0 || a.t_ld < a.t_rows || a.residual)) return OMGSR_E_BADARG;
     if (a.out_ld != 0 && (a.out_ld < a.Cout || a.out_layout != OMGSR_LAYOUT_NHWC)) return OMGSR_E_BADARG;
     if (a.res_el != OMGSR_EL_16 && a.res_el != OMGSR_EL_F32) return OMGSR_E_BADARG;
+    if (a.res_el == OMGSR_EL_F32 && a.residual && a.act == OMGSR_ACT_GEGLU) return OMGSR_E_SHAPE;
     if (a.out_lo_off < 0) return OMGSR_E_BADARG;
     if (a.out_lo_off && (a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cout & 7) || (a.out_ld & 7) || (a.out_lo_off & 7) ||
                          a.out_lo_off < a.Cout || a.out_ld < a.out_lo_off + a.Cout || a.gn_partial)) return OMGSR_E_SHAPE;

@@ -64,7 +64,7 @@ OMGSR_DEVINL void wait_vmcnt() {
 
 // ABL (ablation, A/B runs only): 0 = the kernel; 1 = no DMA; 2 = DMA + ds_reads, no MFMA; 3 = DMA only
 template <typename T, int WGM, int WGN, int ABL = 0, int BM = 256>
-__global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void igemm_dma_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     constexpr int A_BYTES = BM * BK * 2;       // 16 KB at BM 256
     constexpr int NW = WGM * WGN;              // waves
     constexpr int BN = WGN * WTN;

@@ -27,7 +27,9 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
     constexpr int EPI_LD = WTN + 4;
     static_assert(WTN == FN * 32, "wave tile width");
     const int half = lane >> 5, px = lane & 31;
-    const bool geglu = (p.act == OMGSR_ACT_GEGLU);
+    // a GEGLU projection never carries a residual (omgsr_igemm rejects the combination with an fp32 one): the fp32-residual
+    // instantiation drops the gate path and its 8 bias registers - the halo / 256-wide kernels have none to spare
+    const bool geglu = !RES32 && (p.act == OMGSR_ACT_GEGLU);
     const int cols_per_row = geglu ? WTN / 2 : WTN;     // produced output columns per staged row
     const int lanes_per_row = cols_per_row / 8;
     const int rows_per_pass = 64 / lanes_per_row;
