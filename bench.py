@@ -43,7 +43,7 @@ WORKLOADS = {
     # name: (family, image side, default batch, latent tile, overlap, algorithmic TFLOP per image [BASELINE.md §3 / SURVEY §8(d)])
     "s512": ("S", 512, 8, 64, 32, 4.436),          # BASELINE.json configs[1]
     "s1024": ("S", 1024, 4, 64, 32, 22.59),        # configs[2]: 1k output, tiled VAE (encoder tile 256, decoder tile 64)
-    "f1024": ("F", 1024, 1, 128, 64, 89.8),        # configs[3]
+    "f1024": ("F", 1024, 8, 128, 64, 89.8),        # configs[3] (and the per-GPU share of configs[4]: 64 images over 8 GPUs)
 }
 DTYPES = {"fp32": "float32", "fp16": "float16", "bf16": "bfloat16"}
 IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel"}
@@ -274,6 +274,9 @@ def main():
             extra["other_tiers"] = others
             ops.set_compute_dtype(wdtype)
 
+    if rank == 0 and world == 1 and family == "F" and not args.no_cpu_baseline:
+        cpu_baseline, parity = cpu_leg_f(device, wdtype, side, tile, overlap)
+
     if rank == 0:
         tier = {"fp32": "accurate tier: fp32 tensors between GEMMs, fp16 MFMA operands (two-term split on the layers of omgsr_amd/precision.py), fp32 accumulation",
                 "fp16": "fast tier fp16", "bf16": "fast tier bf16 (the reference's default --weight_dtype)"}[args.weight_dtype]
@@ -397,6 +400,53 @@ def cpu_leg(inp, hip_out_nchw, tile, overlap, side, tiled_vae=False):
             "sample": f"1 image {side // 4}->{side}, fp32 eager PyTorch oracle, {secs:.1f} s, torch threads={torch.get_num_threads()}",
             **cpu_info(), "torch": torch.__version__}
     return base, parity, img
+
+
+def cpu_leg_f(device, wdtype, side, tile, overlap):
+    """OMGSR-F parity + CPU baseline on a bounded sample: ONE image through a pipeline whose DiT has the full FLUX.1-dev WIDTH
+    (D 3072, 24 x 128 heads, 4096 + 512 tokens) but 2 + 2 of its 19 + 38 blocks (the fp32 oracle of all 57 needs 48 GB of weights
+    and ~90 TFLOP on the host), CPU-seeded so the fp32 CPU oracle holds bit-identical weights; the VAE is the full FLUX VAE."""
+    import torch
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api import AutoencoderKL, FLUX_VAE_CONFIG, FluxTransformer2DModel
+    from omgsr_amd.pipelines.omgsr_f import OMGSR_F_Infer, prepare_latent_image_ids
+    from omgsr_amd.testing import psnr, rel_l2, seeded_init_, synthetic_lq
+    from oracle import diffusers_ref as R
+    from oracle.pipeline_ref import OmgsrFRef
+    from oracle.pipeline_ref import prepare_latent_image_ids as ref_ids
+    cores = int(os.environ.get("OMGSR_CPU_THREADS", min(16, os.cpu_count() or 1)))
+    torch.set_num_threads(cores)
+    cfg = dict(num_layers=2, num_single_layers=2)
+    ov, of = seeded_init_(R.AutoencoderKL(**FLUX_VAE_CONFIG), 303).eval(), seeded_init_(R.FluxTransformer2DModel(**cfg), 404).eval()
+    g = torch.Generator().manual_seed(4321)
+    x = synthetic_lq(1, side, side, seed=1234)
+    eps = torch.randn(1, 16, side // 8, side // 8, generator=torch.Generator().manual_seed(99))
+    pe, pooled = torch.randn(1, 512, 4096, generator=g), torch.randn(1, 768, generator=g)
+    tids, iids = torch.zeros(512, 3), ref_ids(tile // 2, tile // 2)
+    ov.posterior_noise = eps
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ref = OmgsrFRef(ov, of, 244, 1.0)(x, pe, pooled, tids, iids, tile, overlap)
+        secs = time.perf_counter() - t0
+    pv, pf = AutoencoderKL(**FLUX_VAE_CONFIG), FluxTransformer2DModel(**cfg)
+    pv.load_state_dict(ov.state_dict()); pf.load_state_dict(of.state_dict())
+    del ov, of
+    pf.round_timestep_to_weight_dtype = False          # the fp32 oracle conditions on the exact sigma(t*)
+    pipe = OMGSR_F_Infer(None, None, device, wdtype, 244, 1.0, vae=pv, flux_transformer=pf)
+    pipe.vae.posterior_noise = eps.to(device)
+    with torch.no_grad():
+        got, _ = pipe(x.to(device=device, dtype=wdtype), pe.to(device=device, dtype=wdtype), pooled.to(device=device, dtype=wdtype),
+                      tids.to(device=device, dtype=wdtype), prepare_latent_image_ids(tile // 2, tile // 2, device, wdtype), tile, overlap)
+    got = got.float().cpu()
+    e, p = rel_l2(got, ref), psnr(got, ref)
+    parity = {"vs": "fp32 CPU oracle, same weights/inputs/eps, 1 image, FLUX.1-dev width with 2+2 of 19+38 DiT blocks + the full FLUX VAE",
+              "rel_l2": round(e, 6), "psnr_db": round(p, 2), "north_star": "rel_l2 <= 1e-3 and psnr >= 60 dB", "meets_north_star": bool(e <= 1e-3 and p >= 60.0)}
+    base = {"value": round(1.0 / secs, 5), "unit": "images/s (reduced-depth DiT: 20.3 of the full pipeline's 89.8 TFLOP)", "cores": cores, "kind": "port",
+            "sample": f"1 image {side // 4}->{side}, fp32 eager PyTorch oracle with a 2+2-block DiT, {secs:.1f} s, torch threads={torch.get_num_threads()}",
+            **cpu_info(), "torch": torch.__version__}
+    del pipe
+    torch.cuda.empty_cache()
+    return base, parity
 
 
 def tier_leg(wdtype, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img):

@@ -209,8 +209,10 @@ int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t L, int32_t
  * (FluxAttnProcessor2_0: norm_q/norm_k + apply_rotary_emb).  x bf16 rows [B*L] with stride ld,
  * head h at column col0 + h*D; w f32 [H][D] (per-head weight rows, so one call covers the q heads and the
  * k heads of a fused [q|k] buffer); cos/sin f32 [>= pos0+L][D] (repeat-interleaved pairs); rope may be NULL.
+ * w2 (optional): a second weight table used by the rows whose position in their sequence (row % L) is >= Lsplit - the joint
+ * [text ; image] sequence of a FluxTransformerBlock (norm_added_q/k for the text rows, norm_q/k for the image rows) in one call.
  */
-int omgsr_rmsnorm_rope(void* x, const float* w, const float* cos_t, const float* sin_t, int32_t B,
+int omgsr_rmsnorm_rope(void* x, const float* w, const float* w2, int32_t Lsplit, const float* cos_t, const float* sin_t, int32_t B,
                        int32_t L, int32_t H, int32_t D, int64_t ld, int32_t col0, int32_t pos0,
                        float eps, void* stream);
 

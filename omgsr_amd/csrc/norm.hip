@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // RMSNorm over head_dim (D = 128) * w, then interleaved-pair RoPE, in place.  16 lanes per head
 // (8 elements each), 4 heads per wave.
 template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(T* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ w2, int Lsplit,
                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                             int64_t rows, int L, int H, int D, int64_t ld, int col0,
                                                             int pos0, float eps) {
@@ -429,8 +429,9 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(T* __restrict__ x, co
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float r = rsqrtf(q / (float)D + eps);
+    const float* wt = (w2 && (int)(row % L) >= Lsplit) ? w2 : w;       // joint [text ; image] sequence: two weight tables
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = f[e] * r * w[h * D + sub * 8 + e];
+    for (int e = 0; e < 8; ++e) f[e] = f[e] * r * wt[h * D + sub * 8 + e];
     if (cos_t) {
         const int pos = pos0 + (int)(row % L);
         const float* cp = cos_t + (int64_t)pos * D + sub * 8;
@@ -636,7 +637,7 @@ extern "C" int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t
     return (int)hipGetLastError();
 }
 
-extern "C" int omgsr_rmsnorm_rope(void* x, const float* w, const float* cos_t, const float* sin_t, int32_t B, int32_t L,
+extern "C" int omgsr_rmsnorm_rope(void* x, const float* w, const float* w2, int32_t Lsplit, const float* cos_t, const float* sin_t, int32_t B, int32_t L,
                                   int32_t H, int32_t D, int64_t ld, int32_t col0, int32_t pos0, float eps, void* stream) {
     if (!x || !w || B <= 0 || L <= 0 || H <= 0) return OMGSR_E_BADARG;
     if (D != 128 || (ld & 7) || (col0 & 7) || ((cos_t == nullptr) != (sin_t == nullptr))) return OMGSR_E_SHAPE;
@@ -644,7 +645,7 @@ extern "C" int omgsr_rmsnorm_rope(void* x, const float* w, const float* cos_t, c
     const int64_t rows = (int64_t)B * L;
     const int64_t groups = rows * H;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 4.0 * (double)groups * D, st);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL(rmsnorm_rope_kernel<T>, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, st, (T*)x, w, cos_t,
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL(rmsnorm_rope_kernel<T>, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, st, (T*)x, w, w2, Lsplit, cos_t,
                                         sin_t, rows, L, H, D, ld, col0, pos0, eps));
     return (int)hipGetLastError();
 }

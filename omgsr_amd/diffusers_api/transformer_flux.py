@@ -15,8 +15,10 @@ MI355X-first execution:
   * RMSNorm(q,k)*w + RoPE is one in-place pass over the fused [q|k] buffer (per-head weight table)
   * joint attention (24 heads x 128, 4608 keys) is the fused MFMA attention kernel; in the single blocks it
     writes directly into the [attn | mlp] concat buffer that proj_out consumes
-Batch: images are processed one sequence at a time (M = 4608 tokens already fills the chip; the joint
-buffers stay L2/MALL friendly); the reference itself is batch-1 (infer/infer_omgsr_f.py:95).
+Batch: the B images of a call ride along M in every launch (the reference is batch-1, infer/infer_omgsr_f.py:95; images
+are independent): the single-stream blocks (2/3 of the FLOPs) run GEMMs of B * 4608 rows, so the 24 GB of weights are read
+once per call instead of once per image and the 360-432-tile grids of one sequence stop quantising on the 512 workgroup
+slots; the double-stream blocks' projections into / out of the joint [text ; image] buffers run as B GEMMs in one grid.
 """
 from __future__ import annotations
 
@@ -119,9 +121,11 @@ class FluxTransformerBlock(nn.Module):
         return dict(img=six(self.norm1), ctx=six(self.norm1_context))
 
     def run(self, h, c, mod, rope, ws):
-        """h [Li, D] image tokens, c [Lc, D] text tokens (stream tensors); ws = joint operand buffers."""
+        """h [B, Li, D] image tokens, c [B, Lc, D] text tokens (stream tensors); ws = joint operand buffers [B, L, ...].
+        All B images ride in every launch: row-wise kernels see B*L rows, the projections into / out of the joint buffers run as
+        B GEMMs of one grid (grid.z = B, one weight read), attention takes the batch stride."""
         at = self.attn
-        Lc, Li, D = c.shape[0], h.shape[0], h.shape[1]
+        Lc, Li = c.shape[1], h.shape[1]
         mi, mc = mod["img"], mod["ctx"]
         hn = ops.layer_norm(h, mi["a1"], mi["b1"], 1e-6, split=at.to_q.in_split())
         cn = ops.layer_norm(c, mc["a1"], mc["b1"], 1e-6, split=at.add_q_proj.in_split())
@@ -132,12 +136,10 @@ class FluxTransformerBlock(nn.Module):
         ops.linear_t_into(cn, at.add_v_proj.packed(), vt, 0)
         ops.linear_t_into(hn, at.to_v.packed(), vt, Lc)
         cos, sin = rope
-        ops.rmsnorm_rope_(qk[None, :Lc], at.norm_table(ctx=True), cos, sin, 2 * at.heads, at.head_dim, pos0=0)
-        ops.rmsnorm_rope_(qk[None, Lc:], at.norm_table(), cos, sin, 2 * at.heads, at.head_dim, pos0=Lc)
-        ops.attention(qk[None], qk[None], vt[None], at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=Lc + Li, out=o[None],
-                      out_split=osp)
-        h = at.to_out[0].nhwc(o[Lc:], residual=h, gate=mi["g1"])
-        c = at.to_add_out.nhwc(o[:Lc], residual=c, gate=mc["g1"])
+        ops.rmsnorm_rope_(qk, at.norm_table(ctx=True), cos, sin, 2 * at.heads, at.head_dim, pos0=0, w_after=at.norm_table(), split_at=Lc)
+        ops.attention(qk, qk, vt, at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=Lc + Li, out=o, out_split=osp)
+        h = ops.linear_rows(o, Lc, Li, at.to_out[0].packed(), residual=h, gate=mi["g1"])
+        c = ops.linear_rows(o, 0, Lc, at.to_add_out.packed(), residual=c, gate=mc["g1"])
         h = self.ff.run(ops.layer_norm(h, mi["a2"], mi["b2"], 1e-6, split=self.ff.net[0].proj.in_split()), h, mi["g2"])
         c = self.ff_context.run(ops.layer_norm(c, mc["a2"], mc["b2"], 1e-6, split=self.ff_context.net[0].proj.in_split()), c, mc["g2"])
         return h, c
@@ -159,18 +161,20 @@ class FluxSingleTransformerBlock(nn.Module):
         return dict(a=(1 + scale).contiguous(), b=shift, g=gate)
 
     def run(self, x, mod, rope, ws):
+        """x [B, L, D] joint [text ; image] tokens (stream tensor): every GEMM sees M = B * L rows."""
         at = self.attn
-        L, D = x.shape
+        B, L, D = x.shape
         xn = ops.layer_norm(x, mod["a"], mod["b"], 1e-6, split=at.to_q.in_split())      # read by to_q | to_k, to_v and proj_mlp
         csp = self.proj_out.in_split()
         qk, vt, cat = ws["qk"], ws["vt"], ws["cat2" if csp == 2 else "cat"]
         Kc = D + self.mlp_hidden                           # the [attn | mlp] operand of proj_out; split form: [hi (Kc) | lo (Kc)]
-        ops.linear_into(xn, at.qk_packed(), qk, 0, 0)
+        ops.linear_into(xn.reshape(B * L, -1), at.qk_packed(), qk.reshape(B * L, -1), 0, 0)
         ops.linear_t_into(xn, at.to_v.packed(), vt, 0)
-        ops.rmsnorm_rope_(qk[None], at.norm_table(), rope[0], rope[1], 2 * at.heads, at.head_dim, pos0=0)
-        ops.attention(qk[None], qk[None], vt[None], at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=L, out=cat[None],
+        ops.rmsnorm_rope_(qk, at.norm_table(), rope[0], rope[1], 2 * at.heads, at.head_dim, pos0=0)
+        ops.attention(qk, qk, vt, at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=L, out=cat,
                       out_split=csp, o_lo_col=Kc)
-        ops.linear_into(xn, self.proj_mlp.packed(), cat, 0, D, act=ops.ACT_GELU_TANH, out_split=csp, lo_col0=Kc + D)
+        cat2d = cat.reshape(B * L, -1)
+        ops.linear_into(xn.reshape(B * L, -1), self.proj_mlp.packed(), cat2d, 0, D, act=ops.ACT_GELU_TANH, out_split=csp, lo_col0=Kc + D)
         return self.proj_out.nhwc(cat, residual=x, gate=mod["g"])
 
 
@@ -302,29 +306,27 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
         L = Lc + Li
         dev = x_tok.device
         mlp = self.single_transformer_blocks[0].mlp_hidden if len(self.single_transformer_blocks) else 0
-        ws = dict(qk=torch.empty((L, 2 * D), device=dev, dtype=ops.act_dtype()),
-                  vt=torch.empty((D, ops._round_up(L, 8)), device=dev, dtype=ops.act_dtype()),
-                  o=torch.empty((L, D), device=dev, dtype=ops.act_dtype()),
-                  cat=torch.empty((L, D + mlp), device=dev, dtype=ops.act_dtype()))
+        ad = ops.act_dtype()
+        ws = dict(qk=torch.empty((B, L, 2 * D), device=dev, dtype=ad),
+                  vt=torch.empty((B, D, ops._round_up(L, 8)), device=dev, dtype=ad),
+                  o=torch.empty((B, L, D), device=dev, dtype=ad),
+                  cat=torch.empty((B, L, D + mlp), device=dev, dtype=ad))
         if ops.precise():       # two-term split forms of the operands that to_out / to_add_out / proj_out read (policy dependent)
             if any(b.attn.to_out[0].in_split() == 2 for b in self.transformer_blocks):
-                ws["o2"] = torch.empty((L, 2 * D), device=dev, dtype=ops.act_dtype())
+                ws["o2"] = torch.empty((B, L, 2 * D), device=dev, dtype=ad)
             if any(b.proj_out.in_split() == 2 for b in self.single_transformer_blocks):
-                ws["cat2"] = torch.empty((L, 2 * (D + mlp)), device=dev, dtype=ops.act_dtype())
-        if ws["vt"].shape[1] != L:
+                ws["cat2"] = torch.empty((B, L, 2 * (D + mlp)), device=dev, dtype=ad)
+        if ws["vt"].shape[-1] != L:
             ws["vt"].zero_()
-        outs = []
-        for b in range(B):
-            h = self.x_embedder.nhwc(x_tok[b])
-            c = ctx0[b if ctx0.shape[0] > 1 else 0]
-            for blk, m in zip(self.transformer_blocks, mod["double"]):
-                h, c = blk.run(h, c, m, rope, ws)
-            x = torch.cat([c, h], 0)
-            for blk, m in zip(self.single_transformer_blocks, mod["single"]):
-                x = blk.run(x, m, rope, ws)
-            hn = ops.layer_norm(x[Lc:], mod["out"]["a"], mod["out"]["b"], 1e-6, split=self.proj_out.in_split())
-            outs.append(self.proj_out.nhwc(hn))
-        return torch.stack(outs, 0)
+        h = self.x_embedder.nhwc(x_tok)                                                   # [B, Li, D]
+        c = ctx0.expand(B, -1, -1).contiguous() if ctx0.shape[0] != B else ctx0           # text stream: per image after block 1
+        for blk, m in zip(self.transformer_blocks, mod["double"]):
+            h, c = blk.run(h, c, m, rope, ws)
+        x = torch.cat([c, h], 1)                                                          # [B, L, D] (plumbing copy, once)
+        for blk, m in zip(self.single_transformer_blocks, mod["single"]):
+            x = blk.run(x, m, rope, ws)
+        hn = ops.layer_norm(x[:, Lc:].contiguous(), mod["out"]["a"], mod["out"]["b"], 1e-6, split=self.proj_out.in_split())
+        return self.proj_out.nhwc(hn)
 
     # ---- diffusers API ---------------------------------------------------------------------
     def forward(self, hidden_states, timestep, guidance=None, pooled_projections=None, encoder_hidden_states=None,

@@ -334,12 +334,14 @@ def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int,
     if x.dtype == torch.float32:
         x = to_operand(x, pw.split)
     _req(x, act_dtype(), "x"); _req(out, act_dtype(), "out")
-    M, K = x.numel() // x.shape[-1], x.shape[-1]
-    ld = out.shape[-1]
-    if K != pw.cin or out.dim() != 2 or row0 + M > out.shape[0] or col0 + pw.cout > ld or (col0 & 7):
+    # out [rows, ld], or [B, rows, ld] with x [B, M, K]: image b's M rows land at rows row0 .. row0+M of out[b] (grid.z = B)
+    Bz = out.shape[0] if out.dim() == 3 else 1
+    M, K = x.numel() // x.shape[-1] // Bz, x.shape[-1]
+    ld, nrows = out.shape[-1], out.shape[-2]
+    if K != pw.cin or out.dim() not in (2, 3) or row0 + M > nrows or col0 + pw.cout > ld or (col0 & 7):
         raise ValueError("linear_into: slice does not fit")
-    if residual is not None and residual.numel() != M * pw.cout:
-        raise ValueError("linear_into: residual must be a dense [M, Cout]")
+    if residual is not None and (Bz != 1 or residual.numel() != M * pw.cout):
+        raise ValueError("linear_into: residual must be a dense [M, Cout] (unbatched call)")
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
     a.out = out.data_ptr() + 2 * (row0 * ld + col0)
@@ -356,9 +358,37 @@ def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int,
     a.Ho, a.Wo = 1, M
     a.act, a.out_layout = act, LAYOUT_NHWC
     a.out_ld = ld
-    a.batch, a.alpha = 1, 1.0
+    a.batch, a.alpha = Bz, 1.0
+    a.in_bstride, a.w_bstride, a.out_bstride = M * K, 0, nrows * ld
     a.in_split = int(pw.split == 2)
     _igemm(a, x.device, "omgsr_igemm(linear_into)")
+
+
+def linear_rows(x_buf: torch.Tensor, row0: int, rows: int, pw: PackedWeight, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
+                gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_STREAM) -> torch.Tensor:
+    """out[b] = epilogue(x_buf[b, row0:row0+rows] @ W^T) for an operand buffer x_buf [B, L, K]: a projection of a row range of
+    every image's joint sequence (to_out / to_add_out after joint attention) without gathering the rows first. Returns a dense
+    [B, rows, Cout] stream tensor; residual: dense [B, rows, Cout]."""
+    _req(x_buf, act_dtype(), "x_buf")
+    B, L, K = x_buf.shape
+    if K != pw.cin or row0 < 0 or row0 + rows > L:
+        raise ValueError("linear_rows: row range / channels do not fit")
+    out = _out_tensor((B, rows), pw.cout, out_dtype, 1, x_buf.device)
+    if residual is not None and tuple(residual.shape) != (B, rows, pw.cout):
+        raise ValueError("linear_rows: residual must be [B, rows, Cout]")
+    a = IgemmArgs()
+    a.in_, a.weight, a.bias, a.gate = x_buf.data_ptr() + 2 * row0 * K, pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
+    _fill_out(a, out, 1, residual, pw.cout)
+    a.N, a.H, a.W, a.Cin = 1, 1, rows, K
+    a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
+    a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
+    a.Ho, a.Wo = 1, rows
+    a.act, a.out_layout = act, LAYOUT_NHWC
+    a.batch, a.alpha = B, 1.0
+    a.in_bstride, a.w_bstride, a.out_bstride = L * K, 0, rows * pw.cout
+    a.in_split = int(pw.split == 2)
+    check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_rows)")
+    return out
 
 
 def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: int) -> None:
@@ -367,8 +397,10 @@ def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: 
     if x.dtype == torch.float32:
         x = to_operand(x, pw.split)
     _req(x, act_dtype(), "x"); _req(out_t, act_dtype(), "out_t")
-    L, K = x.numel() // x.shape[-1], x.shape[-1]
-    if out_t.dim() != 2 or out_t.shape[0] != pw.cout or key0 + L > out_t.shape[1] or K != pw.cin:
+    # out_t [Cout, ld], or [B, Cout, ld] with x [B, L, K] (grid.z = B)
+    Bz = out_t.shape[0] if out_t.dim() == 3 else 1
+    L, K = x.numel() // x.shape[-1] // Bz, x.shape[-1]
+    if out_t.dim() not in (2, 3) or out_t.shape[-2] != pw.cout or key0 + L > out_t.shape[-1] or K != pw.cin:
         raise ValueError("linear_t_into: slice does not fit")
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.out = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), out_t.data_ptr() + 2 * key0
@@ -377,8 +409,9 @@ def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: 
     a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
     a.Ho, a.Wo = 1, L
     a.act, a.out_dtype, a.out_layout = ACT_NONE, OUT_BF16, LAYOUT_T
-    a.t_rows, a.t_ld = L, out_t.shape[1]
-    a.batch, a.alpha = 1, 1.0
+    a.t_rows, a.t_ld = L, out_t.shape[-1]
+    a.batch, a.alpha = Bz, 1.0
+    a.in_bstride, a.w_bstride, a.out_bstride = L * K, 0, pw.cout * out_t.shape[-1]
     a.in_split = int(pw.split == 2)
     check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_t_into)")
 
@@ -639,16 +672,18 @@ def softmax_rows(s: torch.Tensor, valid: Optional[int] = None) -> torch.Tensor:
 
 
 def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor],
-                  heads: int, head_dim: int, col0: int = 0, pos0: int = 0, eps: float = 1e-6) -> torch.Tensor:
+                  heads: int, head_dim: int, col0: int = 0, pos0: int = 0, eps: float = 1e-6,
+                  w_after: Optional[torch.Tensor] = None, split_at: int = 0) -> torch.Tensor:
     """In place on x [B, L, ld]: per head RMSNorm(head_dim) * w[h] then RoPE with cos/sin [>= pos0+L, D] (f32).
-    w is [heads, D]: one call can cover the q heads and the k heads of a fused [q|k] buffer."""
+    w is [heads, D]: one call can cover the q heads and the k heads of a fused [q|k] buffer. w_after / split_at: rows at
+    sequence positions >= split_at use w_after instead (joint [text ; image] sequences)."""
     _req(x, act_dtype(), "x"); _req(w, torch.float32, "w")
     B, L, ld = x.shape
-    if tuple(w.shape) != (heads, head_dim):
+    if tuple(w.shape) != (heads, head_dim) or (w_after is not None and tuple(w_after.shape) != (heads, head_dim)):
         raise ValueError(f"rmsnorm_rope_: w must be [{heads}, {head_dim}], got {tuple(w.shape)}")
     if cos is not None and (cos.shape[0] < pos0 + L or sin.shape[0] < pos0 + L or cos.shape[-1] != head_dim):
         raise ValueError(f"rmsnorm_rope_: rope tables {tuple(cos.shape)} do not cover positions {pos0}..{pos0 + L - 1} x {head_dim}")
-    check(_lib.load().omgsr_rmsnorm_rope(x.data_ptr(), w.data_ptr(), _ptr(cos), _ptr(sin), B, L, heads, head_dim, ld,
+    check(_lib.load().omgsr_rmsnorm_rope(x.data_ptr(), w.data_ptr(), _ptr(w_after), split_at, _ptr(cos), _ptr(sin), B, L, heads, head_dim, ld,
                                          col0, pos0, eps, _stream()), "omgsr_rmsnorm_rope")
     return x
 
