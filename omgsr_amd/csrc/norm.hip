@@ -194,22 +194,46 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
     const int step8 = 256 % nch8, stepp = 256 / nch8;
     const int ldy = YEL == 2 ? 2 * C : C;
     int c8 = t % nch8, px = t / nch8;
-#pragma unroll 2
-    for (int i = t; i < total; i += 256) {
-        float f[8];
-        load8<T, XF32>(x, (pix0 + px) * C + c8 * 8, f);
-        if constexpr (Y2EL >= 0) store8<T, Y2EL>(y2, (pix0 + px) * (Y2EL == 2 ? 2 * C : C) + c8 * 8, C, f);
-        const f32x4_t* sa = reinterpret_cast<const f32x4_t*>(sc + c8 * 8);
-        const f32x4_t* ha = reinterpret_cast<const f32x4_t*>(sh + c8 * 8);
+    auto advance = [&](int& cc, int& pp) {
+        cc += step8; pp += stepp;
+        if (cc >= nch8) { cc -= nch8; ++pp; }
+    };
+    auto transform = [&](float (&f)[8], const int cc) {
+        const f32x4_t* sa = reinterpret_cast<const f32x4_t*>(sc + cc * 8);
+        const f32x4_t* ha = reinterpret_cast<const f32x4_t*>(sh + cc * 8);
         const f32x4_t sa0 = sa[0], sa1 = sa[1], ha0 = ha[0], ha1 = ha[1];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = f[e] * (e < 4 ? sa0[e & 3] : sa1[e & 3]) + (e < 4 ? ha0[e & 3] : ha1[e & 3]);
             f[e] = (act == OMGSR_ACT_SILU) ? silu_f(v) : v;
         }
+    };
+    // two chunks (4 x 16-byte loads of an fp32 row) in flight per thread
+    int i = t;
+    for (; i + 256 < total; i += 512) {
+        int c8b = c8, pxb = px;
+        advance(c8b, pxb);
+        float f[8], h[8];
+        load8<T, XF32>(x, (pix0 + px) * C + c8 * 8, f);
+        load8<T, XF32>(x, (pix0 + pxb) * C + c8b * 8, h);
+        if constexpr (Y2EL >= 0) {
+            store8<T, Y2EL>(y2, (pix0 + px) * (Y2EL == 2 ? 2 * C : C) + c8 * 8, C, f);
+            store8<T, Y2EL>(y2, (pix0 + pxb) * (Y2EL == 2 ? 2 * C : C) + c8b * 8, C, h);
+        }
+        transform(f, c8);
+        transform(h, c8b);
         store8<T, YEL>(y, (pix0 + px) * ldy + c8 * 8, C, f);
-        c8 += step8; px += stepp;
-        if (c8 >= nch8) { c8 -= nch8; ++px; }
+        store8<T, YEL>(y, (pix0 + pxb) * ldy + c8b * 8, C, h);
+        c8 = c8b; px = pxb;
+        advance(c8, px);
+    }
+    for (; i < total; i += 256) {
+        float f[8];
+        load8<T, XF32>(x, (pix0 + px) * C + c8 * 8, f);
+        if constexpr (Y2EL >= 0) store8<T, Y2EL>(y2, (pix0 + px) * (Y2EL == 2 ? 2 * C : C) + c8 * 8, C, f);
+        transform(f, c8);
+        store8<T, YEL>(y, (pix0 + px) * ldy + c8 * 8, C, f);
+        advance(c8, px);
     }
 }
 

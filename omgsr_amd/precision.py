@@ -31,8 +31,10 @@ from .nn import Conv2d, Linear
 # FLOPs), shortcuts 5, conv_out 3, resnet convs 24 (unsplit). The lists below split the full-signal operands (a few % of the
 # FLOPs) and the UNet's 64 x 64 level: emulated 7.6e-4, and ~40 % of the extra MFMA work of splitting whole UNet levels
 # (the first policy of this round: every UNet level but 8 x 8 plus the encoder's 512-px level, 8.2e-4 emulated / 8.0e-4 measured).
+# Inside the 64 x 64 level the q / k / v projections stay unsplit: the LayerNorm'd operand they read contributes 0.4 of the 224.
+_L64 = r"^(down_blocks\.0|up_blocks\.3)\."
 UNET_DEFAULT = [r"^conv_in$", r"^conv_out$", r"\.conv_shortcut$", r"\.attentions\.\d+\.proj_(in|out)$", r"samplers\.0\.conv$",
-                r"^down_blocks\.0\.", r"^up_blocks\.3\."]
+                _L64 + r"resnets\.", _L64 + r"attentions\.\d+\.transformer_blocks\.\d+\.(ff\.|attn[12]\.to_out\.)"]
 VAE_DEFAULT = [r"^encoder\.conv_in$", r"^encoder\.conv_out$", r"^quant_conv$", r"^post_quant_conv$", r"^decoder\.conv_in$",
                r"^decoder\.conv_out$", r"\.conv_shortcut$", r"^encoder\..*downsamplers\.0\.conv$"]
 FLUX_DEFAULT = [r"^x_embedder$", r"^proj_out$"]
