@@ -109,10 +109,18 @@ typedef struct omgsr_igemm_args {
     int32_t res_el;        /* element kind of `residual`: OMGSR_EL_16 | OMGSR_EL_F32 (fp32 residual stream) */
     int32_t in_split;      /* 0 | 1: `in` is a two-term split operand (Cin = 2 x the logical channels; the packed weight holds
                               every input channel twice). Informational: FLOP accounting, kernel selection. */
+    int64_t sample_rows;   /* output rows of ONE independent sample (an image's Ho*Wo, a sequence's tokens); 0 = N*Ho*Wo. Only read in
+                              batch-invariant mode (omgsr_set_batch_invariant): kernel-family / split-K decisions then depend on it
+                              instead of the batch's total rows, so a batch of B gives the bits of B batch-1 calls */
     int32_t out_lo_off;    /* > 0: a 16-bit output is written as the two-term split: hi at column n, lo at column n + out_lo_off
                               of the same row (out_lo_off >= Cout, out_ld >= out_lo_off + Cout, both % 8 == 0; NHWC, Cout % 8 == 0) */
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
+/* Batch-invariant dispatch (process-wide, default off). The dispatcher normally picks the kernel family (halo-tile conv vs GEMM-shaped)
+ * and a split-K factor from the TOTAL tile count, so the summation order of a layer - and with it the last bits of the result - can change
+ * with the batch size. With the flag on those two decisions use `sample_rows`: batch-B == B x batch-1 bit for bit (the reference's
+ * contract), at the cost of under-filled launches for small batches. */
+int omgsr_set_batch_invariant(int on);
 /* Bytes of `workspace` that would let omgsr_igemm split the contraction of a small-M / large-K problem over
  * several workgroups (fp32 partial tiles + a reduce pass that applies the epilogue); 0 = no split for this shape. */
 int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* a);

@@ -36,7 +36,7 @@ class IgemmArgs(C.Structure):
         ("in_bstride", C.c_int64), ("w_bstride", C.c_int64), ("out_bstride", C.c_int64),
         ("alpha", C.c_float), ("weight_cm", C.c_void_p), ("workspace", C.c_void_p),
         ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32), ("gn_entries", C.c_int32),
-        ("res_el", C.c_int32), ("in_split", C.c_int32), ("out_lo_off", C.c_int32),
+        ("res_el", C.c_int32), ("in_split", C.c_int32), ("sample_rows", C.c_int64), ("out_lo_off", C.c_int32),
     ]
 
 
@@ -74,6 +74,7 @@ SIGNATURES = {
     "omgsr_get_compute_dtype": (C.c_int, []),
     "omgsr_error_string": (C.c_char_p, [C.c_int]),
     "omgsr_igemm": (C.c_int, [C.POINTER(IgemmArgs), _P]),
+    "omgsr_set_batch_invariant": (C.c_int, [C.c_int]),
     "omgsr_igemm_workspace_bytes": (C.c_int64, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_slots": (C.c_int32, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_entries": (C.c_int32, [C.POINTER(IgemmArgs)]),

@@ -30,7 +30,23 @@ int igemm_halo_tiles(const omgsr_igemm_args& a);
 int igemm_halo_gn_slots(const omgsr_igemm_args& a);
 }
 
+namespace omgsr { static int g_batch_invariant = 0; }
+extern "C" int omgsr_set_batch_invariant(int on) { omgsr::g_batch_invariant = (on != 0); return 0; }
+
 namespace {
+
+// The argument block the POLICY looks at: in batch-invariant mode one sample's worth of rows (see omgsr_set_batch_invariant)
+omgsr_igemm_args policy_view(const omgsr_igemm_args& a) {
+    omgsr_igemm_args p = a;
+    if (omgsr::g_batch_invariant && a.batch == 1) {
+        const int64_t howo = (int64_t)a.Ho * a.Wo;
+        const int64_t rows = a.sample_rows > 0 ? a.sample_rows : howo;
+        if (rows >= howo) p.N = (int32_t)(rows / howo);             // conv: one image
+        else { p.N = 1; p.Ho = 1; p.Wo = (int32_t)rows; }            // token matrix [1, 1, M, K]: one sequence of `rows` tokens
+        if (p.N < 1) p.N = 1;
+    }
+    return p;
+}
 
 constexpr int BK = 32;        // K elements per pipeline step
 constexpr int ROWB = 80;      // LDS row pitch in bytes (64 B of data + 16 B pad)
@@ -239,7 +255,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
 bool use_halo(const omgsr_igemm_args& a);
 
 // Split-K policy: small-M problems whose 256x128 tiles cannot fill the 256 CUs but whose contraction is long.
-int splitk_plan(const omgsr_igemm_args& a, int64_t M64) {
+int splitk_plan(const omgsr_igemm_args& a_real, int64_t M64) {
+    const omgsr_igemm_args a = policy_view(a_real);
+    if (omgsr::g_batch_invariant) M64 = (int64_t)a.N * a.Ho * a.Wo;
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || logical_cols < 96) return 1;
     if (use_halo(a)) return 1;                  // the halo-tile kernel takes the problem (and owns the fused GroupNorm statistics)
@@ -255,7 +273,8 @@ int splitk_plan(const omgsr_igemm_args& a, int64_t M64) {
 }
 
 // the halo-tile kernel's preconditions + the "enough tiles to fill the chip" policy
-bool use_halo(const omgsr_igemm_args& a) {
+bool use_halo(const omgsr_igemm_args& a_real) {
+    const omgsr_igemm_args a = policy_view(a_real);              // geometry tests below do not involve N; the tile count does
     static const char* mode = getenv("OMGSR_IGEMM_MODE");
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     const bool halo_ok = a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 &&
@@ -290,6 +309,9 @@ void gn_plan(const omgsr_igemm_args& a, int* nslot, int* entries) {
         return;
     }
     if (a.workspace && splitk_plan(a, M64) > 1) return;          // the split-K reduce pass does not emit them
+    // batch-invariant mode: the GEMM-shaped kernels fold a 32-row block's statistics in an order that depends on their wave tile
+    // (which the dispatcher picks from the TOTAL row count); the stand-alone statistics pass has one order per image
+    if (omgsr::g_batch_invariant) return;
     const int howo = a.Ho * a.Wo;
     if (howo % 32) return;                                       // GEMM-shaped kernels: one slot per 32-row block, never straddling images
     *nslot = howo / 32;

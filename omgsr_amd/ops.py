@@ -66,6 +66,12 @@ def set_compute_dtype(dtype: torch.dtype) -> None:
     _ACT, _PRECISE = act, dtype == torch.float32
 
 
+def set_batch_invariant(on: bool) -> None:
+    """Process-wide: make kernel-family / split-K choices depend on one sample's size instead of the batch's (omgsr_set_batch_invariant):
+    a batch of B then equals B batch-1 calls bit for bit, at some cost in speed for small batches."""
+    check(_lib.load().omgsr_set_batch_invariant(int(bool(on))), "omgsr_set_batch_invariant")
+
+
 def compute_dtype_name() -> str:
     return "fp32" if _PRECISE else ("bf16" if _ACT == torch.bfloat16 else "fp16")
 
@@ -244,7 +250,7 @@ def _fill_out(a: IgemmArgs, out: torch.Tensor, out_split: int, residual: Optiona
 def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, int, int] | int = 1,
            upsample: bool = False, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
            gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_STREAM, alpha: float = 1.0,
-           out: Optional[torch.Tensor] = None, gn_groups: int = 0, out_split: int = 1) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, gn_groups: int = 0, out_split: int = 1, sample_rows: int = 0) -> torch.Tensor:
     """x [N,H,W,Cin] operand (or a stream tensor: cast / split here) -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on
     the (virtual) input. out_dtype: OUT_STREAM (a stream tensor: default), OUT_BF16 (a 16-bit operand for the next GEMM,
     `out_split` 2 = written as the two-term split) or OUT_F32. residual: a stream tensor of the output's shape.
@@ -282,6 +288,7 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
     a.alpha = alpha
     a.in_split = int(pw.split == 2)
+    a.sample_rows = sample_rows or Ho * Wo
     partial = None
     if gn_groups > 0 and out_split == 1:
         a.gn_groups = gn_groups
@@ -311,7 +318,7 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, act: int = ACT_NONE, residual: 
     x2 = x.reshape(B, 1, M // B, x.shape[-1])
     r2 = None if residual is None else residual.reshape(B, 1, M // B, pw.cout)
     y = conv2d(x2, pw, stride=1, pad=0, act=act, residual=r2, gate=gate, out_dtype=out_dtype, alpha=alpha, gn_groups=gn_groups,
-               out_split=out_split)
+               out_split=out_split, sample_rows=(M // lead[0]) if len(lead) >= 2 else M)
     out = y.reshape(*lead, y.shape[-1])
     carry_gn(y, out)
     return out

@@ -119,3 +119,31 @@ def test_bf16_and_fp16_modes_agree_full_size(full_s):
     p = psnr(b[..., :3].clamp(-1, 1), a[..., :3].clamp(-1, 1))
     print(f"bf16 vs fp16 mode, OMGSR-S 512: PSNR {p:.1f} dB")
     assert p > 40.0
+
+
+@pytest.mark.parametrize("wd", [torch.bfloat16, torch.float32], ids=["bf16", "accurate"])
+def test_batch_invariant_mode_is_exact_full_size(wd):
+    """a batch-B result must equal B independent batch-1 results. With ops.set_batch_invariant(True) the dispatcher's
+    kernel-family / split-K choices depend on ONE sample's size, so at the full SD2.1 shapes (OMGSR-S 128->512, latent-tiled UNet
+    path included via a 96x96 latent) batch 3 == three batch-1 runs BIT FOR BIT, in the fast and in the accurate tier."""
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api import AutoencoderKL, UNet2DConditionModel
+    from omgsr_amd.pipelines.omgsr_s import OMGSR_S_Infer
+    from omgsr_amd.testing import seeded_init_, synthetic_lq
+    try:
+        ops.set_batch_invariant(True)
+        pipe = OMGSR_S_Infer(None, None, 273, DEV, wd, vae=seeded_init_(AutoencoderKL(), 101), unet=seeded_init_(UNet2DConditionModel(), 202))
+        prompt = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(7)).to(DEV, wd)
+        for side in (512, 768):
+            x = synthetic_lq(3, side, side, seed=11).to(DEV, wd)
+            eps = torch.randn(3, 4, side // 8, side // 8, generator=torch.Generator().manual_seed(12)).to(DEV)
+            with torch.no_grad():
+                pipe.vae.posterior_noise = eps
+                full, _ = pipe(x, prompt, 64, 32)
+                for i in range(3):
+                    pipe.vae.posterior_noise = eps[i:i + 1]
+                    one, _ = pipe(x[i:i + 1].contiguous(), prompt, 64, 32)
+                    assert torch.equal(one, full[i:i + 1]), f"{wd} {side}px image {i}: batch-3 and batch-1 bits differ"
+    finally:
+        ops.set_batch_invariant(False)
+        ops.set_compute_dtype(torch.bfloat16)
