@@ -191,7 +191,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void igemm_dma_kernel(const omgs
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (ABL != 1) {
+        constexpr bool LATE = ABL == 0;        // LDS-DMA issue after the step's first half of MFMAs: +3...5 % on the Flux linears, S step +-0 (ABL 5 = issue in front, OMGSR_DMA_VARIANT=0, for A/B)
+        if constexpr (ABL != 1 && !LATE) {
             if (kt + 2 < nk) issue((stage + 2) % NSTAGE);
         }
         if constexpr (ABL == 3) return;
@@ -216,11 +217,19 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void igemm_dma_kernel(const omgs
             }
         } else {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);   // transposed tile
+                if constexpr (LATE) {
+                    if (ks == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kt + 2 < nk) issue((stage + 2) % NSTAGE);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
         }
     };
     for (int kt = 0; kt < nk; kt += NSTAGE) {
@@ -278,6 +287,8 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     g.nk = g.nk_total;
     static const char* shape = getenv("OMGSR_DMA_WAVES");      // A/B runs: "8" = 8 waves of 64x64, "n128" = never use BN 256
     static const char* abl = getenv("OMGSR_DMA_ABLATE");      // timing experiments only: results are garbage
+    static const char* var = getenv("OMGSR_DMA_VARIANT");     // A/B runs: "0" = LDS-DMA issued in front of the MFMAs
+    const bool early = var && var[0] == '0';
     if (abl && abl[0] == '1') return launch_dma<2, 2, 1>(a, g, st);
     if (abl && abl[0] == '2') return launch_dma<2, 2, 2>(a, g, st);
     if (abl && abl[0] == '3') return launch_dma<2, 2, 3>(a, g, st);
@@ -291,7 +302,7 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     const int cols256 = ((logical_cols + 255) / 256) * 256, cols128 = ((logical_cols + 127) / 128) * 128;
     if (!(shape && shape[0] == 'n') && (a.Cout_pad % 256) == 0 && logical_cols >= 256 && t256 >= 200 &&
         (cols256 * 16 <= cols128 * 17 || getenv("OMGSR_DMA_PAD256")))
-        return launch_dma<2, 4>(a, g, st);
+        return early ? launch_dma<2, 4, 5>(a, g, st) : launch_dma<2, 4>(a, g, st);
     // tile-count quantisation on the 512 slots (2 workgroups per CU): when the 256-row grid leaves the last round under
     // ~3/4 full and the 192-row grid fills it better, take 192 x 128
     {
@@ -303,6 +314,6 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
         if (!force256 && (g.M % 192) == 0 && (force192 || (eff(t256b) < 0.78 && eff(t192) > eff(t256b) + 0.1)))
             return launch_dma<2, 2, 0, 192>(a, g, st);
     }
-    return launch_dma<2, 2>(a, g, st);
+    return early ? launch_dma<2, 2, 5>(a, g, st) : launch_dma<2, 2>(a, g, st);
 }
 }  // namespace omgsr

@@ -180,10 +180,18 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (ABL != 2) {
-            if constexpr (tap == 0) { if (cc + 1 < ncc) issue_a(par ^ 1); }
-            if (s + 2 < nsteps) issue_b((tap + 2) % NB);
-        }
+        // LATE: this step's LDS-DMA pieces are issued after the first half of its MFMAs instead of in front of them, so their
+        // issue slots (60-185 cycles per piece) overlap matrix-pipe time: +1.5...3 % on every VAE shape (profiles/r02_halo_late.md;
+        // ABL 5 = the early schedule, OMGSR_HALO_VARIANT=0, for A/B). Safe: the stage they fill was last read in the previous
+        // step, and every wave passed this step's barrier with those reads retired (lgkmcnt(0) above).
+        constexpr bool LATE = (ABL == 0) && !PRIO && !NARROW;
+        auto issue_dma = [&]() {
+            if constexpr (ABL != 2) {
+                if constexpr (tap == 0) { if (cc + 1 < ncc) issue_a(par ^ 1); }
+                if (s + 2 < nsteps) issue_b((tap + 2) % NB);
+            }
+        };
+        if constexpr (!LATE) issue_dma();
         if constexpr (ABL == 3) return;
 
         const unsigned char* As = lds + par * A_BYTES;
@@ -201,11 +209,19 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
         }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);   // transposed tile
+            if constexpr (LATE) {
+                if (ks == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_dma();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto chunk = [&](auto par_c, const int cc) {
@@ -273,7 +289,9 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
                              reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, true>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 1, false>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, false, true>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, true>)};
+                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, true>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 5, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 5, false>)};
         for (const void* f : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -281,7 +299,9 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     }
     dim3 grid(g.ntm * g.ntn, 1, 1);
     static const char* abl = getenv("OMGSR_HALO_ABLATE");      // timing experiments only
-    if (abl && abl[0] == '1') OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 1, false>), grid, dim3(256), LDS_BYTES, st, a, g));
+    static const char* var = getenv("OMGSR_HALO_VARIANT");     // A/B runs: "0" = LDS-DMA issued in front of the step's MFMAs
+    if (var && var[0] == '0' && !narrow) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 5, false>), grid, dim3(256), LDS_BYTES, st, a, g));
+    else if (abl && abl[0] == '1') OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 1, false>), grid, dim3(256), LDS_BYTES, st, a, g));
     else if (abl && abl[0] == '2') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 2, false>), grid, dim3(256), LDS_BYTES, st, a, g);
     else if (abl && abl[0] == '3') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 3, false>), grid, dim3(256), LDS_BYTES, st, a, g);
     else if (narrow) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false, true>), grid, dim3(256), LDS_BYTES, st, a, g));

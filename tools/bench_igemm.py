@@ -24,7 +24,7 @@ dev = "cuda"
 print("mode", os.environ.get("OMGSR_IGEMM_MODE", "auto"))
 FILTER = os.environ.get("SHAPE_FILTER", "")
 for name, N, H, W, Cin, Cout, k in [s for s in SHAPES if FILTER in s[0]]:
-    x = (torch.randn(N, H, W, Cin, device=dev) * 0.5).to(torch.bfloat16)
+    x = (torch.randn(N, H, W, Cin, device=dev) * 0.5).to(ops.act_dtype())
     w = torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5
     pw = ops.pack_conv_weight(w, torch.zeros(Cout, device=dev))
     pad = 1 if k == 3 else 0
