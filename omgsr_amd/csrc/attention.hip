@@ -18,16 +18,38 @@
 //    is contiguous and every operand fragment is a 16-byte (K) or 2 x 8-byte (V^T) LDS read
 //  * LDS pitches: K rows 2*D+16 B (odd number of 16-B slots -> conflict-free ds_read_b128),
 //    V^T rows 136 B (34 banks -> conflict-free ds_read_b64)
+//  * DMA = true (Lk % 64 == 0: every self-attention of the UNet and the Flux joint attention): the K / V^T tiles go
+//    global -> LDS with `global_load_lds_dwordx4` (1 KiB per wave instruction, no staging registers, no ds_write: the
+//    register-staged form spends ~400 LDS cycles per tile on the wide stores, next to ~500 of fragment reads, against 1024
+//    MFMA cycles). A DMA piece lands linearly (lane i -> 16 B at 16 i), so rows are unpadded and the 16-byte slot of a
+//    chunk is XOR-swizzled with the row instead (each lane FETCHES the chunk that belongs at its slot): conflict-free
+//    ds_read_b128 for K and V^T alike. The V^T fragment becomes ONE 16-byte read because the K rows of a 32-key block are
+//    read through the permutation that swaps bits 2 and 3 of the row index: C row (r&3) + 8(r>>2) + 4h of S^T then holds
+//    key 16(r>>3) + 8h + (r&7), i.e. the P^T operand's contraction slots are 8 CONSECUTIVE keys.
 #include "common.hip.h"
 #include "../../include/omgsr_hip.h"
 #include "timing.hip.h"
+#include <stdlib.h>
 
 namespace {
 
-template <typename T, int D>
+OMGSR_DEVINL void glds16_sv(const unsigned voff, const void* sbase, const unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
+template <typename T, int D, bool DMA>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, const int ntiles) {
-    constexpr int KP = 2 * D + 16;
-    constexpr int VP = 136;
+    constexpr int KP = DMA ? 2 * D : 2 * D + 16;
+    constexpr int VP = DMA ? 128 : 136;
     constexpr int K_BYTES = 64 * KP, V_BYTES = D * VP;
     constexpr int STAGE = K_BYTES + V_BYTES;
     constexpr int CPR = D / 8;               // 16-byte chunks per K row
@@ -52,9 +74,43 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
         const T* qr = qp + (int64_t)qrow * p.q_ld + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const x8_t<T>*>(qr + 16 * ks);
+        // retire the loads HERE: hipcc otherwise places their counted vmcnt waits at the first use inside the key loop, where
+        // they also wait for the LDS-DMA of the next tile (vmcnt(7) ... vmcnt(0) across the first eight MFMAs: no prefetch left)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
 
-    u32x4_t kreg[NKC], vreg[NVC];
+    // ---- DMA staging: wave w moves pieces w, w + 4, ... of the K tile and of the V^T tile (1 KiB each); a lane's source offset
+    // is the same for all of its pieces (the swizzle term repeats every 4 pieces), the piece / tile offsets go into the SGPR base
+    constexpr int CPRK = D / 8, RPPK = 64 / CPRK, RPBK = 16 / CPRK;      // K: chunks per row, rows per piece, rows per 256 B of banks
+    constexpr int NPW = (64 * 2 * D / 1024) / 4;                         // pieces per wave and operand (D = 128: 4, 64: 2)
+    unsigned kvoff = 0, vvoff = 0;
+    if constexpr (DMA) {
+        const int krow = RPPK * wave + lane / CPRK, kc = (lane % CPRK) ^ ((krow / RPBK) & (CPRK - 1));
+        kvoff = (unsigned)((krow * p.k_ld + kc * 8) * 2);
+        const int vrow = 8 * wave + (lane >> 3), vc = (lane & 7) ^ ((vrow >> 1) & 7);
+        vvoff = (unsigned)((vrow * p.vt_ld + vc * 8) * 2);
+    }
+    typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+    const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;
+    // piece i of the wave's 2 * NPW per tile: even = K piece i / 2, odd = V^T piece i / 2
+    auto issue_piece = [&](const int kt, const int buf, const int i) {
+        const int j = i >> 1;
+        const unsigned dst = lds_base + buf * STAGE + wave * 1024 + j * 4096;
+        if ((i & 1) == 0) {
+            const unsigned char* kb = reinterpret_cast<const unsigned char*>(kp + (int64_t)kt * 64 * p.k_ld);
+            glds16_sv(kvoff, kb + (int64_t)j * (4 * RPPK) * p.k_ld * 2, __builtin_amdgcn_readfirstlane(dst));
+        } else {
+            const unsigned char* vb = reinterpret_cast<const unsigned char*>(vp + (int64_t)kt * 64);
+            glds16_sv(vvoff, vb + (int64_t)j * 32 * p.vt_ld * 2, __builtin_amdgcn_readfirstlane(dst + K_BYTES));
+        }
+    };
+    auto issue_tile = [&](const int kt, const int buf) {
+#pragma unroll
+        for (int i = 0; i < 2 * NPW; ++i) issue_piece(kt, buf, i);
+    };
+
+    u32x4_t kreg[DMA ? 1 : NKC], vreg[DMA ? 1 : NVC];
     auto load_tile = [&](int kt) {
         const int key_base = kt * 64;
 #pragma unroll
@@ -111,34 +167,84 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     float m_run = -INFINITY, l_run = 0.0f;
     const float sc = p.scale * 1.4426950408889634f;   // softmax in base 2
 
-    load_tile(0);
-    write_tile(0);
-    __syncthreads();
+    // DMA: per-lane fragment offsets inside a stage. K: row 32 sb + pi(l31) (pi swaps bits 2 and 3), chunk 2 ks + half at
+    // slot chunk ^ f(row); V^T: row 32 db + l31, chunk 4 sb + 2 u + half. The block terms (32 sb rows, 32 db rows) leave the
+    // swizzle term unchanged and are immediates.
+    unsigned koff[DMA ? NKS : 1], voff[DMA ? 4 : 1];
+    if constexpr (DMA) {
+        const int prow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+        const int fk = (prow / RPBK) & (CPRK - 1);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) koff[ks] = (unsigned)(prow * KP + (((2 * ks + half) ^ fk) << 4));
+        const int fv = (l31 >> 1) & 7;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) voff[c] = (unsigned)(l31 * VP + (((2 * c + half) ^ fv) << 4));
+        issue_tile(0, 0);
+    } else {
+        load_tile(0);
+        write_tile(0);
+        __syncthreads();
+    }
 
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < ntiles) load_tile(kt + 1);
+        if constexpr (DMA) {
+            // tile kt has landed (this wave's pieces; the barrier extends that to every wave's) and every fragment read of
+            // tile kt - 1 has returned, so its stage may be overwritten
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // issued here, in front of the QK MFMAs: one piece between every two MFMAs measured 3 % slower (901 vs 931 TFLOP/s)
+            if (kt + 1 < ntiles) issue_tile(kt + 1, buf ^ 1);
+        } else {
+            if (kt + 1 < ntiles) load_tile(kt + 1);
+        }
         const unsigned char* Ks = lds + buf * STAGE;
         const unsigned char* Vs = Ks + K_BYTES;
 
         // S^T = K Q^T : two 32-key blocks
         f32x16_t s[2];
+        x8_t<T> vf[DMA ? NDB : 1][4];
+        if constexpr (DMA) {
+            // every K fragment of the tile is requested before the first MFMA (left to itself hipcc reuses ONE fragment
+            // register: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, 32 exposed LDS latencies per tile); sched_barriers pin the phases
+            x8_t<T> kf[2][NKS];
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
+            for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[sb][r] = 0.0f;
-            const unsigned char* kr = Ks + (32 * sb + l31) * KP + half * 16;
+                for (int ks = 0; ks < NKS; ++ks) kf[sb][ks] = *reinterpret_cast<const x8_t<T>*>(Ks + 32 * sb * KP + koff[ks]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const x8_t<T> kf = *reinterpret_cast<const x8_t<T>*>(kr + ks * 32);
-                s[sb] = mfma32(kf, qf[ks], s[sb]);
+            for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[sb][r] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) s[sb] = mfma32(kf[sb][ks], qf[ks], s[sb]);
+            }
+            // ... and the V^T fragments before the softmax, whose ~1000 VALU cycles cover their latency
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vf[db][c] = *reinterpret_cast<const x8_t<T>*>(Vs + 32 * db * VP + voff[c]);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[sb][r] = 0.0f;
+                const unsigned char* kr = Ks + (32 * sb + l31) * KP + half * 16;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const x8_t<T> kf = *reinterpret_cast<const x8_t<T>*>(kr + ks * 32);
+                    s[sb] = mfma32(kf, qf[ks], s[sb]);
+                }
             }
         }
         // online softmax (one query per lane pair), base 2. The raw scores stay unscaled: the row maximum is
         // taken on them (scale > 0), and p = exp2(fma(s, sc, -m*sc)) folds scale, max-subtract and the base change
         // into ONE fma + v_exp_f32 per score. The O / l rescale is skipped when no row of the wave saw its
         // maximum move (the common case after the first tiles).
-        const bool tail = (kt == ntiles - 1) && (p.Lk & 63);
+        const bool tail = !DMA && (kt == ntiles - 1) && (p.Lk & 63);
         float mt = -INFINITY;
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
@@ -181,22 +287,34 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
                 for (int j = 0; j < 8; ++j) pf[sb][u][j] = (T)s[sb][8 * u + j];
 
         // O^T += V^T P^T
+        if constexpr (DMA) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-            const unsigned char* vr = Vs + (32 * db + l31) * VP + 8 * half;
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
+                for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const unsigned char* a = vr + (32 * sb + 16 * u) * 2;
-                    const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(a);
-                    const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(a + 16);
-                    const u32x4_t both = {lo[0], lo[1], hi[0], hi[1]};
-                    o[db] = mfma32(*reinterpret_cast<const x8_t<T>*>(&both), pf[sb][u], o[db]);
-                }
+                    for (int u = 0; u < 2; ++u) o[db] = mfma32(vf[db][2 * sb + u], pf[sb][u], o[db]);
+        } else {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const unsigned char* vr = Vs + (32 * db + l31) * VP + 8 * half;
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const unsigned char* a = vr + (32 * sb + 16 * u) * 2;
+                        const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(a);
+                        const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(a + 16);
+                        const u32x4_t both = {lo[0], lo[1], hi[0], hi[1]};
+                        o[db] = mfma32(*reinterpret_cast<const x8_t<T>*>(&both), pf[sb][u], o[db]);
+                    }
+            }
         }
-        if (kt + 1 < ntiles) write_tile(buf ^ 1);
-        __syncthreads();
+        if constexpr (!DMA) {
+            if (kt + 1 < ntiles) write_tile(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -225,21 +343,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     }
 }
 
-template <int D>
+template <int D, bool DMA>
 int launch_attn(const omgsr_attn_args& a, hipStream_t st) {
-    constexpr int LDS = 2 * (64 * (2 * D + 16) + D * 136);
+    constexpr int LDS = DMA ? 2 * (64 * 2 * D + D * 128) : 2 * (64 * (2 * D + 16) + D * 136);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<bf16_t, D>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<bf16_t, D, DMA>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<f16_t, D>),
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<f16_t, D, DMA>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int ntiles = (a.Lk + 63) / 64;
     dim3 grid((a.Lq + 127) / 128, a.H, a.B);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL((attn_kernel<T, D>), grid, dim3(256), LDS, st, a, ntiles));
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL((attn_kernel<T, D, DMA>), grid, dim3(256), LDS, st, a, ntiles));
     return (int)hipGetLastError();
 }
 
@@ -255,7 +373,10 @@ extern "C" int omgsr_attention(const omgsr_attn_args* ap, void* stream) {
     const double flops = 4.0 * (double)a.B * a.H * (double)a.Lq * a.Lk * a.D;
     const double bytes = 2.0 * (double)a.B * a.H * a.D * (2.0 * a.Lq + 2.0 * a.Lk);
     omgsr::TimingScope ts(OMGSR_TK_ATTN, flops, bytes, st, (long long)a.B * a.H * a.Lq, a.Lk, a.D);
-    if (a.D == 64) return launch_attn<64>(a, st);
-    if (a.D == 128) return launch_attn<128>(a, st);
+    // LDS-DMA staging needs whole 64-key tiles (a DMA piece cannot be masked) and 32-bit source offsets
+    static const char* var = getenv("OMGSR_ATTN_VARIANT");      // A/B runs: "0" = register-staged K / V^T tiles everywhere
+    const bool dma = (a.Lk & 63) == 0 && a.k_ld < (1 << 22) && a.vt_ld < (1 << 22) && !(var && var[0] == '0');
+    if (a.D == 64) return dma ? launch_attn<64, true>(a, st) : launch_attn<64, false>(a, st);
+    if (a.D == 128) return dma ? launch_attn<128, true>(a, st) : launch_attn<128, false>(a, st);
     return OMGSR_E_SHAPE;
 }
