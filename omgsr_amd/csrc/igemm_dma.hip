@@ -62,7 +62,8 @@ OMGSR_DEVINL void wait_vmcnt() {
     else static_assert(N == 0, "unsupported count");
 }
 
-// ABL (ablation, A/B runs only): 0 = the kernel; 1 = no DMA; 2 = DMA + ds_reads, no MFMA; 3 = DMA only
+// ABL (ablation, A/B runs only): 0 = the kernel; 1 = no DMA; 2 = DMA + ds_reads, no MFMA; 3 = DMA only; 4 = no epilogue;
+// 5 = LDS-DMA issued in front of the step's MFMAs; 6 = no fragment reads (profiles/r02_dma_ablation.md)
 template <typename T, int WGM, int WGN, int ABL = 0, int BM = 256>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void igemm_dma_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     constexpr int A_BYTES = BM * BK * 2;       // 16 KB at BM 256
@@ -197,15 +198,25 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void igemm_dma_kernel(const omgs
         }
         if constexpr (ABL == 3) return;
         x8_t<T> af[2][FM], bf[2][FN];
+        if constexpr (ABL == 6) {              // no fragment reads: MFMAs on whatever the registers hold
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            af[0][i] = *reinterpret_cast<const x8_t<T>*>(fa0 + stage * STAGE_BYTES + i * 32 * 64);
-            af[1][i] = *reinterpret_cast<const x8_t<T>*>(fa1 + stage * STAGE_BYTES + i * 32 * 64);
-        }
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            bf[0][j] = *reinterpret_cast<const x8_t<T>*>(fb0 + stage * STAGE_BYTES + j * 32 * 64);
-            bf[1][j] = *reinterpret_cast<const x8_t<T>*>(fb1 + stage * STAGE_BYTES + j * 32 * 64);
+                for (int i = 0; i < FM; ++i) asm volatile("" : "=v"(af[ks][i]));
+#pragma unroll
+                for (int j = 0; j < FN; ++j) asm volatile("" : "=v"(bf[ks][j]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                af[0][i] = *reinterpret_cast<const x8_t<T>*>(fa0 + stage * STAGE_BYTES + i * 32 * 64);
+                af[1][i] = *reinterpret_cast<const x8_t<T>*>(fa1 + stage * STAGE_BYTES + i * 32 * 64);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                bf[0][j] = *reinterpret_cast<const x8_t<T>*>(fb0 + stage * STAGE_BYTES + j * 32 * 64);
+                bf[1][j] = *reinterpret_cast<const x8_t<T>*>(fb1 + stage * STAGE_BYTES + j * 32 * 64);
+            }
         }
         if constexpr (ABL == 2) {
 #pragma unroll
@@ -293,6 +304,10 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     if (abl && abl[0] == '2') return launch_dma<2, 2, 2>(a, g, st);
     if (abl && abl[0] == '3') return launch_dma<2, 2, 3>(a, g, st);
     if (abl && abl[0] == '4') return launch_dma<2, 2, 4>(a, g, st);
+    if (abl && abl[0] == '6') return launch_dma<2, 4, 6>(a, g, st);      // 256 x 256 tile: no fragment reads
+    if (abl && abl[0] == '7') return launch_dma<2, 4, 1>(a, g, st);      // ... no DMA
+    if (abl && abl[0] == '8') return launch_dma<2, 4, 4>(a, g, st);      // ... no epilogue
+    if (abl && abl[0] == '9') return launch_dma<2, 4, 3>(a, g, st);      // ... DMA only
     if (shape && shape[0] == '8') return launch_dma<4, 2>(a, g, st);
     // 256 x 256 tile (8 waves of 128x64): a third fewer operand bytes per FLOP; needs 256-row weight padding and
     // enough tiles to fill the chip
