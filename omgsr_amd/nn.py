@@ -64,6 +64,9 @@ class _Operand:
     """`op_split`: 1, or 2 when this layer's INPUT arrives as a two-term split operand (accurate tier, set per layer by a
     precision policy: omgsr_amd.precision). The producer of the input (norm / cast / GEMM epilogue) asks the consumer."""
     op_split = 1
+    # accurate tier: this layer's OUTPUT is only ever normalised and fed to the next GEMM (a ResnetBlock's conv1): keep it in the
+    # 16-bit compute type instead of the fp32 stream type where the policy says the rounding is affordable (precision.py)
+    out_inner16 = False
 
     def in_split(self) -> int:
         return self.op_split if ops.precise() else 1
@@ -83,6 +86,8 @@ class Conv2d(nn.Conv2d, _Packed, _Operand):
         if bias_override is not None:
             pw = ops.PackedWeight(pw.w, bias_override, pw.cout, pw.cin, pw.R, pw.S, w_cm=pw.w_cm, split=pw.split)
         p = self.padding[0] if pad is None else pad
+        if out_dtype == ops.OUT_STREAM and self.out_inner16 and ops.precise():
+            out_dtype = ops.OUT_BF16
         return ops.conv2d(x, pw, stride=stride or self.stride[0], pad=p, upsample=upsample, act=act, residual=residual,
                           gn_groups=gn_groups, out_dtype=out_dtype, out_split=out_split)
 
