@@ -1,5 +1,5 @@
 """Micro-benchmark of the implicit-GEMM kernels on the OMGSR layer shapes (GPU box).
-Usage: OMGSR_IGEMM_MODE=reg|dma python tools/bench_igemm.py [reps]"""
+Usage: [TIER=fp32] [RES=1] [SHAPE_FILTER=...] OMGSR_IGEMM_MODE=reg|dma python tools/bench_igemm.py [reps]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +21,10 @@ SHAPES = [  # name, N, H, W, Cin, Cout, ksize
 ]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = "cuda"
+TIER = os.environ.get("TIER", "")              # "fp32" = accurate tier (fp32 stream tensors, fp16 operands)
+RES = os.environ.get("RES", "") == "1"         # add a residual in the stream type (a ResnetBlock's conv2 / an attention to_out)
+if TIER:
+    ops.set_compute_dtype({"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[TIER])
 print("mode", os.environ.get("OMGSR_IGEMM_MODE", "auto"))
 FILTER = os.environ.get("SHAPE_FILTER", "")
 for name, N, H, W, Cin, Cout, k in [s for s in SHAPES if FILTER in s[0]]:
@@ -28,11 +32,16 @@ for name, N, H, W, Cin, Cout, k in [s for s in SHAPES if FILTER in s[0]]:
     w = torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5
     pw = ops.pack_conv_weight(w, torch.zeros(Cout, device=dev))
     pad = 1 if k == 3 else 0
-    y = ops.conv2d(x, pw, pad=pad)
+    r = (torch.randn(N, H, W, Cout, device=dev) * 0.5).to(ops.stream_dtype()) if RES else None
+    y = ops.conv2d(x, pw, pad=pad, residual=r)
+    if RES:      # check against the unfused form
+        y0 = ops.conv2d(x, pw, pad=pad).float() + r.float()
+        err = ((y.float() - y0).norm() / y0.norm()).item()
+        assert err < 5e-3, err
     torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(reps):
-        y = ops.conv2d(x, pw, pad=pad)
+        y = ops.conv2d(x, pw, pad=pad, residual=r)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / reps
     fl = 2.0 * N * H * W * Cin * k * k * Cout
