@@ -1,0 +1,33 @@
+"""Assemble profiles/<tag>_*.md + <tag>_traffic.json from what tools/profile_round.sh left under gpurun_out/prof_<dir>.
+Usage: python tools/profile_summary.py gpurun_out/prof_r02b r02_s1024_accurate "title of the workload" [r02_traffic] """
+import json, os, shutil, sys
+
+src, tag, title = sys.argv[1], sys.argv[2], sys.argv[3]
+ttag = sys.argv[4] if len(sys.argv) > 4 else tag + "_traffic"
+bench = json.loads(open(os.path.join(src, "bench_under_trace.json")).read().strip().splitlines()[-1])
+traffic = json.load(open(os.path.join(src, "traffic.json")))
+roof = bench["roofline"]
+fam = traffic["families"]
+lines = []
+lines.append(f"# rocprofv3 --kernel-trace --stats of the default bench: {title}\n")
+lines.append(f"Command (GPU box, `tools/profile_round.sh`): `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 "
+             f"--no-cpu-baseline --no-fast-tiers`; config {json.dumps(bench['config'])}, dtype {bench['dtype']}. "
+             f"5 pipeline passes in the trace (1 warm-up + 3 timed + 1 roofline pass).")
+lines.append(f"bench line under the profiler: {bench['ms_per_step']} ms/step ({bench['value']} {bench['unit']}). bench.py's HIP-event leg in the "
+             f"same run: igemm family {roof['kernel_ms']} ms / {roof['launches']} launches; per kernel (total ms per pass, algorithmic TFLOP/s): "
+             + "; ".join(f"{k} {v['total_ms']} ms / {v['launches']} launches = {v['avg_us']} us avg, {v['achieved_tflops']} TF" for k, v in roof["kernels"].items()) + ".")
+lines.append("The kernel-table rows x 1/5 reproduce those per-pass totals. Rows of torch's own kernels (`at::native`, `__amd_rocclr_*`) belong "
+             "to model set-up (seeded init, weight packing, replica checksum) and are omitted below.\n")
+lines.append(f"HBM traffic of the same command (`profiles/{ttag}.json`, separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, "
+             f"hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024): " +
+             "; ".join(f"{k} {v['hbm_bytes_per_launch'] / 1e6:.0f} MB per launch" for k, v in fam.items()) +
+             f". Algorithmic bytes of the igemm family: {roof.get('algorithmic_bytes_per_launch', 0) / 1e6:.0f} MB per launch.\n")
+lines.append("MFMA / LDS counters of the same command (`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT "
+             "SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE`, `tools/pmc_table.py`; per-launch means):\n")
+lines.append(open(os.path.join(src, "pmc_mfma.md")).read().rstrip() + "\n")
+ks = open(os.path.join(src, "kernel_stats.md")).read().splitlines()
+lines += [l for l in ks if not any(t in l for t in ("at::native", "__amd_rocclr", "elementwise_kernel_with_index", "hipcub", "rocprim"))]
+os.makedirs("profiles", exist_ok=True)
+open(f"profiles/{tag}_kernel_stats.md", "w").write("\n".join(lines) + "\n")
+shutil.copy(os.path.join(src, "traffic.json"), f"profiles/{ttag}.json")
+print(f"profiles/{tag}_kernel_stats.md", len(lines), "lines")
