@@ -202,7 +202,8 @@ def dry_run_cpu(args) -> None:
                           "dry_run": True, "config": {"workload": "dry run (CPU, gloo, reduced models, no kernels)", "global_batch": B * world,
                                                       "images_rank0": [lo, hi],
                                                       "parallelism": f"dp{world} (images sharded, weight broadcast {moved / 2**20:.2f} MiB over {'gloo' if world > 1 else 'nothing'})",
-                                                      "broadcast_bytes": moved, "world_size": world}}))
+                                                      "broadcast_bytes": moved, "world_size": world}}), flush=True)
+    D.shutdown()
 
 
 def main():
@@ -292,7 +293,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
             "setup_s": round(build_secs, 1), **extra,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    D.shutdown()
 
 
 def make_inputs(family, side, B, tile, rank, device, wdtype):

@@ -102,6 +102,15 @@ def barrier():
         dist.barrier()
 
 
+def shutdown() -> None:
+    """Every rank waits for the slowest one (rank 0 runs the untimed roofline leg after the timed region), then the process
+    group is destroyed: no rank exits while a peer could still enter a collective, and RCCL tears down cleanly."""
+    if dist.is_initialized():
+        if dist.get_world_size() > 1:
+            dist.barrier()
+        dist.destroy_process_group()
+
+
 def max_over_ranks(x: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x
