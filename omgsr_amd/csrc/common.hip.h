@@ -6,6 +6,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -170,4 +172,12 @@ OMGSR_DEVINL int xcd_remap(int b, int nblk) {
     const int xcd = b & 7, idx = b >> 3;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
+}
+
+// Ablation switches (OMGSR_*_ABLATE: parts of a kernel compiled out, RESULTS ARE GARBAGE, timing experiments only) are honoured
+// only next to OMGSR_ABLATION_OK=1, so a stray variable cannot corrupt a production run. The *_VARIANT / *_MODE / *_BM switches
+// select between equivalent schedules (same results) and need no gate.
+static inline const char* ablation_env(const char* name) {
+    const char* ok = getenv("OMGSR_ABLATION_OK");
+    return (ok && ok[0] == '1') ? getenv(name) : nullptr;
 }

@@ -263,8 +263,7 @@ int splitk_plan(const omgsr_igemm_args& a_real, int64_t M64) {
     if (use_halo(a)) return 1;                  // the halo-tile kernel takes the problem (and owns the fused GroupNorm statistics)
     const int nk = a.K_pad / 32;
     const int64_t tiles = ((M64 + 255) / 256) * ((logical_cols + 127) / 128);
-    static const char* old = getenv("OMGSR_SPLITK_OLD");              // A/B runs
-    const int slots = old ? 256 : 512;                                 // two 256 x 128 workgroups per CU
+    const int slots = 512;                                             // two 256 x 128 workgroups per CU
     if (tiles >= slots / 2 || nk < 48) return 1;
     int splits = (int)(slots / tiles);
     if (splits > 8) splits = 8;
@@ -279,14 +278,13 @@ bool use_halo(const omgsr_igemm_args& a_real) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     const bool halo_ok = a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 &&
                          (a.Cin % 32) == 0 && a.batch == 1 && a.Ho == (a.H << a.upsample) && a.Wo == (a.W << a.upsample) && a.Wo >= 16 &&
-                         (logical_cols >= 96 || (logical_cols <= 32 && a.act != OMGSR_ACT_GEGLU && !getenv("OMGSR_HALO_NO_NARROW"))) &&
+                         (logical_cols >= 96 || (logical_cols <= 32 && a.act != OMGSR_ACT_GEGLU)) &&
                          a.out_layout == OMGSR_LAYOUT_NHWC;
     if (!halo_ok || (mode && (!strcmp(mode, "reg") || !strcmp(mode, "dma")))) return false;
     if (mode && !strcmp(mode, "halo")) return true;
     // the halo tile is 32 pixels wide: on narrow maps (the UNet's 16 x 16 level) half of every tile would be padding
-    static const char* narrow = getenv("OMGSR_HALO_NARROW");           // A/B runs: "1" = old behaviour
     const int padded_w = ((a.Wo + 31) / 32) * 32;
-    if (!(narrow && narrow[0] == '1') && padded_w * 3 > a.Wo * 4) return false;      // > 1/3 of the columns wasted
+    if (padded_w * 3 > a.Wo * 4) return false;      // > 1/3 of the columns wasted
     return omgsr::igemm_halo_tiles(a) >= 192;
 }
 

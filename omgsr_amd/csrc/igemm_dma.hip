@@ -296,8 +296,8 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     }
     g.splits = 1;
     g.nk = g.nk_total;
-    static const char* shape = getenv("OMGSR_DMA_WAVES");      // A/B runs: "8" = 8 waves of 64x64, "n128" = never use BN 256
-    static const char* abl = getenv("OMGSR_DMA_ABLATE");      // timing experiments only: results are garbage
+    static const char* shape = getenv("OMGSR_DMA_WAVES");      // A/B runs: "n128" = never use BN 256
+    static const char* abl = ablation_env("OMGSR_DMA_ABLATE");      // timing experiments only: results are garbage (needs OMGSR_ABLATION_OK=1)
     static const char* var = getenv("OMGSR_DMA_VARIANT");     // A/B runs: "0" = LDS-DMA issued in front of the MFMAs
     const bool early = var && var[0] == '0';
     if (abl && abl[0] == '1') return launch_dma<2, 2, 1>(a, g, st);
@@ -308,7 +308,6 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     if (abl && abl[0] == '7') return launch_dma<2, 4, 1>(a, g, st);      // ... no DMA
     if (abl && abl[0] == '8') return launch_dma<2, 4, 4>(a, g, st);      // ... no epilogue
     if (abl && abl[0] == '9') return launch_dma<2, 4, 3>(a, g, st);      // ... DMA only
-    if (shape && shape[0] == '8') return launch_dma<4, 2>(a, g, st);
     // 256 x 256 tile (8 waves of 128x64): a third fewer operand bytes per FLOP; needs 256-row weight padding and
     // enough tiles to fill the chip
     const int64_t t256 = (int64_t)g.ntm * ((logical_cols + 255) / 256) * a.batch;
@@ -316,7 +315,7 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     // of 128-wide ones: q/k/v/out of the UNet's first level 108 -> 89 us)
     const int cols256 = ((logical_cols + 255) / 256) * 256, cols128 = ((logical_cols + 127) / 128) * 128;
     if (!(shape && shape[0] == 'n') && (a.Cout_pad % 256) == 0 && logical_cols >= 256 && t256 >= 200 &&
-        (cols256 * 16 <= cols128 * 17 || getenv("OMGSR_DMA_PAD256")))
+        cols256 * 16 <= cols128 * 17)
         return early ? launch_dma<2, 4, 5>(a, g, st) : launch_dma<2, 4>(a, g, st);
     // tile-count quantisation on the 512 slots (2 workgroups per CU): when the 256-row grid leaves the last round under
     // ~3/4 full and the 192-row grid fills it better, take 192 x 128

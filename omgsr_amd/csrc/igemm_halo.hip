@@ -298,7 +298,7 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(g.ntm * g.ntn, 1, 1);
-    static const char* abl = getenv("OMGSR_HALO_ABLATE");      // timing experiments only
+    static const char* abl = ablation_env("OMGSR_HALO_ABLATE");      // timing experiments only: results are garbage (needs OMGSR_ABLATION_OK=1)
     static const char* var = getenv("OMGSR_HALO_VARIANT");     // A/B runs: "0" = LDS-DMA issued in front of the step's MFMAs
     if (var && var[0] == '0' && !narrow) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 5, false>), grid, dim3(256), LDS_BYTES, st, a, g));
     else if (abl && abl[0] == '1') OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 1, false>), grid, dim3(256), LDS_BYTES, st, a, g));
