@@ -26,6 +26,8 @@
 namespace omgsr {
 int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
+bool igemm_p8_wanted(const omgsr_igemm_args& a, const IgemmGeo& g);
+int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 int igemm_halo_tiles(const omgsr_igemm_args& a);
 int igemm_halo_gn_slots(const omgsr_igemm_args& a);
 }
@@ -404,6 +406,11 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     if (use_halo(a)) { ts.rec.variant = 3; return omgsr::igemm_halo_launch(a, g, st); }
     const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0;   // the DMA kernel's K-steps never straddle taps
     if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192))) {
+        static const char* p8 = getenv("OMGSR_P8");               // A/B runs: "0" = never use the ping-pong GEMM kernel
+        if (!(p8 && p8[0] == '0') && !omgsr::g_batch_invariant && omgsr::igemm_p8_wanted(a, g)) {
+            ts.rec.variant = 5;
+            return omgsr::igemm_p8_launch(a, g, st);
+        }
         ts.rec.variant = 2;
         return omgsr::igemm_dma_launch(a, g, st);
     }

@@ -45,4 +45,9 @@ for name, N, H, W, Cin, Cout, k in [s for s in SHAPES if FILTER in s[0]]:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / reps
     fl = 2.0 * N * H * W * Cin * k * k * Cout
-    print(f"{name:32s} {dt * 1e3:8.3f} ms  {fl / dt / 1e12:8.1f} TFLOP/s   finite={bool(torch.isfinite(y.float()).all())}", flush=True)
+    chk = ""
+    if k == 1:       # GEMM-shaped: check against a torch fp32 matmul on the rounded operands
+        wq = w.reshape(Cout, Cin).to(ops.act_dtype()).float()
+        ref = x.reshape(-1, Cin).float() @ wq.t() + (r.reshape(-1, Cout).float() if RES else 0.0)
+        chk = f"  rel err vs torch {((y.reshape(-1, Cout).float() - ref).norm() / ref.norm()).item():.2e}"
+    print(f"{name:32s} {dt * 1e3:8.3f} ms  {fl / dt / 1e12:8.1f} TFLOP/s   finite={bool(torch.isfinite(y.float()).all())}{chk}", flush=True)
