@@ -523,6 +523,39 @@ def test_linear_shapes_around_dispatch_thresholds(M, K, Nout):
     assert_close(y, F.linear(x, w, b) + res, f"linear{(M, K, Nout)}")
 
 
+def test_ping_pong_gemm_kernel():
+    """igemm_p8_kernel (256 x 256 x 64, two wave groups half a phase apart; GEMM-shaped problems with K >= 1536 and >= 200 tiles):
+    a ragged M (rows past M are clamped and dropped), bias + residual, GEGLU, f32 output, a batched bmm, and the same launch
+    repeated (a mis-placed LDS-DMA wait shows up as rare wrong tiles, not as a wrong mean)."""
+    ops = _ops()
+    M, K, Nout = 25700, 1536, 512                      # 101 x 2 tiles of 256 x 256
+    x = rnd(1, M, K, seed=301)
+    w = rnd(Nout, K, seed=302, scale=K ** -0.5)
+    b = rnd(Nout, seed=303)
+    res = rnd(1, M, Nout, seed=304)
+    pw = ops.pack_linear_weight(w, b, device=DEV)
+    xd, rd = bf(x).to(DEV), bf(res).to(DEV)
+    y = ops.linear(xd, pw, residual=rd)
+    assert_close(y, F.linear(x, w, b) + res, "p8 linear + residual, ragged M")
+    for _ in range(60):
+        assert torch.equal(ops.linear(xd, pw, residual=rd), y), "p8 linear: repeat differs"
+    y32 = ops.linear(xd, pw, out_dtype=ops.OUT_F32)
+    assert_close(y32, F.linear(x, w, b), "p8 f32 out", rel_l2=1e-5, max_ulps=0.05)
+    inner = 256                                        # GEGLU: 512 packed columns
+    wg = rnd(2 * inner, 2048, seed=305, scale=2048 ** -0.5)
+    bg = rnd(2 * inner, seed=306, scale=0.1)
+    xg = rnd(1, 25600, 2048, seed=307)
+    h = F.linear(xg, wg, bg)
+    a, g = h.chunk(2, dim=-1)
+    yg = ops.linear(bf(xg).to(DEV), ops.pack_geglu_weight(wg, bg, device=DEV))
+    assert_close(yg, a * F.gelu(g), "p8 geglu")
+    B, Mb, Kb, Nb = 8, 2048, 1536, 1024                # 8 x 8 x 4 = 256 tiles through grid.z
+    a_ = rnd(B, Mb, Kb, seed=308)
+    b_ = rnd(B, Nb, Kb, seed=309)
+    s = ops.bmm_nt(bf(a_).to(DEV), bf(b_).to(DEV), alpha=Kb ** -0.5, out_dtype=ops.OUT_F32)
+    assert_close(s, torch.einsum("bmk,bnk->bmn", a_, b_) * Kb ** -0.5, "p8 bmm_nt", rel_l2=1e-5, max_ulps=0.05)
+
+
 @pytest.mark.parametrize("kind,N,C,Cout,H,W,G", [
     ("halo-channel", 4, 320, 320, 64, 64, 32),        # UNet level 0: group size 10 -> one entry per channel, slot per wave tile
     ("halo-channel", 4, 320, 640, 32, 96, 32),        # group size 20
