@@ -46,6 +46,12 @@ for name, N, H, W, Cin, Cout, k in [s for s in SHAPES if FILTER in s[0]]:
     dt = (time.perf_counter() - t) / reps
     fl = 2.0 * N * H * W * Cin * k * k * Cout
     chk = ""
+    if k == 3 and os.environ.get("CHECK_CONV"):      # against torch's fp32 conv on the rounded operands (one image)
+        wq = w.to(ops.act_dtype()).float()
+        ref = torch.nn.functional.conv2d(x[:1].float().permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1)
+        if RES:
+            ref = ref + r[:1].float()
+        chk = f"  rel err vs torch {((y[:1].float() - ref).norm() / ref.norm()).item():.2e}"
     if k == 1:       # GEMM-shaped: check against a torch fp32 matmul on the rounded operands
         wq = w.reshape(Cout, Cin).to(ops.act_dtype()).float()
         ref = x.reshape(-1, Cin).float() @ wq.t() + (r.reshape(-1, Cout).float() if RES else 0.0)
