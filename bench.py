@@ -290,6 +290,7 @@ def main():
                        "global_batch": B * world, "latent_tile": tile, "tile_overlap": overlap, "mid_timestep": 273 if family == "S" else 244,
                        "timed_region": "pipe.forward: NCHW image in HBM -> NCHW image (clamped), the reference's own region",
                        "parallelism": f"dp{world} (images sharded, RCCL weight broadcast {moved / 2**20:.1f} MiB)", "world_size": world},
+            "args": {"workload": args.workload, "weight_dtype": args.weight_dtype, "batch": B},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
             "setup_s": round(build_secs, 1), **extra,
         }

@@ -29,5 +29,6 @@ ks = open(os.path.join(src, "kernel_stats.md")).read().splitlines()
 lines += [l for l in ks if not any(t in l for t in ("at::native", "__amd_rocclr", "elementwise_kernel_with_index", "hipcub", "rocprim"))]
 os.makedirs("profiles", exist_ok=True)
 open(f"profiles/{tag}_kernel_stats.md", "w").write("\n".join(lines) + "\n")
-shutil.copy(os.path.join(src, "traffic.json"), f"profiles/{ttag}.json")
+traffic.update(bench.get("args", {}))            # bench.py matches the file to its own run by (workload, weight_dtype, batch)
+json.dump(traffic, open(f"profiles/{ttag}.json", "w"), indent=1)
 print(f"profiles/{tag}_kernel_stats.md", len(lines), "lines")
