@@ -212,7 +212,9 @@ bool igemm_p8_wanted(const omgsr_igemm_args& a, const IgemmGeo& g) {
     const int cols256 = ((logical_cols + 255) / 256) * 256, cols128 = ((logical_cols + 127) / 128) * 128;
     // K >= 1536: with fewer K-tiles the six half-tiles of prologue and the 129 KB of LDS (one workgroup per CU) cost more than the
     // schedule wins (the UNet's GEGLU projections, K = 640 / 1280: S-1024 step 165.1 -> 165.7 ms with them on this kernel)
-    return t256 >= 200 && cols256 * 16 <= cols128 * 17 && a.Cin >= 24 * BK;
+    static const char* mt = getenv("OMGSR_P8_MIN_TILES");          // A/B runs
+    const int min_tiles = mt ? atoi(mt) : 128;      // half the CUs: 192 tiles (Flux context tokens, M = 4096) run 25 % faster here than as 384 tiles of 256 x 128
+    return t256 >= min_tiles && cols256 * 16 <= cols128 * 17 && a.Cin >= 24 * BK;
 }
 
 int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {

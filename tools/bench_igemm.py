@@ -18,6 +18,9 @@ SHAPES = [  # name, N, H, W, Cin, Cout, ksize
     ("flux lin 3072->3072 M=4608", 1, 1, 4608, 3072, 3072, 1),
     ("flux lin 3072->12288 M=4608", 1, 1, 4608, 3072, 12288, 1),
     ("flux lin 15360->3072 M=4608", 1, 1, 4608, 15360, 3072, 1),
+    ("flux ctx lin 3072->3072 M=4096", 1, 1, 4096, 3072, 3072, 1),
+    ("flux ctx lin 12288->3072 M=4096", 1, 1, 4096, 12288, 3072, 1),
+    ("flux ctx lin 3072->6144 M=4096", 1, 1, 4096, 3072, 6144, 1),
 ]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = "cuda"
