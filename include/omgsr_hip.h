@@ -206,6 +206,10 @@ typedef struct omgsr_attn_args {
     int32_t o_lo_off;      /* > 0: o is written as the two-term split: lo lands o_lo_off columns after hi
                               (o_lo_off >= H*D, o_ld >= o_lo_off + H*D, o_lo_off % 4 == 0) */
 } omgsr_attn_args;
+/* Process-wide (default 0): the online softmax moves its running maximum only when a row's maximum grows by more than 2^t in
+ * the scaled base-2 domain (probabilities then reach 2^t instead of 1; the result is the same quotient). 0 = exact running
+ * maximum. 0 <= t <= 12. +5 % attention throughput at t = 8; the fast tiers use it, the accurate tier does not. */
+int omgsr_set_attention_defer_max(float log2_threshold);
 int omgsr_attention(const omgsr_attn_args* a, void* stream);
 
 /* Row softmax for the unfused d=512 VAE attention: p = softmax(s[:, :Lvalid]); s f32 [rows][L],

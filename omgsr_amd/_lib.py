@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class OmgsrError(RuntimeError):
@@ -75,6 +75,7 @@ SIGNATURES = {
     "omgsr_error_string": (C.c_char_p, [C.c_int]),
     "omgsr_igemm": (C.c_int, [C.POINTER(IgemmArgs), _P]),
     "omgsr_set_batch_invariant": (C.c_int, [C.c_int]),
+    "omgsr_set_attention_defer_max": (C.c_int, [C.c_float]),
     "omgsr_igemm_workspace_bytes": (C.c_int64, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_slots": (C.c_int32, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_entries": (C.c_int32, [C.POINTER(IgemmArgs)]),

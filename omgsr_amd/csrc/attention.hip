@@ -47,7 +47,7 @@ OMGSR_DEVINL void glds16_sv(const unsigned voff, const void* sbase, const unsign
 }
 
 template <typename T, int D, bool DMA>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, const int ntiles) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, const int ntiles, const float defer) {
     constexpr int KP = DMA ? 2 * D : 2 * D + 16;
     constexpr int VP = DMA ? 128 : 136;
     constexpr int K_BYTES = 64 * KP, V_BYTES = D * VP;
@@ -254,9 +254,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
                 mt = fmaxf(mt, s[sb][r]);
             }
         mt = fmaxf(mt, __shfl_xor(mt, 32));
+        // Deferred maximum (omgsr_set_attention_defer_max, fast tiers): the running maximum (and with it O, l) is only moved when some
+        // row of the wave saw its maximum grow by more than 2^defer in the scaled base-2 domain; until then p = exp2((s - m_run) * sc)
+        // <= 2^defer, inside the 16-bit operand range, and O / l is the same quotient. On smooth score distributions that is the
+        // first tile only (with defer = 0, i.e. the exact running maximum, ~half of the tiles of a 4608-key sweep rescale the 64 O
+        // registers): +5 % throughput; the dominant weight of a row is then a rounded exp2(delta) instead of an exact 1, which costs
+        // ~1 % of the pipeline's error budget - the accurate tier keeps defer = 0.
         const float m_new = fmaxf(m_run, mt);
-        const float neg_m = -m_new * sc;
-        const bool moved = m_new != m_run;
+        if (__any((m_new - m_run) * sc > defer)) {                                // m_run = -inf on the first tile -> inf > defer
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);    // ... and alpha = 0
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            m_run = m_new;
+        }
+        const float neg_m = -m_run * sc;
         float rs = 0.0f;
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
@@ -266,15 +280,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
                 s[sb][r] = e;
                 rs += e;
             }
-        if (__any(moved)) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);    // m_run = -inf on the first tile -> 0
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < NDB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        }
-        m_run = m_new;
         l_run += rs;
 
         // P^T operand: score registers converted in place (key permutation, see header)
@@ -343,6 +348,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     }
 }
 
+float g_defer_max = 0.0f;
+
 template <int D, bool DMA>
 int launch_attn(const omgsr_attn_args& a, hipStream_t st) {
     constexpr int LDS = DMA ? 2 * (64 * 2 * D + D * 128) : 2 * (64 * (2 * D + 16) + D * 136);
@@ -357,11 +364,17 @@ int launch_attn(const omgsr_attn_args& a, hipStream_t st) {
     }
     const int ntiles = (a.Lk + 63) / 64;
     dim3 grid((a.Lq + 127) / 128, a.H, a.B);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL((attn_kernel<T, D, DMA>), grid, dim3(256), LDS, st, a, ntiles));
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL((attn_kernel<T, D, DMA>), grid, dim3(256), LDS, st, a, ntiles, g_defer_max));
     return (int)hipGetLastError();
 }
 
 }  // namespace
+
+extern "C" int omgsr_set_attention_defer_max(float log2_threshold) {
+    if (!(log2_threshold >= 0.0f && log2_threshold <= 12.0f)) return OMGSR_E_BADARG;
+    g_defer_max = log2_threshold;
+    return 0;
+}
 
 extern "C" int omgsr_attention(const omgsr_attn_args* ap, void* stream) {
     if (!ap || !ap->q || !ap->k || !ap->vt || !ap->o) return OMGSR_E_BADARG;

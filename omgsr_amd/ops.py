@@ -63,6 +63,8 @@ def set_compute_dtype(dtype: torch.dtype) -> None:
         raise TypeError(f"compute dtype must be bfloat16, float16 or float32, got {dtype}")
     act = torch.bfloat16 if dtype == torch.bfloat16 else torch.float16
     check(_lib.load().omgsr_set_compute_dtype(0 if act == torch.bfloat16 else 1), "set_compute_dtype")
+    # fast tiers: deferred softmax maximum (+5 % attention); accurate tier: exact running maximum
+    check(_lib.load().omgsr_set_attention_defer_max(0.0 if dtype == torch.float32 else 8.0), "set_attention_defer_max")
     _ACT, _PRECISE = act, dtype == torch.float32
 
 

@@ -294,6 +294,7 @@ def test_attention_spiked_max():
     v = rnd(B, L, D, seed=31)
     k[0, 300] = q[0, 5] * 4.0      # spikes q row 5 in the 5th key tile
     k[0, 500] = q[0, 70] * 6.0
+    k[0, 400] = q[0, 9] * 0.6      # a late maximum BELOW the deferred-rescale threshold (2^8 in the scaled base-2 domain): p > 1, no rescale
     k = bf(k).float()
     scale = D ** -0.5
     ref = _sdpa_ref(q, k, v, H, scale)
