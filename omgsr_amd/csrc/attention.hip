@@ -215,12 +215,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
                 for (int ks = 0; ks < NKS; ++ks) kf[sb][ks] = *reinterpret_cast<const x8_t<T>*>(Ks + 32 * sb * KP + koff[ks]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
+            for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[sb][r] = 0.0f;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) s[sb] = mfma32(kf[sb][ks], qf[ks], s[sb]);
-            }
+            __builtin_amdgcn_s_setprio(0);
             // ... and the V^T fragments before the softmax, whose ~1000 VALU cycles cover their latency
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
@@ -294,12 +297,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
         // O^T += V^T P^T
         if constexpr (DMA) {
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) o[db] = mfma32(vf[db][2 * sb + u], pf[sb][u], o[db]);
+            __builtin_amdgcn_s_setprio(0);
         } else {
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
