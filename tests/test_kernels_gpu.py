@@ -165,6 +165,26 @@ def test_linear_transposed_out():
     assert (yt[:, :, L:] == 0).all()
 
 
+@pytest.mark.parametrize("B,L,K,Nout", [(2, 256, 320, 320), (3, 4096, 320, 320), (1, 4608, 3072, 3072), (2, 96, 640, 200)])
+def test_linear_transposed_out_whole_blocks(B, L, K, Nout):
+    """L % 32 == 0: the column-wise 16-byte epilogue path of the transposed output (register-staged, LDS-DMA and ping-pong kernels),
+    with a bias; and through linear_t_into at a key offset of a wider V^T buffer."""
+    ops = _ops()
+    x = rnd(B, L, K, seed=116)
+    w = rnd(Nout, K, seed=117, scale=1.0 / math.sqrt(K))
+    b = rnd(Nout, seed=118)
+    pw = ops.pack_linear_weight(w, b, device=DEV)
+    xd = bf(x).to(DEV)
+    yt = ops.linear_t(xd, pw, L)
+    assert yt.shape == (B, Nout, L)
+    ref = F.linear(x, w, b).transpose(1, 2)
+    assert_close(yt, ref, f"linear_t whole blocks {(B, L, K, Nout)}")
+    vt = torch.full((B, Nout, L + 64), 7.0, device=DEV, dtype=ops.act_dtype())
+    ops.linear_t_into(xd, pw, vt, 32)
+    assert_close(vt[:, :, 32:32 + L], ref, "linear_t_into at key 32")
+    assert (vt[:, :, :32] == 7).all() and (vt[:, :, 32 + L:] == 7).all()
+
+
 def test_split_k_paths():
     """Small-M / long-K problems are split over K (fp32 partial tiles + reduce pass with the full epilogue)."""
     ops = _ops()
