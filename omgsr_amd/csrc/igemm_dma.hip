@@ -296,7 +296,7 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     }
     g.splits = 1;
     g.nk = g.nk_total;
-    static const char* shape = getenv("OMGSR_DMA_WAVES");      // A/B runs: "n128" = never use BN 256
+    static const char* shape = getenv("OMGSR_DMA_WAVES");      // A/B runs: "256" = allow the lockstep 8-wave 256 x 256 tile again
     static const char* abl = ablation_env("OMGSR_DMA_ABLATE");      // timing experiments only: results are garbage (needs OMGSR_ABLATION_OK=1)
     static const char* var = getenv("OMGSR_DMA_VARIANT");     // A/B runs: "0" = LDS-DMA issued in front of the MFMAs
     const bool early = var && var[0] == '0';
@@ -314,7 +314,9 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     // ... and no more padded columns than the 128-wide grid would compute (N = 320 is 512 columns of 256-wide tiles but 384
     // of 128-wide ones: q/k/v/out of the UNet's first level 108 -> 89 us)
     const int cols256 = ((logical_cols + 255) / 256) * 256, cols128 = ((logical_cols + 127) / 128) * 128;
-    if (!(shape && shape[0] == 'n') && (a.Cout_pad % 256) == 0 && logical_cols >= 256 && t256 >= 200 &&
+    // (since the ping-pong kernel took the long-K GEMMs the lockstep tile loses to two independent 256 x 128 workgroups per CU on
+    // everything that is left: short K, epilogue-bound - S-1024 step -0.7 ms, F-1024 -1.9 ms without it; kept for A/B only)
+    if ((shape && shape[0] == '2') && (a.Cout_pad % 256) == 0 && logical_cols >= 256 && t256 >= 200 &&
         cols256 * 16 <= cols128 * 17)
         return early ? launch_dma<2, 4, 5>(a, g, st) : launch_dma<2, 4>(a, g, st);
     // tile-count quantisation on the 512 slots (2 workgroups per CU): when the 256-row grid leaves the last round under
