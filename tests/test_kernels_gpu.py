@@ -287,7 +287,8 @@ def _sdpa_ref(q, k, v, heads, scale):
 
 @pytest.mark.parametrize("B,H,D,Lq,Lk,bcast", [
     (2, 5, 64, 256, 256, False), (1, 10, 64, 1024, 1024, False), (2, 20, 64, 64, 64, False),
-    (2, 5, 64, 256, 77, True), (1, 5, 64, 100, 77, False), (1, 4, 128, 320, 320, False), (1, 2, 128, 200, 136, False)])
+    (2, 5, 64, 256, 77, True), (1, 5, 64, 100, 77, False), (1, 4, 128, 320, 320, False), (1, 2, 128, 200, 136, False),
+    (1, 2, 128, 200, 192, False), (2, 5, 64, 256, 128, True), (1, 3, 128, 1000, 4608, False)])        # LDS-DMA staging (Lk % 64 == 0): ragged Lq, broadcast K / V, a long sweep
 def test_attention(B, H, D, Lq, Lk, bcast):
     ops = _ops()
     inner = H * D
