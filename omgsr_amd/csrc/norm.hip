@@ -454,12 +454,16 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(T* __restrict__ x, co
     for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float r = rsqrtf(q / (float)D + eps);
     const float* wt = (w2 && (int)(row % L) >= Lsplit) ? w2 : w;       // joint [text ; image] sequence: two weight tables
+    // weight / cos / sin rows as 2 x 16-byte loads each (24 scalar loads per thread made this pass run at 4.3 TB/s)
+    float wv[8];
+    load_affine8(wt, h * D + sub * 8, 1.0f, wv);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = f[e] * r * wt[h * D + sub * 8 + e];
+    for (int e = 0; e < 8; ++e) f[e] = f[e] * r * wv[e];
     if (cos_t) {
         const int pos = pos0 + (int)(row % L);
-        const float* cp = cos_t + (int64_t)pos * D + sub * 8;
-        const float* sp = sin_t + (int64_t)pos * D + sub * 8;
+        float cp[8], sp[8];
+        load_affine8(cos_t, (int)((int64_t)pos * D) + sub * 8, 1.0f, cp);
+        load_affine8(sin_t, (int)((int64_t)pos * D) + sub * 8, 0.0f, sp);
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
             const float a = f[e], b = f[e + 1];
