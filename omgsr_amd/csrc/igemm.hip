@@ -21,6 +21,7 @@
 #include "timing.hip.h"
 #include "igemm_epilogue.hip.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 namespace omgsr {
@@ -404,6 +405,13 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         if (nslot <= 0 || a.gn_entries != entries) return OMGSR_E_BADARG;
     }
     if (use_halo(a)) { ts.rec.variant = 3; return omgsr::igemm_halo_launch(a, g, st); }
+    {
+        static const char* dbg = getenv("OMGSR_DEBUG_DISPATCH");      // one line per conv-shaped problem that did NOT take the halo kernel
+        if (dbg && a.R == 3)
+            fprintf(stderr, "[omgsr] 3x3 off the halo path: N %d H %d W %d Cin %d Cout %d stride %d pad %d,%d ups %d Ho %d Wo %d cm %d batch %d act %d layout %d tiles %d\n",
+                    a.N, a.H, a.W, a.Cin, a.Cout, a.stride, a.pad_top, a.pad_left, a.upsample, a.Ho, a.Wo, a.weight_cm != nullptr, a.batch, a.act, a.out_layout,
+                    omgsr::igemm_halo_tiles(a));
+    }
     const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0;   // the DMA kernel's K-steps never straddle taps
     if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192))) {
         static const char* p8 = getenv("OMGSR_P8");               // A/B runs: "0" = never use the ping-pong GEMM kernel
