@@ -82,6 +82,12 @@ CONV_CASES = [
     (4, 128, 8, 86, 150, 1, (1, 1, 1, 1), False, True, False, 0),
     (1, 64, 16, 256, 200, 1, (1, 1, 1, 1), False, False, True, 1),
     (2, 32, 32, 100, 260, 1, (1, 1, 1, 1), True, True, False, 0),
+    # convs that miss the halo kernel and take the ping-pong GEMM kernel's implicit-GEMM form (K >= 1536, >= 128 tiles of 256 x 256)
+    (72, 256, 512, 16, 16, 1, (1, 1, 1, 1), False, True, True, 0),     # 16-wide maps (UNet 16 x 16 level)
+    (8, 256, 256, 128, 128, 2, (0, 1, 0, 1), False, True, False, 0),   # VAE down-sampling conv
+    (9, 192, 256, 118, 122, 2, (1, 1, 1, 1), False, True, False, 1),   # stride 2, ragged, 33 792 rows (last tile partial)
+    (144, 256, 256, 8, 8, 1, (1, 1, 1, 1), True, False, False, 0),     # nearest-2x upsampling to 16 x 16
+    (40, 512, 512, 40, 40, 1, (1, 1, 1, 1), False, True, True, 0),     # 40-wide maps (tiled-VAE encoder's last level)
 ]
 
 
