@@ -1,0 +1,38 @@
+"""Soak: the same launch repeated many times must give the same bits (a mis-placed LDS-DMA wait shows up as rare wrong tiles).
+Kernels with hand-placed waits: igemm_p8_kernel, attn_kernel (LDS-DMA path), igemm_halo_kernel, igemm_dma_kernel. Usage: soak_repeat.py [reps]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omgsr_amd import ops
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+dev = "cuda"
+g = torch.Generator().manual_seed(7)
+def soak(name, fn, n):
+    ref = fn(); bad = 0
+    for _ in range(n):
+        bad += int(not torch.equal(fn(), ref))
+    print(f"{name:48s} {n} repeats, {bad} differ", flush=True)
+    return bad
+total = 0
+for tier in (torch.bfloat16, torch.float32):
+    ops.set_compute_dtype(tier)
+    dt = ops.act_dtype()
+    tag = "accurate" if tier == torch.float32 else "bf16"
+    for M, K, N in [(4608, 3072, 3072), (36864, 3072, 12288), (4096, 12288, 3072), (25700, 1536, 512)]:
+        x = (torch.randn(1, M, K, generator=g) * 0.5).to(dt).to(dev)
+        pw = ops.pack_linear_weight(torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g), device=dev)
+        total += soak(f"[{tag}] p8 linear {M}x{K}->{N}", lambda: ops.linear(x, pw, out_dtype=ops.OUT_BF16), reps if M < 30000 else reps // 4)
+    for B, H, D, L in [(2, 24, 128, 4608), (8, 5, 64, 4096)]:
+        qk = (torch.randn(B, L, 2 * H * D, generator=g) * 0.5).to(dt).to(dev)
+        vt = (torch.randn(B, H * D, L, generator=g) * 0.5).to(dt).to(dev)
+        total += soak(f"[{tag}] attention {B}x{H}x{D} L {L}", lambda: ops.attention(qk, qk, vt, H, D, D ** -0.5, q_col=0, k_col=H * D, Lk=L), reps)
+    for N_, C, Co, H_, W_ in [(4, 128, 128, 256, 256), (4, 512, 512, 64, 64), (36, 320, 320, 64, 64)]:
+        xc = (torch.randn(N_, H_, W_, C, generator=g) * 0.5).to(dt).to(dev)
+        pc = ops.pack_conv_weight(torch.randn(Co, C, 3, 3, generator=g) * (9 * C) ** -0.5, torch.zeros(Co), device=dev)
+        total += soak(f"[{tag}] halo conv {N_}x{H_}x{W_} {C}->{Co}", lambda: ops.conv2d(xc, pc, pad=1), reps)
+    x2 = (torch.randn(1, 147456, 320, generator=g) * 0.5).to(dt).to(dev)
+    p2 = ops.pack_linear_weight(torch.randn(320, 320, generator=g) * 320 ** -0.5, None, device=dev)
+    total += soak(f"[{tag}] dma linear 147456x320->320", lambda: ops.linear(x2, p2, out_dtype=ops.OUT_BF16), reps)
+ops.set_compute_dtype(torch.bfloat16)
+print("TOTAL differing:", total)
+sys.exit(1 if total else 0)
