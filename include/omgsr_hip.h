@@ -114,6 +114,13 @@ typedef struct omgsr_igemm_args {
                               instead of the batch's total rows, so a batch of B gives the bits of B batch-1 calls */
     int32_t out_lo_off;    /* > 0: a 16-bit output is written as the two-term split: hi at column n, lo at column n + out_lo_off
                               of the same row (out_lo_off >= Cout, out_ld >= out_lo_off + Cout, both % 8 == 0; NHWC, Cout % 8 == 0) */
+    int32_t in_ld;         /* physical channels of one input pixel row; 0 = Cin. in_ld < Cin (in_ld <= Cin <= 2 * in_ld, in_ld % 8 == 0): the
+                              contraction is longer than the row and WRAPS - channel c of a tap reads input channel c - in_ld for
+                              c >= in_ld. That is how a weight carried as the two-term split w = w_hi + w_lo (accurate tier, fp32
+                              checkpoints that are not 16-bit representable) meets the operand without copying it: the packed weight
+                              holds [w_hi | w_lo] per tap against an operand [a] (Cin = 2C, in_ld = C), or [w_hi | w_hi | w_lo] against a
+                              split operand [a_hi | a_lo] (Cin = 3C, in_ld = 2C: a_hi w_hi + a_lo w_hi + a_hi w_lo in one fp32 accumulator) */
+    int32_t w_split;       /* 0 | 1: the packed weight carries the extra [w_lo] segment (informational: FLOP accounting) */
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
 /* Batch-invariant dispatch (process-wide, default off). The dispatcher normally picks the kernel family (halo-tile conv vs GEMM-shaped)
@@ -312,8 +319,11 @@ int omgsr_timing_reset(void);
  * the dispatcher launched - 1 igemm_kernel (register staged), 2 igemm_dma_kernel, 3 igemm_halo_kernel, 4 igemm_dma_kernel
  * split-K + splitk_reduce_kernel. flops / bytes: ALGORITHMIC work of the launch (a two-term split operand's duplicated
  * channels count once). */
-typedef struct omgsr_timing_entry { int32_t kind; float ms; double flops; double bytes; int64_t m, n, k; int32_t variant; int32_t reserved; } omgsr_timing_entry;
+typedef struct omgsr_timing_entry { int32_t kind; float ms; double flops; double bytes; int64_t m, n, k; int32_t variant; int32_t stage; } omgsr_timing_entry;
 int omgsr_timing_collect(omgsr_timing_entry* out, int cap);
+/* Tag every launch recorded from now on with `stage` (the pipelines mark encode = 1 / denoiser = 2 / decode = 3; 0 = untagged), so the
+ * roofline leg can report per-stage time and the denoiser-only MFMA fraction. Free when timing is off. */
+int omgsr_timing_stage(int stage);
 /* Dense 16-bit MFMA micro-benchmark (compute dtype) on the current device: measured TFLOP/s through the HOST pointer.
  * Synchronises `stream`; a benchmarking utility (bench.py records it beside the roofline fractions). */
 int omgsr_mfma_peak(int32_t iters, float* tflops, void* stream);

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class OmgsrError(RuntimeError):
@@ -37,6 +37,7 @@ class IgemmArgs(C.Structure):
         ("alpha", C.c_float), ("weight_cm", C.c_void_p), ("workspace", C.c_void_p),
         ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32), ("gn_entries", C.c_int32),
         ("res_el", C.c_int32), ("in_split", C.c_int32), ("sample_rows", C.c_int64), ("out_lo_off", C.c_int32),
+        ("in_ld", C.c_int32), ("w_split", C.c_int32),
     ]
 
 
@@ -61,7 +62,7 @@ class AttnArgs(C.Structure):
 
 class TimingEntry(C.Structure):
     _fields_ = [("kind", C.c_int32), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double),
-                ("m", C.c_int64), ("n", C.c_int64), ("k", C.c_int64), ("variant", C.c_int32), ("reserved", C.c_int32)]
+                ("m", C.c_int64), ("n", C.c_int64), ("k", C.c_int64), ("variant", C.c_int32), ("stage", C.c_int32)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -107,6 +108,7 @@ SIGNATURES = {
     "omgsr_resample_u8": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "omgsr_timing_enable": (C.c_int, [C.c_int]),
     "omgsr_timing_reset": (C.c_int, []),
+    "omgsr_timing_stage": (C.c_int, [C.c_int]),
     "omgsr_timing_collect": (C.c_int, [C.POINTER(TimingEntry), C.c_int]),
     "omgsr_mfma_peak": (C.c_int, [_I, C.POINTER(C.c_float), _P]),
 }

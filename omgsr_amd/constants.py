@@ -13,11 +13,12 @@ This module writes them to ONE safetensors file next to the weights and loads th
 inference host needs neither `transformers`, the 4.7 B-parameter T5 nor a warm-up forward: `load_s(pipe, path)` returns the
 prompt tensor to pass to `pipe(...)`.
 
-Wire format (version 1): a safetensors container; `__metadata__` holds
+Wire format (version 2): a safetensors container; `__metadata__` holds
   format = "omgsr-constants", version, family ("S" | "F"), tier (bf16 | fp16 | fp32: ops.compute_dtype_name()), abi (C ABI version),
-  mid_timestep, (F: guidance_scale, t_curr), checksum.<module> = bit-exact checksum of the weights the constants were folded from
+  mid_timestep, (F: guidance_scale, t_curr), checksum.<module> = bit-exact checksum of the weights the constants were folded from,
+  policy.<module> = fingerprint of the accurate tier's precision policy they were folded under ("none" in the fast tiers)
 and the tensors are named `<model>.<kind>.<qualified module name>[.<field>]` (listed by `describe(path)`). A file whose tier,
-timestep or weight checksum does not match the pipeline it is loaded into is refused.
+timestep, weight checksum or precision policy does not match the pipeline it is loaded into is refused.
 """
 from __future__ import annotations
 
@@ -28,7 +29,7 @@ import torch
 from . import _lib, ops
 from .dist import module_checksum
 
-FORMAT, VERSION = "omgsr-constants", "1"
+FORMAT, VERSION = "omgsr-constants", "2"
 
 
 class ConstantsMismatch(RuntimeError):
@@ -44,8 +45,11 @@ def _meta(family: str, pipe, extra: Dict[str, str], modules: Dict[str, torch.nn.
     meta = {"format": FORMAT, "version": VERSION, "family": family, "tier": ops.compute_dtype_name(), "abi": str(_lib.ABI_VERSION),
             "mid_timestep": str(int(pipe.mid_timestep))}
     meta.update(extra)
+    from .precision import policy_fingerprint
     for name, m in modules.items():
         meta[f"checksum.{name}"] = _checksum(m)
+        # the folded K / V^T / context tensors are GEMM outputs: they depend on which layers carry split operands / weights
+        meta[f"policy.{name}"] = policy_fingerprint(m) if ops.precise() else "none"
     return meta
 
 

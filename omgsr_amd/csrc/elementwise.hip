@@ -184,7 +184,7 @@ inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)((tot
 
 }  // namespace
 
-extern "C" int omgsr_abi_version(void) { return 12; }
+extern "C" int omgsr_abi_version(void) { return 13; }
 
 extern "C" int omgsr_set_compute_dtype(int dtype) {
     if (dtype != OMGSR_DT_BF16 && dtype != OMGSR_DT_F16) return OMGSR_E_BADARG;
@@ -343,6 +343,7 @@ extern "C" int omgsr_flux_pack(const void* src, void* dst, int32_t N, int32_t H,
 }
 
 extern "C" int omgsr_timing_enable(int on) { omgsr::timing_state().on = (on != 0); return 0; }
+extern "C" int omgsr_timing_stage(int stage) { omgsr::timing_state().stage = stage; return 0; }
 
 extern "C" int omgsr_timing_reset(void) {
     auto& s = omgsr::timing_state();
@@ -360,7 +361,7 @@ extern "C" int omgsr_timing_collect(omgsr_timing_entry* out, int cap) {
             float ms = 0.0f;
             (void)hipEventElapsedTime(&ms, r.e0, r.e1);
             out[n].kind = r.kind; out[n].ms = ms; out[n].flops = r.flops; out[n].bytes = r.bytes;
-            out[n].m = r.m; out[n].n = r.n; out[n].k = r.k; out[n].variant = r.variant; out[n].reserved = 0;
+            out[n].m = r.m; out[n].n = r.n; out[n].k = r.k; out[n].variant = r.variant; out[n].stage = r.stage;
         }
         ++n;
     }

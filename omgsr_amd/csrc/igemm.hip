@@ -103,6 +103,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args 
     // chunk cursor: this thread's chunk at K-step kt covers k = kt*32 + kc*8 .. +8 = (tap, c0..c0+8)
     int c0 = kc * 8, tap_r = 0, tap_s = 0;
     while (c0 >= p.Cin) { c0 -= p.Cin; if (++tap_s == p.S) { tap_s = 0; ++tap_r; } }
+    const int ild = p.in_ld > 0 ? p.in_ld : p.Cin;     // physical channels per pixel row; contraction channels >= ild wrap (w_lo segment)
 
     u32x4_t a_reg[A_CH], b_reg[B_CHN];
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const omgsr_igemm_args 
             if (ok) {
                 const int iy = vy >> p.upsample, ix = vx >> p.upsample;
                 const int64_t pix = ((int64_t)a_img[i] * p.H + iy) * p.W + ix;
-                v = *reinterpret_cast<const u32x4_t*>(in + pix * p.Cin + c0);
+                v = *reinterpret_cast<const u32x4_t*>(in + pix * ild + (c0 >= ild ? c0 - ild : c0));
             }
             a_reg[i] = v;
         }
@@ -248,6 +249,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
         if (p.residual) x += p.res_el == OMGSR_EL_F32 ? ((const float*)p.residual)[(int64_t)m * p.Cout + n + e]
                                                        : (float)((const T*)p.residual)[(int64_t)m * p.Cout + n + e];
         if (p.out_dtype == OMGSR_OUT_BF16) {
+            // same overflow behaviour as the fused epilogues (pack2 / split8): fp16 saturates at +-65504 instead of hi = inf, lo = -inf
+            if constexpr (std::is_same<T, f16_t>::value) x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
             const T hi = (T)x;
             ((T*)p.out)[(int64_t)m * ldo + n + e] = hi;
             if (p.out_lo_off > 0) ((T*)p.out)[(int64_t)m * ldo + p.out_lo_off + n + e] = (T)(x - (float)hi);
@@ -262,7 +265,7 @@ int splitk_plan(const omgsr_igemm_args& a_real, int64_t M64) {
     const omgsr_igemm_args a = policy_view(a_real);
     if (omgsr::g_batch_invariant) M64 = (int64_t)a.N * a.Ho * a.Wo;
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
-    if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || logical_cols < 96) return 1;
+    if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || (a.in_ld % 32) || logical_cols < 96) return 1;
     if (use_halo(a)) return 1;                  // the halo-tile kernel takes the problem (and owns the fused GroupNorm statistics)
     const int nk = a.K_pad / 32;
     const int64_t tiles = ((M64 + 255) / 256) * ((logical_cols + 127) / 128);
@@ -280,7 +283,7 @@ bool use_halo(const omgsr_igemm_args& a_real) {
     static const char* mode = getenv("OMGSR_IGEMM_MODE");
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     const bool halo_ok = a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 &&
-                         (a.Cin % 32) == 0 && a.batch == 1 && a.Ho == (a.H << a.upsample) && a.Wo == (a.W << a.upsample) && a.Wo >= 16 &&
+                         (a.Cin % 32) == 0 && (a.in_ld % 32) == 0 && a.batch == 1 && a.Ho == (a.H << a.upsample) && a.Wo == (a.W << a.upsample) && a.Wo >= 16 &&
                          (logical_cols >= 96 || (logical_cols <= 32 && a.act != OMGSR_ACT_GEGLU)) &&
                          a.out_layout == OMGSR_LAYOUT_NHWC;
     if (!halo_ok || (mode && (!strcmp(mode, "reg") || !strcmp(mode, "dma")))) return false;
@@ -362,7 +365,11 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     if (a.out_lo_off < 0) return OMGSR_E_BADARG;
     if (a.out_lo_off && (a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cout & 7) || (a.out_ld & 7) || (a.out_lo_off & 7) ||
                          a.out_lo_off < a.Cout || a.out_ld < a.out_lo_off + a.Cout || a.gn_partial)) return OMGSR_E_SHAPE;
-    if (a.in_split && (a.Cin & 15)) return OMGSR_E_SHAPE;
+    if (a.in_split && ((a.in_ld > 0 ? a.in_ld : a.Cin) & 15)) return OMGSR_E_SHAPE;
+    if (a.in_ld < 0 || (a.in_ld & 7) || (a.in_ld > 0 && (a.in_ld > a.Cin || a.Cin > 2 * a.in_ld))) return OMGSR_E_SHAPE;
+    if (a.in_ld == a.Cin) a.in_ld = 0;
+    const int ksegs = 1 + (a.in_split ? 1 : 0) + (a.w_split ? 1 : 0);      // K-concat segments of one logical channel set
+    if (a.Cin % (8 * ksegs)) return OMGSR_E_SHAPE;
     Geo g;
     g.M = (int)M64;
     g.HoWo = a.Ho * a.Wo;
@@ -371,17 +378,21 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     g.nk = a.K_pad / BK;
     hipStream_t st = (hipStream_t)stream;
     // algorithmic work: a split operand's duplicated channels are precision overhead, not useful FLOPs
-    const int cin_logical = a.in_split ? a.Cin / 2 : a.Cin;
+    const int cin_logical = a.Cin / ksegs;
     const double flops = 2.0 * (double)M64 * (double)a.R * a.S * cin_logical * (double)logical_cols * a.batch;
     const double out_b = (a.out_dtype == OMGSR_OUT_F32 ? 4.0 : (a.out_lo_off ? 4.0 : 2.0)), res_b = a.residual ? (a.res_el == OMGSR_EL_F32 ? 4.0 : 2.0) : 0.0;
-    const double bytes = (2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)a.Cout_pad * a.K_pad) + (double)M64 * a.Cout * (out_b + res_b)) * a.batch;
+    const double bytes = (2.0 * ((double)a.N * a.H * a.W * (a.in_ld > 0 ? a.in_ld : a.Cin) + (double)a.Cout_pad * a.K_pad) + (double)M64 * a.Cout * (out_b + res_b)) * a.batch;
     omgsr::TimingScope ts(OMGSR_TK_IGEMM, flops, bytes, st, M64 * a.batch, logical_cols, (long long)a.R * a.S * a.Cin);
     // Tile choice: the 128x128 tile is the MFMA-efficient default; narrow outputs use 128x32 so
     // padded columns do not burn MFMA cycles; small problems drop to 64x64 to fill the 256 CUs.
-    const int64_t tiles128 = ((M64 + 127) / 128) * (a.Cout_pad / 128) * a.batch;
+    // batch-invariant mode: every kernel-family decision below looks at ONE sample's rows (policy_view), like use_halo / splitk_plan
+    const omgsr_igemm_args pv = policy_view(a);
+    const int64_t Mp = omgsr::g_batch_invariant ? (int64_t)pv.N * pv.Ho * pv.Wo : M64;
+    const int64_t pbatch = omgsr::g_batch_invariant ? 1 : a.batch;
+    const int64_t tiles128 = ((Mp + 127) / 128) * (a.Cout_pad / 128) * pbatch;
     // Large problems: LDS-DMA kernel (256x128 tile, 3-stage ring). OMGSR_IGEMM_MODE=reg|dma overrides (A/B runs).
     static const char* mode = getenv("OMGSR_IGEMM_MODE");
-    const int64_t tiles256 = ((M64 + 255) / 256) * ((logical_cols + 127) / 128) * a.batch;
+    const int64_t tiles256 = ((Mp + 255) / 256) * ((logical_cols + 127) / 128) * pbatch;
     g.splits = 1; g.nk_total = g.nk;
     if (a.workspace && !(mode && (!strcmp(mode, "reg") || !strcmp(mode, "halo")))) {
         const int splits = splitk_plan(a, M64);
@@ -412,7 +423,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
                     a.N, a.H, a.W, a.Cin, a.Cout, a.stride, a.pad_top, a.pad_left, a.upsample, a.Ho, a.Wo, a.weight_cm != nullptr, a.batch, a.act, a.out_layout,
                     omgsr::igemm_halo_tiles(a));
     }
-    const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0;   // the DMA kernel's K-steps never straddle taps
+    const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0 && (a.in_ld % 32) == 0;   // the DMA kernel's K-steps never straddle taps (or the wrap point)
     if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192))) {
         static const char* p8 = getenv("OMGSR_P8");               // A/B runs: "0" = never use the ping-pong GEMM kernel
         if (!(p8 && p8[0] == '0') && !omgsr::g_batch_invariant && omgsr::igemm_p8_wanted(a, g)) {

@@ -128,6 +128,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void igemm_dma_kernel(const omgs
     const unsigned char* a_ptr[APW];
     int a_inc[APW];
     const int steps_per_tap = p.Cin / BK;
+    const int ild = p.in_ld > 0 ? p.in_ld : p.Cin;   // physical channels per pixel row
+    const int wrap_at = ild / BK;                    // K-steps of a tap at / past this one re-read the row from its start (w_lo segment)
     int kin = ks0 % steps_per_tap;           // wave-uniform cursor of the NEXT step to issue
     int tap_r = (ks0 / steps_per_tap) / p.S, tap_s = (ks0 / steps_per_tap) % p.S;
     bool fresh = true;                       // the first issue of a split may start in the middle of a tap
@@ -140,11 +142,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void igemm_dma_kernel(const omgs
                 const bool ok = a_img[i] >= 0 && (unsigned)vy < (unsigned)g.Hv && (unsigned)vx < (unsigned)g.Wv;
                 const int iy = vy >> p.upsample, ix = vx >> p.upsample;
                 const int64_t pix = ((int64_t)a_img[i] * p.H + iy) * p.W + ix;
-                a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * p.Cin + kc * 8 + kin * BK)
+                a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * ild + kc * 8 + (kin >= wrap_at ? kin - wrap_at : kin) * BK)
                               : reinterpret_cast<const unsigned char*>(g_zero_page);
                 a_inc[i] = ok ? BK * 2 : 0;
             }
             fresh = false;
+        } else if (kin == wrap_at) {
+#pragma unroll
+            for (int i = 0; i < APW; ++i) a_ptr[i] -= (int64_t)a_inc[i] * wrap_at;
         }
         const unsigned sa = lds_base + stage * STAGE_BYTES + (16 * wave * APW) * 64;
         const unsigned sb = lds_base + stage * STAGE_BYTES + A_BYTES + (16 * wave * BPW) * 64;

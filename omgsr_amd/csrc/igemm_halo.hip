@@ -82,6 +82,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     // A patch pieces: piece j = wave*6 + i covers patch rows [16j, 16j+16); patch row -> (py, px)
     const unsigned char* a_ptr[APW];
     int a_inc[APW];
+    const int ild = p.in_ld > 0 ? p.in_ld : p.Cin;      // physical channels per pixel row
+    const int wrap_at = ild / 32;                       // chunk index at which the patch pointer returns to channel 0 (w_lo segment)
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
         const int pr = 16 * (wave * APW + i) + lrow;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
         const bool ok = (wave * APW + i) < APIECES && pr < PROWS && (unsigned)vy < (unsigned)p.Ho && (unsigned)vx < (unsigned)p.Wo;
         const int iy = vy >> p.upsample, ix = vx >> p.upsample;
         const int64_t pix = ((int64_t)img * p.H + iy) * p.W + ix;
-        a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * p.Cin + kc * 8)
+        a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * ild + kc * 8)
                       : reinterpret_cast<const unsigned char*>(g_zero_page_h);
         a_inc[i] = ok ? 64 : 0;
     }
@@ -103,7 +105,11 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
                        : reinterpret_cast<const unsigned char*>(g_zero_page_h);
     const int64_t b_step = (int64_t)p.Cout_pad * 64;       // bytes between consecutive (chunk, tap) slices
 
-    auto issue_a = [&](int buf) {
+    auto issue_a = [&](int buf, const int chunk) {
+        if (chunk == wrap_at) {
+#pragma unroll
+            for (int i = 0; i < APW; ++i) a_ptr[i] -= (int64_t)a_inc[i] * wrap_at;
+        }
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const int piece = wave * APW + i;
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
         }
 
     if constexpr (ABL != 2) {
-        issue_a(0);
+        issue_a(0, 0);
         issue_b(0);
         issue_b(1);
     }
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
         constexpr bool LATE = (ABL == 0) && !PRIO && !NARROW;
         auto issue_dma = [&]() {
             if constexpr (ABL != 2) {
-                if constexpr (tap == 0) { if (cc + 1 < ncc) issue_a(par ^ 1); }
+                if constexpr (tap == 0) { if (cc + 1 < ncc) issue_a(par ^ 1, cc + 1); }
                 if (s + 2 < nsteps) issue_b((tap + 2) % NB);
             }
         };

@@ -70,6 +70,8 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const omgsr_igemm_args
     typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
     const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;
     const int nkt = p.Cin / BK;                        // even, >= 2 (igemm_p8_ok)
+    const int ild = p.in_ld > 0 ? p.in_ld : p.Cin;     // physical channels per operand row
+    const int wrap_at = ild / BK;                      // K-tiles at / past this one re-read the operand row from its start (w_lo segment)
 
     // ---- prefetch coordinates: piece j (0, 1) of wave w covers rows 16 w + 8 j .. + 7 of a half-tile ----------------------
     unsigned aoff[2][2], boff[2][2];                   // [half-tile][piece]: byte offsets off abase / bbase (k-tile 0)
@@ -81,14 +83,14 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const omgsr_igemm_args
             const int chunk = (lane & 7) ^ ((4 * j + (lane >> 4)) & 7);          // (rl >> 1) & 7 == (4 j + (lane >> 4)) & 7
             int m = m0 + 128 * h + rl;
             if (m > g.M - 1) m = g.M - 1;                                         // rows past M: any valid row, the epilogue drops them
-            aoff[h][j] = (unsigned)(((int64_t)m * p.Cin + chunk * 8) * 2);
+            aoff[h][j] = (unsigned)(((int64_t)m * ild + chunk * 8) * 2);
             boff[h][j] = (unsigned)(((int64_t)(n0 + 128 * h + rl) * p.K_pad + chunk * 8) * 2);
         }
     // slot: 0, 1 = A half-tiles, 2, 3 = B half-tiles; kt past the end -> the dummy KiB (count stays 2 pieces per phase)
     auto stage = [&](const int buf, const int slot, const int kt) {
         const bool real = kt < nkt;
         const int k = real ? kt : nkt - 1;
-        const unsigned char* sb = (slot < 2 ? abase : bbase) + (int64_t)k * (BK * 2);
+        const unsigned char* sb = slot < 2 ? abase + (int64_t)(k >= wrap_at ? k - wrap_at : k) * (BK * 2) : bbase + (int64_t)k * (BK * 2);
         const unsigned dst = lds_base + buf * BUF_BYTES + slot * HALF_BYTES + (2 * wave) * 1024;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -201,7 +203,7 @@ namespace omgsr {
 bool igemm_p8_ok(const omgsr_igemm_args& a, const IgemmGeo& g) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     return a.R == 1 && a.S == 1 && a.stride == 1 && a.pad_top == 0 && a.pad_left == 0 && a.upsample == 0 && a.Ho == a.H && a.Wo == a.W &&
-           a.K_pad == a.Cin && (a.Cin % (2 * BK)) == 0 && (a.Cout_pad % BN) == 0 && logical_cols >= BN && g.splits == 1 &&
+           a.K_pad == a.Cin && (a.Cin % (2 * BK)) == 0 && (a.in_ld == 0 || (a.in_ld % BK) == 0) && (a.Cout_pad % BN) == 0 && logical_cols >= BN && g.splits == 1 &&
            (int64_t)g.M * a.Cin * 2 < (1ll << 32) && (int64_t)a.Cout_pad * a.K_pad * 2 < (1ll << 32);
 }
 // ... and worth it: enough 256 x 256 tiles to fill the chip, no more padded columns than the 128-wide grid would compute

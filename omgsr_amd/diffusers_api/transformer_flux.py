@@ -63,9 +63,9 @@ class FluxAttention(nn.Module, _Cached):
 
     def qk_packed(self, ctx: bool = False) -> ops.PackedWeight:
         q, k = (self.add_q_proj, self.add_k_proj) if ctx else (self.to_q, self.to_k)
-        sp = q.in_split()
+        sp, wsp = q.in_split(), q.in_wsplit()
         return self._cache("qk_ctx" if ctx else "qk", lambda: ops.pack_linear_weight(
-            torch.cat([q.weight, k.weight], 0), torch.cat([q.bias, k.bias], 0), split=sp), q.weight, k.weight, q.bias, k.bias, sp)
+            torch.cat([q.weight, k.weight], 0), torch.cat([q.bias, k.bias], 0), split=sp, w_split=wsp), q.weight, k.weight, q.bias, k.bias, sp, wsp)
 
     def norm_table(self, ctx: bool = False) -> torch.Tensor:
         nq, nk = (self.norm_added_q, self.norm_added_k) if ctx else (self.norm_q, self.norm_k)
@@ -293,7 +293,7 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
         return self._ctx_cache.get((ehs,), self._ctx_key(), build)
 
     def _ctx_key(self) -> tuple:
-        return _key(self.context_embedder.weight, self.context_embedder.bias, self.context_embedder.in_split())
+        return _key(self.context_embedder.weight, self.context_embedder.bias, self.context_embedder.in_split(), self.context_embedder.in_wsplit())
 
     # ---- token executor --------------------------------------------------------------------
     def tokens(self, x_tok: torch.Tensor, timestep, guidance, pooled, ehs, txt_ids, img_ids) -> torch.Tensor:

@@ -82,11 +82,11 @@ class Attention(nn.Module):
         return self.to_q.in_split()
 
     def _qk_packed(self):
-        sp = self.in_split()
+        sp, wsp = self.in_split(), self.to_q.in_wsplit()
 
         def build():
-            return ops.pack_linear_weight(torch.cat([self.to_q.weight, self.to_k.weight], dim=0), None, split=sp)
-        k = _key(self.to_q.weight, self.to_k.weight, sp)
+            return ops.pack_linear_weight(torch.cat([self.to_q.weight, self.to_k.weight], dim=0), None, split=sp, w_split=wsp)
+        k = _key(self.to_q.weight, self.to_k.weight, sp, wsp)
         if getattr(self, "_qk_key", None) != k:
             self._qk, self._qk_key = build(), k
         return self._qk
@@ -111,7 +111,7 @@ class Attention(nn.Module):
         return self._ctx_cache.get((ehs,), self._ctx_key(), build)
 
     def _ctx_key(self) -> tuple:
-        return _key(self.to_k.weight, self.to_v.weight, self.to_k.in_split())
+        return _key(self.to_k.weight, self.to_v.weight, self.to_k.in_split(), self.to_k.in_wsplit(), self.to_v.in_wsplit())
 
     def cross_nhwc(self, xn: torch.Tensor, ehs: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         kk, vt, Lk = self.context(ehs)
@@ -126,10 +126,10 @@ class GEGLU(nn.Module):
         self.proj = Linear(dim_in, dim_out * 2)
 
     def packed(self):
-        sp = self.proj.in_split()
-        k = _key(self.proj.weight, self.proj.bias, sp)
+        sp, wsp = self.proj.in_split(), self.proj.in_wsplit()
+        k = _key(self.proj.weight, self.proj.bias, sp, wsp)
         if getattr(self, "_pk_key", None) != k:
-            self._pk, self._pk_key = ops.pack_geglu_weight(self.proj.weight, self.proj.bias, split=sp), k
+            self._pk, self._pk_key = ops.pack_geglu_weight(self.proj.weight, self.proj.bias, split=sp, w_split=wsp), k
         return self._pk
 
 

@@ -35,6 +35,17 @@ def init(backend: str | None = None) -> Tuple[int, int, int]:
     return rank, local_rank, world
 
 
+def world_size_seen() -> int:
+    """Ranks that actually answer on the process group: an all-reduce of 1 over RCCL (1 without a group). bench.py prints it as
+    `n_ranks_seen` next to the launcher's WORLD_SIZE."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    one = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(one.item())
+
+
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous split of `total` images over `world` ranks (first `total % world` ranks get one more)."""
     base, rem = divmod(total, world)

@@ -11,6 +11,7 @@ Packed (KRSC bf16) weights are built lazily and rebuilt if the parameter changes
 """
 from __future__ import annotations
 
+import dataclasses
 from typing import Optional
 
 import torch
@@ -64,6 +65,10 @@ class _Operand:
     """`op_split`: 1, or 2 when this layer's INPUT arrives as a two-term split operand (accurate tier, set per layer by a
     precision policy: omgsr_amd.precision). The producer of the input (norm / cast / GEMM epilogue) asks the consumer."""
     op_split = 1
+    # `w_split`: 1, or 2 when this layer's WEIGHT is carried as the two-term split w_hi + w_lo (accurate tier, fp32 checkpoints whose
+    # values are not 16-bit representable; precision.set_weight_split). Invisible to producers: the operand row is unchanged, the
+    # packed weight gains a [w_lo] K segment that wraps over the operand's (hi) half (ops.pack_conv_weight).
+    w_split = 1
     # accurate tier: this layer's OUTPUT is only ever normalised and fed to the next GEMM (a ResnetBlock's conv1): keep it in the
     # 16-bit compute type instead of the fp32 stream type where the policy says the rounding is affordable (precision.py)
     out_inner16 = False
@@ -71,12 +76,15 @@ class _Operand:
     def in_split(self) -> int:
         return self.op_split if ops.precise() else 1
 
+    def in_wsplit(self) -> int:
+        return self.w_split if ops.precise() else 1
+
 
 class Conv2d(nn.Conv2d, _Packed, _Operand):
     def packed(self) -> ops.PackedWeight:
         # logical Cout widened to a multiple of 8 (zero rows): 3/4-channel heads write 16-byte NHWC rows
-        sp = self.in_split()
-        return self._packed(lambda: ops.pack_conv_weight(self.weight, self.bias, cout_multiple=8, split=sp), self.weight, self.bias, sp)
+        sp, wsp = self.in_split(), self.in_wsplit()
+        return self._packed(lambda: ops.pack_conv_weight(self.weight, self.bias, cout_multiple=8, split=sp, w_split=wsp), self.weight, self.bias, sp, wsp)
 
     def nhwc(self, x, *, pad=None, upsample=False, act=ops.ACT_NONE, residual=None, bias_override=None, stride=None, gn_groups=0,
              out_dtype=ops.OUT_STREAM, out_split=1):
@@ -84,7 +92,7 @@ class Conv2d(nn.Conv2d, _Packed, _Operand):
         out_channels are exact zeros."""
         pw = self.packed()
         if bias_override is not None:
-            pw = ops.PackedWeight(pw.w, bias_override, pw.cout, pw.cin, pw.R, pw.S, w_cm=pw.w_cm, split=pw.split)
+            pw = dataclasses.replace(pw, bias=bias_override)
         p = self.padding[0] if pad is None else pad
         if out_dtype == ops.OUT_STREAM and self.out_inner16 and ops.precise():
             out_dtype = ops.OUT_BF16
@@ -99,8 +107,8 @@ class Conv2d(nn.Conv2d, _Packed, _Operand):
 
 class Linear(nn.Linear, _Packed, _Operand):
     def packed(self) -> ops.PackedWeight:
-        sp = self.in_split()
-        return self._packed(lambda: ops.pack_linear_weight(self.weight, self.bias, split=sp), self.weight, self.bias, sp)
+        sp, wsp = self.in_split(), self.in_wsplit()
+        return self._packed(lambda: ops.pack_linear_weight(self.weight, self.bias, split=sp, w_split=wsp), self.weight, self.bias, sp, wsp)
 
     def nhwc(self, x, *, act=ops.ACT_NONE, residual=None, gate=None, out_dtype=ops.OUT_STREAM, gn_groups=0, out_split=1):
         return ops.linear(x, self.packed(), act=act, residual=residual, gate=gate, out_dtype=out_dtype, gn_groups=gn_groups,

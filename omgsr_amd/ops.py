@@ -74,6 +74,15 @@ def set_batch_invariant(on: bool) -> None:
     check(_lib.load().omgsr_set_batch_invariant(int(bool(on))), "omgsr_set_batch_invariant")
 
 
+STAGE_NONE, STAGE_ENCODE, STAGE_DENOISE, STAGE_DECODE = 0, 1, 2, 3
+
+
+def timing_stage(stage: int) -> None:
+    """Tag the launches that follow for the per-launch timing leg (omgsr_timing_stage): the pipelines mark VAE encode / denoiser /
+    VAE decode so bench.py can report per-stage time and the denoiser-only MFMA fraction. One host-side store; free when timing is off."""
+    _lib.load().omgsr_timing_stage(stage)
+
+
 def compute_dtype_name() -> str:
     return "fp32" if _PRECISE else ("bf16" if _ACT == torch.bfloat16 else "fp16")
 
@@ -143,7 +152,10 @@ class PackedWeight:
     S: int
     geglu: bool = False
     w_cm: Optional[torch.Tensor] = None   # chunk-major second packing (3x3, Cin % 32 == 0): halo-tile kernel
-    split: int = 1     # 2: the input is a two-term split operand; `cin` counts both halves (every input channel packed twice)
+    split: int = 1     # 2: the input is a two-term split operand [hi | lo]: every input channel packed twice ([w | w])
+    w_split: int = 1   # 2: the weight itself is carried as w_hi + w_lo: one more K segment [w_lo] that re-reads the operand's
+                       # first (hi) half - the contraction WRAPS (omgsr_igemm_args.in_ld); `cin` counts every segment
+    in_ld: int = 0     # physical channels of the operand row this weight expects (split * padded Cin); 0 = cin
 
     @property
     def cout_pad(self) -> int:
@@ -153,12 +165,23 @@ class PackedWeight:
     def k_pad(self) -> int:
         return self.w.shape[1]
 
+    @property
+    def row_channels(self) -> int:
+        """Channels of one operand row ([a] or [a_hi | a_lo]); < cin when the weight carries its own low half (w_split 2)."""
+        return self.in_ld or self.cin
+
 
 def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, cout_multiple: int = 1,
-                     split: int = 1) -> PackedWeight:
-    """[Cout, Cin, R, S] (torch conv layout) -> [Cout_pad, roundup(R*S*Cin8, 32)] bf16, k = (r*S+s)*Cin8 + c.
+                     split: int = 1, w_split: int = 1) -> PackedWeight:
+    """[Cout, Cin, R, S] (torch conv layout) -> [Cout_pad, roundup(R*S*Kc, 32)] in the compute type, k = (r*S+s)*Kc + c.
     cout_multiple=8 widens the LOGICAL output to a multiple of 8 channels (zero weights, zero bias) so a
-    3/4-channel conv writes 16-byte rows that the next kernel can consume directly."""
+    3/4-channel conv writes 16-byte rows that the next kernel can consume directly.
+    Per tap the contraction is a K-concatenation of segments of Cin8 channels, Kc = Cin8 * (split + w_split - 1):
+      split 1, w_split 1   [w_hi]                 x [a]            one rounding of a, one of w
+      split 2, w_split 1   [w_hi | w_hi]          x [a_hi | a_lo]  a to 2^-22
+      split 1, w_split 2   [w_hi | w_lo]          x [a] (wraps)    w to 2^-22
+      split 2, w_split 2   [w_hi | w_hi | w_lo]   x [a_hi | a_lo] (the third segment wraps to a_hi): both to 2^-22
+    with w_hi = round(w), w_lo = round(w - w_hi) in the compute type; everything accumulates in ONE fp32 accumulator."""
     cout, cin, R, S = weight.shape
     dev = device or weight.device
     if cout % cout_multiple:
@@ -171,9 +194,15 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
     w = weight.detach().to(device=dev, dtype=torch.float32).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
     if cin8 != cin:
         w = torch.nn.functional.pad(w, (0, cin8 - cin))
-    if split == 2:          # [hi (cin8) | lo (cin8)] operand rows: both halves meet the same weights
-        w = torch.cat([w, w], dim=-1)
-        cin8 *= 2
+    if split not in (1, 2) or w_split not in (1, 2):
+        raise ValueError("split / w_split must be 1 or 2")
+    in_ld = cin8 * split
+    w_hi = w.to(act_dtype()).float()
+    segs = [w_hi] * split           # [hi (cin8) | lo (cin8)] operand rows: both halves meet the same (rounded) weights
+    if w_split == 2:
+        segs.append((w - w_hi).to(act_dtype()).float())      # ... and the operand's hi half meets the weights' low halves
+    w = torch.cat(segs, dim=-1) if len(segs) > 1 else w_hi
+    cin8 = w.shape[-1]
     w = w.reshape(cout, R * S * cin8)
     k_pad = _round_up(w.shape[1], 32)
     cout_pad = _round_up(cout, 256 if cout >= 256 else 128)   # 256-row padding lets the 256x256 GEMM tile run
@@ -185,15 +214,15 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
         # slice-major: [Cin/32][9 taps][Cout_pad][32] - the 128 x 32 weight slice of one (chunk, tap) K-step is one
         # contiguous 8 KB run, so every LDS-DMA wave instruction reads 8 full 128-B lines
         w_cm = out.view(cout_pad, 9, cin8 // 32, 32).permute(2, 1, 0, 3).contiguous()
-    return PackedWeight(out, b, cout, cin8, R, S, w_cm=w_cm, split=split)
+    return PackedWeight(out, b, cout, cin8, R, S, w_cm=w_cm, split=split, w_split=w_split, in_ld=in_ld)
 
 
-def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, split: int = 1) -> PackedWeight:
+def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, split: int = 1, w_split: int = 1) -> PackedWeight:
     """[out, in] -> 1x1 'conv' weight."""
-    return pack_conv_weight(weight[:, :, None, None], bias, device, split=split)
+    return pack_conv_weight(weight[:, :, None, None], bias, device, split=split, w_split=w_split)
 
 
-def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, split: int = 1) -> PackedWeight:
+def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, split: int = 1, w_split: int = 1) -> PackedWeight:
     """GEGLU projection [2*inner, in] (rows [a | gate], diffusers `chunk(2, -1)`) -> rows interleaved in
     blocks of 32: [a_0..31, g_0..31, a_32..63, g_32..63, ...] so one 64-wide wave tile holds both halves."""
     two_inner, cin = weight.shape
@@ -202,7 +231,7 @@ def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device
         raise ValueError("GEGLU inner dim must be a multiple of 32")
     a, g = weight[:inner], weight[inner:]
     w = torch.stack([a.reshape(inner // 32, 32, cin), g.reshape(inner // 32, 32, cin)], dim=1).reshape(two_inner, cin)
-    pw = pack_linear_weight(w, None, device, split=split)
+    pw = pack_linear_weight(w, None, device, split=split, w_split=w_split)
     if bias is not None:
         ba, bg = bias[:inner], bias[inner:]
         b = torch.stack([ba.reshape(-1, 32), bg.reshape(-1, 32)], dim=1).reshape(two_inner)
@@ -240,6 +269,14 @@ def _out_tensor(shape, cout: int, out_dtype: int, out_split: int, device) -> tor
     return torch.empty((*shape, cout * out_split), device=device, dtype=_ACT)
 
 
+def _fill_k(a: IgemmArgs, pw: PackedWeight) -> None:
+    """Contraction geometry of a packed weight: Cin = every K segment of a tap, in_ld = the operand row it wraps over."""
+    a.Cin = pw.cin
+    a.in_ld = pw.row_channels if pw.row_channels != pw.cin else 0
+    a.in_split = int(pw.split == 2)
+    a.w_split = int(pw.w_split == 2)
+
+
 def _fill_out(a: IgemmArgs, out: torch.Tensor, out_split: int, residual: Optional[torch.Tensor], cout: int) -> None:
     a.out = out.data_ptr()
     a.out_dtype = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
@@ -262,8 +299,8 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
         x = to_operand(x, pw.split)
     _req(x, act_dtype(), "x")
     N, H, W, Cin = x.shape
-    if Cin != pw.cin:
-        raise ValueError(f"conv2d: input has {Cin} channels, packed weight expects {pw.cin}")
+    if Cin != pw.row_channels:
+        raise ValueError(f"conv2d: input has {Cin} channels, packed weight expects {pw.row_channels}")
     if isinstance(pad, int):
         pad = (pad, pad, pad, pad)
     pt, pb, pl, pr = pad
@@ -280,7 +317,8 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     a.in_, a.weight, a.bias, a.gate = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
     _fill_out(a, out, out_split, residual, pw.cout)
     a.weight_cm = _ptr(pw.w_cm)
-    a.N, a.H, a.W, a.Cin = N, H, W, Cin
+    a.N, a.H, a.W = N, H, W
+    _fill_k(a, pw)
     a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
     a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = pw.R, pw.S, stride, pt, pl, int(upsample)
     a.Ho, a.Wo = Ho, Wo
@@ -289,7 +327,6 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     a.out_ld = out.shape[-1] if out_split == 2 else 0
     a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
     a.alpha = alpha
-    a.in_split = int(pw.split == 2)
     a.sample_rows = sample_rows or Ho * Wo
     partial = None
     if gn_groups > 0 and out_split == 1:
@@ -347,7 +384,7 @@ def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int,
     Bz = out.shape[0] if out.dim() == 3 else 1
     M, K = x.numel() // x.shape[-1] // Bz, x.shape[-1]
     ld, nrows = out.shape[-1], out.shape[-2]
-    if K != pw.cin or out.dim() not in (2, 3) or row0 + M > nrows or col0 + pw.cout > ld or (col0 & 7):
+    if K != pw.row_channels or out.dim() not in (2, 3) or row0 + M > nrows or col0 + pw.cout > ld or (col0 & 7):
         raise ValueError("linear_into: slice does not fit")
     if residual is not None and (Bz != 1 or residual.numel() != M * pw.cout):
         raise ValueError("linear_into: residual must be a dense [M, Cout] (unbatched call)")
@@ -361,7 +398,8 @@ def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int,
             raise ValueError("linear_into: the low halves do not fit the row")
     if residual is not None:
         a.residual, a.res_el = residual.data_ptr(), _el(residual, "residual")
-    a.N, a.H, a.W, a.Cin = 1, 1, M, K
+    a.N, a.H, a.W = 1, 1, M
+    _fill_k(a, pw)
     a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
     a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
     a.Ho, a.Wo = 1, M
@@ -369,7 +407,7 @@ def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int,
     a.out_ld = ld
     a.batch, a.alpha = Bz, 1.0
     a.in_bstride, a.w_bstride, a.out_bstride = M * K, 0, nrows * ld
-    a.in_split = int(pw.split == 2)
+    a.sample_rows = M
     _igemm(a, x.device, "omgsr_igemm(linear_into)")
 
 
@@ -380,7 +418,7 @@ def linear_rows(x_buf: torch.Tensor, row0: int, rows: int, pw: PackedWeight, *, 
     [B, rows, Cout] stream tensor; residual: dense [B, rows, Cout]."""
     _req(x_buf, act_dtype(), "x_buf")
     B, L, K = x_buf.shape
-    if K != pw.cin or row0 < 0 or row0 + rows > L:
+    if K != pw.row_channels or row0 < 0 or row0 + rows > L:
         raise ValueError("linear_rows: row range / channels do not fit")
     out = _out_tensor((B, rows), pw.cout, out_dtype, 1, x_buf.device)
     if residual is not None and tuple(residual.shape) != (B, rows, pw.cout):
@@ -388,14 +426,15 @@ def linear_rows(x_buf: torch.Tensor, row0: int, rows: int, pw: PackedWeight, *, 
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate = x_buf.data_ptr() + 2 * row0 * K, pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
     _fill_out(a, out, 1, residual, pw.cout)
-    a.N, a.H, a.W, a.Cin = 1, 1, rows, K
+    a.N, a.H, a.W = 1, 1, rows
+    _fill_k(a, pw)
     a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
     a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
     a.Ho, a.Wo = 1, rows
     a.act, a.out_layout = act, LAYOUT_NHWC
     a.batch, a.alpha = B, 1.0
     a.in_bstride, a.w_bstride, a.out_bstride = L * K, 0, rows * pw.cout
-    a.in_split = int(pw.split == 2)
+    a.sample_rows = rows
     check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_rows)")
     return out
 
@@ -409,11 +448,12 @@ def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: 
     # out_t [Cout, ld], or [B, Cout, ld] with x [B, L, K] (grid.z = B)
     Bz = out_t.shape[0] if out_t.dim() == 3 else 1
     L, K = x.numel() // x.shape[-1] // Bz, x.shape[-1]
-    if out_t.dim() not in (2, 3) or out_t.shape[-2] != pw.cout or key0 + L > out_t.shape[-1] or K != pw.cin:
+    if out_t.dim() not in (2, 3) or out_t.shape[-2] != pw.cout or key0 + L > out_t.shape[-1] or K != pw.row_channels:
         raise ValueError("linear_t_into: slice does not fit")
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.out = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), out_t.data_ptr() + 2 * key0
-    a.N, a.H, a.W, a.Cin = 1, 1, L, K
+    a.N, a.H, a.W = 1, 1, L
+    _fill_k(a, pw)
     a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
     a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
     a.Ho, a.Wo = 1, L
@@ -421,7 +461,7 @@ def linear_t_into(x: torch.Tensor, pw: PackedWeight, out_t: torch.Tensor, key0: 
     a.t_rows, a.t_ld = L, out_t.shape[-1]
     a.batch, a.alpha = Bz, 1.0
     a.in_bstride, a.w_bstride, a.out_bstride = L * K, 0, pw.cout * out_t.shape[-1]
-    a.in_split = int(pw.split == 2)
+    a.sample_rows = L
     check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_t_into)")
 
 
@@ -432,14 +472,15 @@ def linear_t(x: torch.Tensor, pw: PackedWeight, rows_per_batch: int, ld: Optiona
         x = to_operand(x, pw.split)
     _req(x, act_dtype(), "x")
     B, L, K = x.shape
-    if L != rows_per_batch or K != pw.cin:
+    if L != rows_per_batch or K != pw.row_channels:
         raise ValueError("linear_t: shape mismatch")
     ld = ld or _round_up(L, 8)
     out = torch.zeros((B, pw.cout, ld), device=x.device, dtype=act_dtype()) if ld != L else \
         torch.empty((B, pw.cout, ld), device=x.device, dtype=act_dtype())
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate, a.residual, a.out = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), None, None, out.data_ptr()
-    a.N, a.H, a.W, a.Cin = 1, 1, B * L, K
+    a.N, a.H, a.W = 1, 1, B * L
+    _fill_k(a, pw)
     a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
     a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
     a.Ho, a.Wo = 1, B * L
@@ -447,7 +488,7 @@ def linear_t(x: torch.Tensor, pw: PackedWeight, rows_per_batch: int, ld: Optiona
     a.t_rows, a.t_ld = L, ld
     a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
     a.alpha = 1.0
-    a.in_split = int(pw.split == 2)
+    a.sample_rows = L
     check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(linear_t)")
     return out
 

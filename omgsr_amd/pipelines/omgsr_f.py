@@ -42,7 +42,7 @@ def prepare_latent_image_ids(height: int, width: int, device, dtype) -> torch.Te
 class OMGSR_F_Infer(torch.nn.Module):
     def __init__(self, flux_path: Optional[str], lora_path: Optional[str], device, weight_dtype=torch.bfloat16,
                  mid_timestep: int = 244, guidance_scale: float = 1.0, vae: Optional[AutoencoderKL] = None,
-                 flux_transformer: Optional[FluxTransformer2DModel] = None, verbose: bool = False):
+                 flux_transformer: Optional[FluxTransformer2DModel] = None, verbose: bool = False, precision_policy=None):
         super().__init__()
         ops.set_compute_dtype(weight_dtype)       # --weight_dtype picks the tier (bf16 | fp16 fast, fp32 accurate: see OMGSR_S_Infer)
         if vae is None:
@@ -68,8 +68,8 @@ class OMGSR_F_Infer(torch.nn.Module):
         self.device = device
         self.verbose = verbose
         if weight_dtype == torch.float32:
-            from ..precision import apply_default_policy
-            apply_default_policy(vae=self.vae, flux=self.flux_transformer)
+            from ..precision import resolve
+            resolve(precision_policy, vae=self.vae, flux=self.flux_transformer)
 
     def _init_tiled_vae(self, encoder_tile_size=256, decoder_tile_size=256, fast_decoder=False, fast_encoder=False,
                         color_fix=False, vae_to_gpu=True):
@@ -95,10 +95,12 @@ class OMGSR_F_Infer(torch.nn.Module):
         sf, sh = float(self.vae.config.scaling_factor), float(self.vae.config.shift_factor)
         C = self.vae.config.latent_channels
         dt = self.t_prev - self.t_curr
+        ops.timing_stage(ops.STAGE_ENCODE)
         moments = self.vae.encode_moments_nhwc(lq_nhwc8)
         post = DiagonalGaussianDistribution(moments, C, self.vae.posterior_noise, ops.stream_dtype())
         z = post.sample_nhwc(shift=sh, scale=sf)                                  # [B,h,w,16]
         _, h, w, _ = z.shape
+        ops.timing_stage(ops.STAGE_DENOISE)
         if h * w <= tile_size * tile_size:
             tok, vel = self._velocity_tokens(z, prompt_embeds, pooled, text_ids, image_ids)
             tok = ops.axpby(tok, vel, 1.0 / sf, dt / sf, sh, 1.0)                  # (x + dt*v)/sf + shift, packed layout
@@ -109,7 +111,10 @@ class OMGSR_F_Infer(torch.nn.Module):
                 return ops.flux_unpack(vel, tile.shape[1], tile.shape[2])
             v = tiled_denoise(z, C, tile_size, tile_overlap, denoise)
             z1 = ops.axpby(z, v, 1.0 / sf, dt / sf, sh, 1.0)
-        return self.vae.decode_nhwc(z1)
+        ops.timing_stage(ops.STAGE_DECODE)
+        img = self.vae.decode_nhwc(z1)
+        ops.timing_stage(ops.STAGE_NONE)
+        return img
 
     @torch.no_grad()
     def forward(self, lq_img, prompt_embeds, pooled_prompt_embeds, text_ids, latent_image_ids, tile_size, tile_overlap):

@@ -24,7 +24,8 @@ from .latent_tiling import tiled_denoise
 
 class OMGSR_S_Infer(torch.nn.Module):
     def __init__(self, sd_path: Optional[str], lora_path: Optional[str], mid_timestep: int, device, weight_dtype=torch.bfloat16,
-                 vae: Optional[AutoencoderKL] = None, unet: Optional[UNet2DConditionModel] = None, verbose: bool = False):
+                 vae: Optional[AutoencoderKL] = None, unet: Optional[UNet2DConditionModel] = None, verbose: bool = False,
+                 precision_policy=None):
         """With `sd_path` the modules are loaded from an HF directory exactly like the reference
         (infer/omgsr_s_infer_model.py:11-25); `vae=` / `unet=` inject already-built modules instead
         (synthetic-weight benchmarks and tests — there are no checkpoints on the GPU box)."""
@@ -48,9 +49,9 @@ class OMGSR_S_Infer(torch.nn.Module):
         self.vae = vae.to(device=device, dtype=weight_dtype).eval()
         self.unet = unet.to(device=device, dtype=weight_dtype).eval()
         self.device = device
-        if weight_dtype == torch.float32:
-            from ..precision import apply_default_policy
-            apply_default_policy(vae=self.vae, unet=self.unet)
+        if weight_dtype == torch.float32:       # which layers carry two-term split operands / weights (omgsr_amd/precision.py)
+            from ..precision import resolve
+            resolve(precision_policy, vae=self.vae, unet=self.unet)
 
     def _init_tiled_vae(self, encoder_tile_size=256, decoder_tile_size=256, fast_decoder=False, fast_encoder=False,
                         color_fix=False, vae_to_gpu=True):
@@ -65,10 +66,12 @@ class OMGSR_S_Infer(torch.nn.Module):
     def sr_nhwc(self, lq_nhwc8: torch.Tensor, prompt_embeds: torch.Tensor, tile_size: int, tile_overlap: int) -> torch.Tensor:
         """lq [B,H,W,8] stream tensor (RGB + zero pad) -> image NHWC [B,H,W,8] stream tensor, UNCLAMPED."""
         sf = float(self.vae.config.scaling_factor)
+        ops.timing_stage(ops.STAGE_ENCODE)
         moments = self.vae.encode_moments_nhwc(lq_nhwc8)
         post = self.vae_posterior(moments)
         z = post.sample_nhwc(shift=0.0, scale=sf)                                   # [B,h,w,8]
         _, h, w, _ = z.shape
+        ops.timing_stage(ops.STAGE_DENOISE)
         if h * w <= tile_size * tile_size:
             if self.verbose:
                 print("[Tiled Latent]: the input size is tiny and unnecessary to tile.")
@@ -82,7 +85,10 @@ class OMGSR_S_Infer(torch.nn.Module):
         s1, s2 = math.sqrt(1.0 - a), math.sqrt(a)
         # (z - s1*eps) / s2 / scaling_factor  in one fused pass
         z0 = ops.axpby(z, eps, 1.0, -s1, 0.0, 1.0 / (s2 * sf))
-        return self.vae.decode_nhwc(z0)
+        ops.timing_stage(ops.STAGE_DECODE)
+        img = self.vae.decode_nhwc(z0)
+        ops.timing_stage(ops.STAGE_NONE)
+        return img
 
     def vae_posterior(self, moments):
         from ..diffusers_api.autoencoder_kl import DiagonalGaussianDistribution

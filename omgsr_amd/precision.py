@@ -43,6 +43,10 @@ FLUX_DEFAULT = [r"^x_embedder$", r"^proj_out$"]
 # policy above): decoder levels at >= 1/2 of the output resolution +1.5 (83 % of the decoder's inner-tensor bytes), the whole
 # decoder +~6, encoder levels at >= 1/2 resolution +11.6, the whole VAE +18. Only the first is taken.
 VAE_INNER16 = [r"^decoder\.up_blocks\.[23]\.resnets\.\d+\.conv1$"]
+# The shipped lists: activation side (two-term split operand) and weight side (two-term split weight) per model. Until the emulator
+# runs with full-mantissa weights say otherwise the weight side mirrors the activation side.
+VAE_ACT, UNET_ACT, FLUX_ACT = VAE_DEFAULT, UNET_DEFAULT, FLUX_DEFAULT
+VAE_W, UNET_W, FLUX_W = VAE_DEFAULT, UNET_DEFAULT, FLUX_DEFAULT
 
 
 def set_operand_split(model: nn.Module, patterns: Iterable[str], split: int = 2) -> int:
@@ -60,6 +64,22 @@ def set_operand_split(model: nn.Module, patterns: Iterable[str], split: int = 2)
     return n
 
 
+def set_weight_split(model: nn.Module, patterns: Iterable[str], split: int = 2) -> int:
+    """Mark the Conv2d / Linear layers whose WEIGHT is carried as the two-term split w_hi + w_lo (one more K segment that wraps
+    over the operand's hi half: +1x the layer's MFMA work, no change to any producer); returns how many were marked."""
+    if split not in (1, 2):
+        raise ValueError("split must be 1 or 2")
+    regs = [re.compile(p) for p in patterns]
+    n = 0
+    for name, m in model.named_modules():
+        if isinstance(m, (Conv2d, Linear)):
+            hit = any(r.search(name) for r in regs)
+            m.w_split = split if hit else 1
+            n += int(hit)
+    check_policy(model)
+    return n
+
+
 def set_inner16(model: nn.Module, patterns: Iterable[str]) -> int:
     """Mark the Conv2d layers whose output stays in the 16-bit compute type in the accurate tier; returns how many."""
     regs = [re.compile(p) for p in patterns]
@@ -71,9 +91,38 @@ def set_inner16(model: nn.Module, patterns: Iterable[str]) -> int:
     return n
 
 
-def check_policy(model: nn.Module) -> None:
-    """Layers that read ONE shared operand must agree on its form: q / k / v (and Flux's proj_mlp) of a self-attention."""
+def policy_fingerprint(model: nn.Module) -> str:
+    """Hash of the per-layer (op_split, w_split, out_inner16) assignment: constants folded under one policy (cross-attention
+    K / V^T, omgsr_amd.constants) are refused under another."""
+    import hashlib
+    h = hashlib.sha256()
     for name, m in model.named_modules():
+        if isinstance(m, (Conv2d, Linear)):
+            h.update(f"{name}:{m.op_split}:{m.w_split}:{int(m.out_inner16)};".encode())
+    return h.hexdigest()[:16]
+
+
+def _same(mods, attr: str, what: str) -> None:
+    vals = {getattr(g, attr) for g in mods}
+    if len(vals) > 1:
+        raise ValueError(f"precision policy: {what} must agree on {attr}, got {sorted(vals)}")
+
+
+def check_policy(model: nn.Module) -> None:
+    """Layers that read ONE shared operand must agree on its form: q / k / v (and Flux's proj_mlp) of a self-attention, Flux's
+    add_q / add_k / add_v projections, and to_out / to_add_out (one attention-output buffer). Layers packed into ONE weight
+    (the fused q | k projections) must also agree on the weight split."""
+    for name, m in model.named_modules():
+        add = [getattr(m, a, None) for a in ("add_q_proj", "add_k_proj", "add_v_proj")]
+        if all(isinstance(g, Linear) for g in add):
+            _same(add, "op_split", f"{name}.add_q_proj / add_k_proj / add_v_proj (one LayerNorm'd context operand)")
+            _same(add[:2], "w_split", f"{name}.add_q_proj / add_k_proj (one fused weight)")
+        outs = [getattr(m, "to_out", None), getattr(m, "to_add_out", None)]
+        if isinstance(outs[1], Linear) and isinstance(outs[0], nn.ModuleList) and isinstance(outs[0][0], Linear):
+            _same([outs[0][0], outs[1]], "op_split", f"{name}.to_out.0 / to_add_out (one attention-output operand)")
+        qk = [getattr(m, a, None) for a in ("to_q", "to_k")]
+        if all(isinstance(g, Linear) for g in qk) and not getattr(m, "is_cross", False):
+            _same(qk, "w_split", f"{name}.to_q / to_k (one fused weight)")
         group = [getattr(m, a, None) for a in ("to_q", "to_k", "to_v")]
         if all(isinstance(g, Linear) for g in group):
             cross = getattr(m, "is_cross", False)
@@ -90,9 +139,44 @@ def check_policy(model: nn.Module) -> None:
 
 def apply_default_policy(vae: Optional[nn.Module] = None, unet: Optional[nn.Module] = None, flux: Optional[nn.Module] = None) -> None:
     if vae is not None:
-        set_operand_split(vae, VAE_DEFAULT)
+        set_operand_split(vae, VAE_ACT)
+        set_weight_split(vae, VAE_W)
         set_inner16(vae, VAE_INNER16)
     if unet is not None:
-        set_operand_split(unet, UNET_DEFAULT)
+        set_operand_split(unet, UNET_ACT)
+        set_weight_split(unet, UNET_W)
     if flux is not None:
-        set_operand_split(flux, FLUX_DEFAULT)
+        set_operand_split(flux, FLUX_ACT)
+        set_weight_split(flux, FLUX_W)
+
+
+def resolve(policy, **models) -> None:
+    """The pipelines' `precision_policy=` argument (accurate tier only): None / "default" = the shipped lists above; "all" = every
+    layer's operand AND weight as two-term splits (3x the MFMA work, the 2^-22 floor: the fallback when a checkpoint's
+    statistics are far from what the shipped lists were sized on); or {"vae" | "unet" | "flux": dict(act=[...], weight=[...],
+    inner16=[...])} with regular expressions over module names. OMGSR_PRECISION_POLICY=all|default overrides None."""
+    import os
+    if policy is None:
+        policy = os.environ.get("OMGSR_PRECISION_POLICY") or "default"
+    if policy == "default":
+        return apply_default_policy(**models)
+    for key, m in models.items():
+        if m is None:
+            continue
+        if policy == "all":
+            apply_policy(m, [r"."], [r"."])
+        elif isinstance(policy, dict):
+            if key in policy:
+                apply_policy(m, **policy[key])
+            else:
+                apply_default_policy(**{key: m})
+        else:
+            raise ValueError(f"precision_policy must be None, 'default', 'all' or a dict, got {policy!r}")
+
+
+def apply_policy(model: nn.Module, act: Iterable[str], weight: Iterable[str] = (), inner16: Iterable[str] = ()) -> None:
+    """An explicit policy for one model (pipelines: `precision_policy=` / the CLI's --precision_policy all): lists of regular
+    expressions over module names; [r"."] splits every layer (activation and weight to 2^-22: 3x the MFMA work)."""
+    set_operand_split(model, list(act))
+    set_weight_split(model, list(weight))
+    set_inner16(model, list(inner16))

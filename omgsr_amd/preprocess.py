@@ -13,6 +13,7 @@ run as HIP kernels (csrc/preprocess.hip, omgsr_resample_u8). Same names / argume
 from __future__ import annotations
 
 import math
+from collections import OrderedDict
 from functools import lru_cache
 from typing import Tuple
 
@@ -81,15 +82,26 @@ def precompute_coeffs(in_size: int, out_size: int, filt: str) -> Tuple[np.ndarra
     return bounds, kk, ksize
 
 
-_dev_tables: dict = {}
+# Device copies of the tap tables: a bounded LRU (a folder of differently sized images - the reference driver's use case - asks for up
+# to six new tables per image; an unbounded dict would pin all of them in HBM for the life of the process). The host-side loop above
+# stays scalar on purpose: Pillow's taps go through libm's sin in float64 and a vectorised sin (numpy dispatches to SIMD kernels whose
+# last ulp differs) would break the bit-exactness the goldens pin; its results are cached per (in, out, filter) too.
+_DEV_TABLES_MAX = 64
+_dev_tables: "OrderedDict[tuple, tuple]" = OrderedDict()
 
 
 def _tables(in_size: int, out_size: int, filt: str, device):
     key = (in_size, out_size, filt, str(device))
-    if key not in _dev_tables:
-        b, k, ks = precompute_coeffs(in_size, out_size, filt)
-        _dev_tables[key] = (torch.from_numpy(b).to(device).contiguous(), torch.from_numpy(k).to(device).contiguous(), ks)
-    return _dev_tables[key]
+    hit = _dev_tables.get(key)
+    if hit is not None:
+        _dev_tables.move_to_end(key)
+        return hit
+    b, k, ks = precompute_coeffs(in_size, out_size, filt)
+    val = (torch.from_numpy(b).to(device).contiguous(), torch.from_numpy(k).to(device).contiguous(), ks)
+    _dev_tables[key] = val
+    while len(_dev_tables) > _DEV_TABLES_MAX:
+        _dev_tables.popitem(last=False)           # the launches that used it are ordered before its free on the same stream
+    return val
 
 
 def _pass(img: torch.Tensor, out_size: int, axis: int, filt: str) -> torch.Tensor:

@@ -13,9 +13,11 @@ import torch.nn as nn
 
 
 @torch.no_grad()
-def seeded_init_(model: nn.Module, seed: int = 0, device=None) -> nn.Module:
-    """Fan-in scaled normal weights, small random biases, norm affines near (1, 0); rounded to bf16 values.
-    Deterministic per parameter NAME (not traversal order), generated on CPU."""
+def seeded_init_(model: nn.Module, seed: int = 0, device=None, rounded: bool = True) -> nn.Module:
+    """Fan-in scaled normal weights, small random biases, norm affines near (1, 0). Deterministic per parameter NAME (not
+    traversal order), generated on CPU. rounded=True: values rounded to bf16-representable ones (every tier then starts from
+    bit-identical parameters); rounded=False: full fp32 mantissas - what a real checkpoint looks like after an fp32 LoRA merge
+    (infer/omgsr_s_infer_model.py:16-23), the case the accurate tier's weight-side split exists for."""
     for name, p in model.named_parameters():
         g = torch.Generator().manual_seed((hash_name(name) + seed) & 0x7FFFFFFF)
         shape = tuple(p.shape)
@@ -28,8 +30,9 @@ def seeded_init_(model: nn.Module, seed: int = 0, device=None) -> nn.Module:
             v = 1.0 + 0.1 * torch.randn(shape, generator=g)
         else:                               # biases
             v = 0.05 * torch.randn(shape, generator=g)
-        v = v.to(torch.bfloat16).to(p.dtype)
-        p.copy_(v.to(p.device))
+        if rounded:
+            v = v.to(torch.bfloat16)
+        p.copy_(v.to(p.dtype).to(p.device))
     return model
 
 

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import re
 import sys
 import time
 
@@ -33,18 +34,35 @@ class Scheme:
     """only: optional set of (stage, kind) pairs whose OPERAND roundings are kept (all others exact) - error budget runs.
     stage in {enc, unet, dec, lat}; kind in {conv, lin, attn, lat}."""
 
-    def __init__(self, operand, inner, stream, only=None, hilo=None, hilo_fn=None):
+    def __init__(self, operand, inner, stream, only=None, hilo=None, hilo_fn=None, names=None, act_split=None, inner16=None):
+        """names / act_split: name-based policy (the product's own form, omgsr_amd/precision.py): names maps id(module) ->
+        (model key, qualified name), act_split maps model key -> list of regular expressions; an operand whose CONSUMER module
+        matches is carried as the two-term split. Operands without a consumer module (latents) count as exact."""
         self.operand, self.inner, self.stream = operand, inner, stream
         self.only, self.hilo, self.hilo_fn = only, hilo or set(), hilo_fn
+        self.names = names
+        self.act_regs = {k: [re.compile(r) for r in v] for k, v in (act_split or {}).items()}
+        self.inner_regs = {k: [re.compile(r) for r in v] for k, v in (inner16 or {}).items()}
         self.stage = "lat"
         self.seen = set()
         self.seen4 = set()
+        self.unnamed = set()
 
     @staticmethod
     def _q(x, dt):
         return x if dt is None else x.to(dt).float()
 
-    def op(self, x, kind="conv", sub=""):
+    def op(self, x, kind="conv", sub="", mod=None):
+        if self.names is not None and kind != "attn":
+            if mod is None:
+                if kind != "lat":
+                    self.unnamed.add((self.stage, kind, sub))
+                return x                     # latent-sized tensors stay fp32 / are split everywhere in the product
+            model, name = self.names[id(mod)]
+            if any(r.search(name) for r in self.act_regs.get(model, ())):
+                hi = self._q(x, self.operand)
+                return hi + self._q(x - hi, self.operand)
+            return self._q(x, self.operand)
         key = (self.stage, kind)
         res = x.shape[-1] if x.dim() == 4 else int(round((x.shape[-2]) ** 0.5))    # spatial side ([B,C,H,W] or [B,L,C] tokens)
         key3 = (self.stage, kind, res)
@@ -58,7 +76,10 @@ class Scheme:
             return hi + self._q(x - hi, self.operand)
         return self._q(x, self.operand)
 
-    def inn(self, x):
+    def inn(self, x, mod=None):
+        if self.names is not None:           # name-based: the PRODUCING conv's output stays 16-bit where the inner16 list says so
+            model, name = self.names[id(mod)]
+            return self._q(x, self.operand) if any(r.search(name) for r in self.inner_regs.get(model, ())) else x
         return self._q(x, self.inner)
 
     def st(self, x):
@@ -66,36 +87,36 @@ class Scheme:
 
 
 def resnet(S: Scheme, r, x, temb=None):
-    a = S.op(F.silu(r.norm1(x)), "conv", "n1")
+    a = S.op(F.silu(r.norm1(x)), "conv", "n1", r.conv1)
     h = r.conv1(a)
     if r.time_emb_proj is not None:
         h = h + r.time_emb_proj(F.silu(temb))[:, :, None, None]
-    h = S.inn(h)
-    b = S.op(F.silu(r.norm2(h)), "conv", "n2")
-    sc = x if r.conv_shortcut is None else r.conv_shortcut(S.op(x, "conv", "sc"))
+    h = S.inn(h, r.conv1)
+    b = S.op(F.silu(r.norm2(h)), "conv", "n2", r.conv2)
+    sc = x if r.conv_shortcut is None else r.conv_shortcut(S.op(x, "conv", "sc", r.conv_shortcut))
     return S.st(sc + r.conv2(b))
 
 
 def attn_unet(S: Scheme, at, n, ctx=None):
-    c = n if ctx is None else S.op(ctx, "lin", "ctx")
+    c = n if ctx is None else S.op(ctx, "lin", "ctx", at.to_k)
     q, k, v = S.op(at.to_q(n), "attn"), S.op(at.to_k(c), "attn"), S.op(at.to_v(c), "attn")
     q, k, v = at._heads(q), at._heads(k), at._heads(v)
     p = S.op((torch.matmul(q, k.transpose(-1, -2)) * at.scale).softmax(dim=-1), "attn")
     o = torch.matmul(p, v).transpose(1, 2).reshape(n.shape[0], -1, at.heads * at.dim_head)
-    return at.to_out[0](S.op(o, "lin", "o"))
+    return at.to_out[0](S.op(o, "lin", "o", at.to_out[0]))
 
 
 def transformer2d(S: Scheme, t, x, ehs):
     B, Cc, H, W = x.shape
-    y = S.op(t.norm(x), "lin", "gn").permute(0, 2, 3, 1).reshape(B, H * W, Cc)
+    y = S.op(t.norm(x), "lin", "gn", t.proj_in).permute(0, 2, 3, 1).reshape(B, H * W, Cc)
     y = S.st(t.proj_in(y))
     for blk in t.transformer_blocks:
-        y = S.st(y + attn_unet(S, blk.attn1, S.op(blk.norm1(y), "lin", "ln1")))
-        y = S.st(y + attn_unet(S, blk.attn2, S.op(blk.norm2(y), "lin", "ln2"), ehs))
-        n = S.op(blk.norm3(y), "lin", "ln3")
+        y = S.st(y + attn_unet(S, blk.attn1, S.op(blk.norm1(y), "lin", "ln1", blk.attn1.to_q)))
+        y = S.st(y + attn_unet(S, blk.attn2, S.op(blk.norm2(y), "lin", "ln2", blk.attn2.to_q), ehs))
+        n = S.op(blk.norm3(y), "lin", "ln3", blk.ff.net[0].proj)
         hg, gate = blk.ff.net[0].proj(n).chunk(2, dim=-1)
-        y = S.st(y + blk.ff.net[2](S.op(hg * F.gelu(gate), "lin", "ffh")))
-    y = t.proj_out(S.op(y, "lin", "y")).reshape(B, H, W, Cc).permute(0, 3, 1, 2)
+        y = S.st(y + blk.ff.net[2](S.op(hg * F.gelu(gate), "lin", "ffh", blk.ff.net[2])))
+    y = t.proj_out(S.op(y, "lin", "y", t.proj_out)).reshape(B, H, W, Cc).permute(0, 3, 1, 2)
     return S.st(y + x)
 
 
@@ -105,7 +126,7 @@ def unet(S: Scheme, u, sample, timestep, ehs):
     emb = u.time_embedding(R.timestep_sinusoid(t, u.config.block_out_channels[0]))
     if ehs.shape[0] != B:
         ehs = ehs.expand(B, -1, -1)
-    h = S.st(u.conv_in(S.op(sample, "lat")))
+    h = S.st(u.conv_in(S.op(sample, "lat", "", u.conv_in)))
     skips = [h]
     for blk in u.down_blocks:
         for j, r in enumerate(blk.resnets):
@@ -114,7 +135,7 @@ def unet(S: Scheme, u, sample, timestep, ehs):
                 h = transformer2d(S, blk.attentions[j], h, ehs)
             skips.append(h)
         if blk.downsamplers is not None:
-            h = S.st(blk.downsamplers[0](S.op(h, "conv", "samp")))
+            h = S.st(blk.downsamplers[0](S.op(h, "conv", "samp", blk.downsamplers[0].conv)))
             skips.append(h)
     m = u.mid_block
     h = resnet(S, m.resnets[0], h, emb)
@@ -127,16 +148,16 @@ def unet(S: Scheme, u, sample, timestep, ehs):
             if blk.attentions is not None:
                 h = transformer2d(S, blk.attentions[j], h, ehs)
         if blk.upsamplers is not None:
-            h = S.st(blk.upsamplers[0](S.op(h, "conv", "samp")))
-    return S.op(u.conv_out(S.op(F.silu(u.conv_norm_out(h)))), "lat")
+            h = S.st(blk.upsamplers[0](S.op(h, "conv", "samp", blk.upsamplers[0].conv)))
+    return S.op(u.conv_out(S.op(F.silu(u.conv_norm_out(h)), "conv", "", u.conv_out)), "lat")
 
 
 def vae_attn(S: Scheme, at, x):
     B, Cc, H, W = x.shape
-    g = S.op(at.group_norm(x.view(B, Cc, H * W)), "lin").transpose(1, 2)
+    g = S.op(at.group_norm(x.view(B, Cc, H * W)), "lin", "", at.to_q).transpose(1, 2)
     q, k, v = S.op(at.to_q(g), "attn"), S.op(at.to_k(g), "attn"), S.op(at.to_v(g), "attn")
     p = S.op((torch.matmul(q, k.transpose(-1, -2)) * at.scale).softmax(dim=-1), "attn")
-    o = at.to_out[0](S.op(torch.matmul(p, v), "lin"))
+    o = at.to_out[0](S.op(torch.matmul(p, v), "lin", "", at.to_out[0]))
     return S.st(o.transpose(-1, -2).reshape(B, Cc, H, W) + x)
 
 
@@ -147,31 +168,31 @@ def vae_mid(S, m, h):
 
 
 def encoder(S: Scheme, e, x):
-    h = S.st(e.conv_in(S.op(x, "lat")))
+    h = S.st(e.conv_in(S.op(x, "lat", "", e.conv_in)))
     for b in e.down_blocks:
         for r in b.resnets:
             h = resnet(S, r, h)
         if b.downsamplers is not None:
-            h = S.st(b.downsamplers[0](S.op(h, "conv", "samp")))
+            h = S.st(b.downsamplers[0](S.op(h, "conv", "samp", b.downsamplers[0].conv)))
     h = vae_mid(S, e.mid_block, h)
-    return S.op(e.conv_out(S.op(F.silu(e.conv_norm_out(h)))), "lat")
+    return e.conv_out(S.op(F.silu(e.conv_norm_out(h)), "conv", "", e.conv_out))
 
 
 def decoder(S: Scheme, d, z):
-    h = S.st(d.conv_in(S.op(z, "lat")))
+    h = S.st(d.conv_in(S.op(z, "lat", "", d.conv_in)))
     h = vae_mid(S, d.mid_block, h)
     for b in d.up_blocks:
         for r in b.resnets:
             h = resnet(S, r, h)
         if b.upsamplers is not None:
-            h = S.st(b.upsamplers[0](S.op(h, "conv", "samp")))
-    return S.op(d.conv_out(S.op(F.silu(d.conv_norm_out(h)))), "lat")
+            h = S.st(b.upsamplers[0](S.op(h, "conv", "samp", b.upsamplers[0].conv)))
+    return S.op(d.conv_out(S.op(F.silu(d.conv_norm_out(h)), "conv", "", d.conv_out)), "lat")
 
 
 def omgsr_s(S: Scheme, vae, u, alpha_t, x, ehs, eps, tile, overlap):
     sf = vae.config.scaling_factor
     S.stage = "enc"
-    m = vae.quant_conv(encoder(S, vae.encoder, x))
+    m = vae.quant_conv(S.op(encoder(S, vae.encoder, x), "lat", "", vae.quant_conv))
     S.stage = "lat"
     mean, logvar = m.chunk(2, dim=1)
     z = S.op((mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * eps) * sf, "lat")
@@ -186,7 +207,7 @@ def omgsr_s(S: Scheme, vae, u, alpha_t, x, ehs, eps, tile, overlap):
     S.stage = "lat"
     z0 = S.op((z - (1 - alpha_t).sqrt() * pred) / alpha_t.sqrt() / sf, "lat")
     S.stage = "dec"
-    return decoder(S, vae.decoder, vae.post_quant_conv(z0)).clamp(-1, 1)
+    return decoder(S, vae.decoder, vae.post_quant_conv(S.op(z0, "lat", "", vae.post_quant_conv))).clamp(-1, 1)
 
 
 def policy_r2_first(stage, kind, res, sub):
@@ -212,6 +233,43 @@ def policy_full_signal(stage, kind, res, sub):
 
 POLICIES = {"r2_first": policy_r2_first, "full_signal": policy_full_signal}
 
+
+# ---- name-based policies (the product's own lists: omgsr_amd/precision.py) with the WEIGHT side emulated too -----------------
+def names_of(vae, u):
+    out = {id(m): ("vae", n) for n, m in vae.named_modules()}
+    out.update({id(m): ("unet", n) for n, m in u.named_modules()})
+    return out
+
+
+@torch.no_grad()
+def weights_as_packed(model, w_split, dt=torch.float16):
+    """A copy of `model` holding the weights the MFMAs see: every Conv2d / Linear weight rounded to `dt`, or, where a w_split
+    pattern matches, its two-term split w_hi + w_lo. The time embedding / time_emb_proj linears are folded in fp32 by the product
+    (constant at fixed t*) and stay exact."""
+    m2 = type(model)(**dict(model.config)).eval()        # (oracle Config objects do not deep-copy)
+    m2.load_state_dict(model.state_dict())
+    regs = [re.compile(r) for r in w_split]
+    for name, mod in m2.named_modules():
+        if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)) and "time_emb" not in name:
+            w = mod.weight.data
+            hi = w.to(dt).float()
+            mod.weight.data = hi + (w - hi).to(dt).float() if any(r.search(name) for r in regs) else hi
+    return m2
+
+
+def named_policies():
+    from omgsr_amd import precision as Pn
+    base = dict(act=dict(vae=Pn.VAE_DEFAULT, unet=Pn.UNET_DEFAULT), inner16=dict(vae=Pn.VAE_INNER16), w=dict(vae=[], unet=[]))
+    out = {"r2": base,
+           "r2_wsame": dict(base, w=dict(vae=Pn.VAE_DEFAULT, unet=Pn.UNET_DEFAULT)),
+           "all_w": dict(base, w=dict(vae=[r"."], unet=[r"."])),
+           "all_aw": dict(act=dict(vae=[r"."], unet=[r"."]), inner16={}, w=dict(vae=[r"."], unet=[r"."]))}
+    for k in ("VAE_ACT", "UNET_ACT", "VAE_W", "UNET_W"):
+        if not hasattr(Pn, k):
+            return out
+    out["shipped"] = dict(act=dict(vae=Pn.VAE_ACT, unet=Pn.UNET_ACT), inner16=dict(vae=Pn.VAE_INNER16), w=dict(vae=Pn.VAE_W, unet=Pn.UNET_W))
+    return out
+
 SCHEMES = {
     "bf16_all": (torch.bfloat16,) * 3,
     "f16_all": (torch.float16,) * 3,
@@ -229,10 +287,16 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--budget-stage", default="unet")
     ap.add_argument("--budget", default="", help="f16 | bf16: per (stage, kind) contribution of the operand roundings")
+    ap.add_argument("--named", default="", help="comma list of name-based policies (named_policies(), or a JSON file of them): activation "
+                                                "AND weight roundings emulated")
+    ap.add_argument("--fp32-weights", action="store_true", help="seeded weights with full fp32 mantissas (not pre-rounded to bf16 values)")
+    ap.add_argument("--wseed", type=int, default=0)
+    ap.add_argument("--xseed", type=int, default=1234)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
-    vae, u = seeded_init_(R.AutoencoderKL(), 101).eval(), seeded_init_(R.UNet2DConditionModel(), 202).eval()
-    x = synthetic_lq(1, a.side, a.side, seed=1234)
+    vae = seeded_init_(R.AutoencoderKL(), 101 + a.wseed, rounded=not a.fp32_weights).eval()
+    u = seeded_init_(R.UNet2DConditionModel(), 202 + a.wseed, rounded=not a.fp32_weights).eval()
+    x = synthetic_lq(1, a.side, a.side, seed=a.xseed)
     eps = torch.randn(1, 4, a.side // 8, a.side // 8, generator=torch.Generator().manual_seed(99))
     ehs = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(4321)).to(torch.bfloat16).float()
     alpha_t = R.DDPMScheduler().alphas_cumprod[273]
@@ -243,6 +307,24 @@ def main():
         print(f"oracle: {time.time() - t0:.1f} s, rms {ref.pow(2).mean().sqrt():.3f}", flush=True)
         same = omgsr_s(Scheme(None, None, None), vae, u, alpha_t, x, ehs, eps, 64, 32)
         print(f"emulator with no rounding vs oracle: rel-L2 {rel_l2(same, ref):.2e}", flush=True)
+        if a.named:
+            import json
+            pols = named_policies()
+            for name in a.named.split(","):
+                if os.path.isfile(name):
+                    pols.update(json.load(open(name)))
+            for name in a.named.split(","):
+                if os.path.isfile(name):
+                    continue
+                pol = pols[name]
+                v2, u2 = weights_as_packed(vae, pol["w"]["vae"]), weights_as_packed(u, pol["w"]["unet"])
+                v2.posterior_noise = eps
+                S = Scheme(torch.float16, None, None, names=names_of(v2, u2), act_split=pol["act"], inner16=pol.get("inner16"))
+                got = omgsr_s(S, v2, u2, alpha_t, x, ehs, eps, 64, 32)
+                e = rel_l2(got, ref)
+                print(f"{name:16s} rel-L2 {e:.3e}  var {e * e * 1e8:.1f}  PSNR {psnr(got, ref):.1f} dB  unnamed operands: {sorted(S.unnamed)}", flush=True)
+                del v2, u2
+            return
         if a.budget.endswith("_subs"):
             dt = torch.float16 if a.budget.startswith("f16") else torch.bfloat16
             probe = Scheme(dt, None, None)

@@ -1,0 +1,92 @@
+"""BASELINE configs[3] at FULL size and FULL depth: OMGSR-F 256 -> 1024 (infer/omgsr_f_infer_model.py:174-212,322-336) —
+the untiled FLUX VAE at 1024^2 (d = 512, N = 16384 mid attention), the 2x2 pack, ONE FluxTransformer2DModel call at
+sigma(t* = 244) with all 19 double + 38 single blocks at FLUX.1-dev width (D 3072, 24 heads x 128, 4096 + 512 tokens), the
+Euler step, unpack, un-scale and decode — against the fp32 CPU oracle.
+
+The oracle's DiT streams its weights block by block (oracle/flux_streamed_ref.py: the resident fp32 model is 48 GB) from the
+product model's own parameters, which are generated ON the GPU with full fp32 mantissas (omgsr_amd.testing.seeded_init_device_:
+nothing is pre-rounded to a 16-bit-representable value), so both sides hold bit-identical weights by construction and the
+accurate tier is measured on weights it has to round itself. One oracle run (~90 TFLOP on the host) serves every comparison:
+the pipeline's image and, through a trace of the oracle's DiT call, the DiT's velocity alone.
+
+Tiers: fp32 = accurate tier at the north-star bar (rel-L2 <= 1e-3, PSNR >= 60 dB); bf16 = the reference's default dtype: the
+module is cast to bf16 (weights rounded to 8-bit mantissas, like `--weight_dtype bf16` does) and compared with the SAME fp32
+oracle, so its bound includes the weight rounding of the tier (stated below, measured 2026-10 on MI355X).
+"""
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+BOUNDS = {          # tier: (pipeline rel-L2, pipeline PSNR dB, DiT-alone rel-L2)
+    "fp32": (1e-3, 60.0, 1e-3),
+    "bf16": (6e-2, 33.0, 6e-2),
+}
+
+
+@pytest.fixture(scope="module")
+def f_case():
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api import FLUX_VAE_CONFIG, FluxTransformer2DModel
+    from omgsr_amd.testing import seeded_init_, seeded_init_device_, synthetic_lq
+    from oracle import diffusers_ref as R
+    from oracle.flux_streamed_ref import StreamedFlux, module_fetcher
+    from oracle.pipeline_ref import OmgsrFRef, prepare_latent_image_ids
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ops.set_compute_dtype(torch.float32)
+    with torch.device("meta"):
+        pf = FluxTransformer2DModel()
+    pf = pf.to_empty(device=DEV)
+    seeded_init_device_(pf, 404)                       # full-mantissa fp32 weights, generated on the GPU
+    ov = seeded_init_(R.AutoencoderKL(**FLUX_VAE_CONFIG), 303, rounded=False).eval()
+    g = torch.Generator().manual_seed(4321)
+    x = synthetic_lq(1, 1024, 1024, seed=1234)
+    eps = torch.randn(1, 16, 128, 128, generator=torch.Generator().manual_seed(99))
+    pe, pooled = torch.randn(1, 512, 4096, generator=g), torch.randn(1, 768, generator=g)
+    tids, iids = torch.zeros(512, 3), prepare_latent_image_ids(64, 64)
+    ov.posterior_noise = eps
+    st = StreamedFlux(module_fetcher(pf))
+    st.trace = []
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = OmgsrFRef(ov, st, 244, 1.0)(x, pe, pooled, tids, iids, 128, 64)
+    print(f"fp32 oracle, OMGSR-F 256->1024 with the full-depth DiT streamed: {time.perf_counter() - t0:.1f} s")
+    tok, vel = st.trace[0]
+    yield dict(flux=pf, vae_sd=ov.state_dict(), x=x, eps=eps, pe=pe, pooled=pooled, tids=tids, iids=iids, ref=ref, tok=tok, vel=vel)
+    ops.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("tier", ["fp32", "bf16"])       # order matters: the bf16 leg casts the shared module in place
+def test_omgsr_f_1024_full_depth_vs_oracle(f_case, tier):
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api import AutoencoderKL, FLUX_VAE_CONFIG
+    from omgsr_amd.pipelines.omgsr_f import OMGSR_F_Infer, get_flux_setting_timesteps
+    from omgsr_amd.testing import psnr, rel_l2
+    c = f_case
+    wd = torch.float32 if tier == "fp32" else torch.bfloat16
+    tol, min_psnr, tol_dit = BOUNDS[tier]
+    try:
+        pv = AutoencoderKL(**FLUX_VAE_CONFIG)
+        pv.load_state_dict(c["vae_sd"])
+        pf = c["flux"]
+        pf.round_timestep_to_weight_dtype = False      # condition on the exact sigma(t*), like the fp32 oracle does
+        pipe = OMGSR_F_Infer(None, None, DEV, wd, 244, 1.0, vae=pv, flux_transformer=pf)
+        pipe.vae.posterior_noise = c["eps"].to(DEV)
+        to = lambda t: t.to(device=DEV, dtype=wd)      # noqa: E731
+        with torch.no_grad():
+            got, _ = pipe(to(c["x"]), to(c["pe"]), to(c["pooled"]), to(c["tids"]), to(c["iids"]), 128, 64)
+            t_curr = get_flux_setting_timesteps()[-(244 + 1)]
+            vel = pipe.flux_transformer(hidden_states=to(c["tok"]), timestep=torch.tensor([t_curr], device=DEV),
+                                        guidance=torch.full((1,), 1.0, device=DEV), pooled_projections=to(c["pooled"]),
+                                        encoder_hidden_states=to(c["pe"]), txt_ids=to(c["tids"]), img_ids=to(c["iids"]), return_dict=False)[0]
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
+    got, vel = got.float().cpu(), vel.float().cpu()
+    e, p, ed = rel_l2(got, c["ref"]), psnr(got, c["ref"]), rel_l2(vel, c["vel"])
+    print(f"OMGSR-F 256->1024, 19+38 blocks, {tier}: pipeline rel-L2 {e:.3e} PSNR {p:.1f} dB; DiT alone rel-L2 {ed:.3e} "
+          f"(bounds {tol:g} / {min_psnr} dB / {tol_dit:g})")
+    assert got.shape == c["ref"].shape and torch.isfinite(got).all() and torch.isfinite(vel).all()
+    assert ed <= tol_dit and e <= tol and p >= min_psnr

@@ -137,3 +137,25 @@ def test_f_forward_tile():
     assert [list(c) for c in flux.calls] == G["f_tile_calls"].tolist()
     torch.testing.assert_close(vae.seen[0], T("f_tile_decoded_latent"), rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(img, T("f_tile_img"), rtol=1e-6, atol=1e-6)
+
+
+def test_streamed_flux_equals_resident():
+    """oracle/flux_streamed_ref.py (one block's weights resident at a time: the full-depth FLUX oracle) == the resident oracle
+    model, bit for bit, on a small configuration."""
+    from omgsr_amd.testing import seeded_init_
+    from oracle import diffusers_ref as R
+    from oracle.flux_streamed_ref import StreamedFlux, module_fetcher
+    cfg = dict(num_layers=2, num_single_layers=3, attention_head_dim=16, num_attention_heads=2, joint_attention_dim=24,
+               pooled_projection_dim=12, in_channels=8, axes_dims_rope=[4, 6, 6])
+    m = seeded_init_(R.FluxTransformer2DModel(**cfg), 5).eval()
+    g = torch.Generator().manual_seed(0)
+    x, pe, pooled = torch.randn(2, 16, 8, generator=g), torch.randn(1, 5, 24, generator=g), torch.randn(1, 12, generator=g)
+    tids, iids = torch.zeros(5, 3), P.prepare_latent_image_ids(4, 4)
+    kw = dict(hidden_states=x, timestep=torch.tensor([0.505]), guidance=torch.ones(2), pooled_projections=pooled,
+              encoder_hidden_states=pe, txt_ids=tids, img_ids=iids, return_dict=False)
+    with torch.no_grad():
+        ref = m(**kw)[0]
+    st = StreamedFlux(module_fetcher(m), **cfg)
+    st.trace = []
+    got = st(**kw)[0]
+    assert torch.equal(got, ref) and len(st.trace) == 1 and torch.equal(st.trace[0][1], ref)

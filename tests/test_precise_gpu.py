@@ -93,6 +93,68 @@ def test_conv_fp32_stream_split_operand_residual(N, H, W, Cin, Cout, k, split):
     assert torch.allclose(var.double().cpu(), r.var(dim=(1, 3), unbiased=False), atol=1e-5, rtol=1e-4)
 
 
+# (N, H, W, Cin, Cout, k): halo-tile conv, register-staged small conv, LDS-DMA GEMM (1x1, many rows), Cin % 32 != 0 (the
+# wrap point falls inside a 32-channel step: register-staged kernel only), split-K (few rows, long K), strided conv
+_WSPLIT_CASES = [(2, 64, 64, 128, 128, 3), (1, 64, 96, 320, 320, 3), (2, 16, 16, 1280, 640, 3), (4, 128, 128, 256, 128, 1),
+                 (1, 64, 64, 8, 320, 3), (1, 24, 24, 48, 96, 3), (3, 24, 24, 512, 8, 3), (1, 8, 8, 1280, 1280, 3)]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k", _WSPLIT_CASES)
+@pytest.mark.parametrize("split,w_split", [(1, 2), (2, 2)])
+def test_conv_weight_split(N, H, W, Cin, Cout, k, split, w_split):
+    """Full-mantissa fp32 weights (what a checkpoint looks like after an fp32 LoRA merge): w_split 2 packs [w_hi | w_lo] (or
+    [w_hi | w_hi | w_lo] against a split operand) and the contraction wraps over the operand row (omgsr_igemm_args.in_ld).
+    With an operand that is exact (fp16-representable input, or the two-term split) only the fp32 accumulation is left: ~1e-6
+    against an fp64 conv; the same weights rounded once to fp16 sit at ~2e-4."""
+    from omgsr_amd import ops
+    x = torch.randn(N, H, W, Cin, generator=_g(8))
+    if split == 1:
+        x = x.to(torch.float16).float()                     # no activation rounding left: isolates the weight side
+    w = torch.randn(Cout, Cin, k, k, generator=_g(9)) * (k * k * Cin) ** -0.5
+    b = 0.1 * torch.randn(Cout, generator=_g(10))
+    res = torch.randn(N, H, W, Cout, generator=_g(11))
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=k // 2).permute(0, 2, 3, 1) + res.double()
+    pw = ops.pack_conv_weight(w, b, device=DEV, cout_multiple=8, split=split, w_split=w_split)
+    assert pw.row_channels == split * Cin and pw.cin == (split + 1) * Cin
+    y = ops.conv2d(x.to(DEV), pw, pad=k // 2, residual=res.to(DEV))
+    assert _rel(y[..., :Cout], ref) < 3e-6
+    pw1 = ops.pack_conv_weight(w, b, device=DEV, cout_multiple=8, split=split, w_split=1)
+    y1 = ops.conv2d(x.to(DEV), pw1, pad=k // 2, residual=res.to(DEV))
+    assert 2e-5 < _rel(y1[..., :Cout], ref) < 4e-4          # one fp16 rounding of every weight
+
+
+@pytest.mark.parametrize("split,w_split", [(1, 2), (2, 2)])
+def test_conv_weight_split_upsample_stride(split, w_split):
+    from omgsr_amd import ops
+    x = torch.randn(2, 48, 48, 256, generator=_g(21))
+    if split == 1:
+        x = x.to(torch.float16).float()
+    w = torch.randn(256, 256, 3, 3, generator=_g(22)) * (9 * 256) ** -0.5
+    pw = ops.pack_conv_weight(w, None, device=DEV, split=split, w_split=w_split)
+    up = ops.conv2d(x.to(DEV), pw, pad=1, upsample=True)
+    ref = F.conv2d(F.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2.0, mode="nearest"), w.double(), padding=1).permute(0, 2, 3, 1)
+    assert _rel(up, ref) < 3e-6
+    dn = ops.conv2d(x.to(DEV), pw, stride=2, pad=(0, 1, 0, 1))
+    ref = F.conv2d(F.pad(x.permute(0, 3, 1, 2).double(), (0, 1, 0, 1)), w.double(), stride=2).permute(0, 2, 3, 1)
+    assert _rel(dn, ref) < 3e-6
+
+
+@pytest.mark.parametrize("M,K,Nn", [(4608, 3072, 3072), (9216, 1536, 512), (300, 320, 1280), (147456, 320, 320)])
+@pytest.mark.parametrize("split,w_split", [(1, 2), (2, 2)])
+def test_linear_weight_split(M, K, Nn, split, w_split):
+    """The GEMM-shaped kernels (ping-pong 256 x 256 for K >= 1536, LDS-DMA 256 x 128, register staged) with a wrapped contraction."""
+    from omgsr_amd import ops
+    x = torch.randn(1, M, K, generator=_g(23))
+    if split == 1:
+        x = x.to(torch.float16).float()
+    w = torch.randn(Nn, K, generator=_g(24)) * K ** -0.5
+    b = 0.1 * torch.randn(Nn, generator=_g(25))
+    pw = ops.pack_linear_weight(w, b, device=DEV, split=split, w_split=w_split)
+    y = ops.linear(x.to(DEV), pw)
+    ref = torch.addmm(b.to(DEV).double(), x[0].to(DEV).double(), w.to(DEV).double().t())[None]
+    assert _rel(y, ref) < 3e-6
+
+
 def test_linear_epilogue_writes_split_operand():
     """A GEMM whose output is the next GEMM's operand (FF hidden, attention output): out_split 2 writes [hi | lo]."""
     from omgsr_amd import ops
