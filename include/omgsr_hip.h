@@ -121,6 +121,14 @@ typedef struct omgsr_igemm_args {
                               holds [w_hi | w_lo] per tap against an operand [a] (Cin = 2C, in_ld = C), or [w_hi | w_hi | w_lo] against a
                               split operand [a_hi | a_lo] (Cin = 3C, in_ld = 2C: a_hi w_hi + a_lo w_hi + a_hi w_lo in one fp32 accumulator) */
     int32_t w_split;       /* 0 | 1: the packed weight carries the extra [w_lo] segment (informational: FLOP accounting) */
+    const void* weight_ph; /* optional (upsample == 1, 3x3 stride 1 pad 1, Cin % 32 == 0): the four PHASE-SUMMED 2 x 2 kernels of the nearest-2x
+                              upsampling conv, slice-major [4 phases (2a + b)][Cin/32][4 taps (2dy + dx)][Cout_pad][32]. Output pixel
+                              (2y + a, 2x + b) reads input rows y - 1 + a + dy and columns x - 1 + b + dx with the 3 x 3 taps that land on the same
+                              input pixel summed: the conv then runs as four 2 x 2 convolutions of the low-res map (4 / 9 of the MFMA work of
+                              gathering nine taps from the virtual high-res map). Same K layout per tap as `weight` (split segments included) | NULL */
+    uint32_t* overflow_flag; /* optional (fp16 compute type only): a device word the epilogue ORs 1 into when a value it writes as a 16-bit
+                              output lies beyond +-65504 (the stores saturate there). The accurate tier's range guard: the pipelines
+                              check it once per call, at the sync the reference's forward() already has | NULL */
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
 /* Batch-invariant dispatch (process-wide, default off). The dispatcher normally picks the kernel family (halo-tile conv vs GEMM-shaped)
@@ -175,15 +183,16 @@ int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, float* mean, f
 /* y = act((x - mean[n,g]) * rstd[n,g] * gamma[c] + beta[c]);  act in {NONE, SILU}. x and y may alias when both are
  * OMGSR_EL_16. x_el: OMGSR_EL_16 | OMGSR_EL_F32; y_el: OMGSR_EL_16 | OMGSR_EL_SPLIT (y is an MFMA operand).
  * y2 (optional, x_el OMGSR_EL_F32 only): a second output, x ITSELF rounded to an operand of kind y2_el (OMGSR_EL_16 |
- * OMGSR_EL_SPLIT) - the input of the ResnetBlock's 1x1 conv_shortcut, cast while the tensor streams by. */
+ * OMGSR_EL_SPLIT) - the input of the ResnetBlock's 1x1 conv_shortcut, cast while the tensor streams by.
+ * overflow_flag (optional, fp16 compute type): ORed with 1 when a y2 value lies beyond +-65504 (omgsr_igemm_args.overflow_flag). */
 int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, int32_t N, int64_t HW, int32_t C,
-                          int32_t G, int32_t act, int32_t x_el, int32_t y_el, void* y2, int32_t y2_el, void* stream);
+                          int32_t G, int32_t act, int32_t x_el, int32_t y_el, void* y2, int32_t y2_el, uint32_t* overflow_flag, void* stream);
 /* Same with `rows` rows of x sharing `stat_rows` rows of statistics: row r uses mean[r % stat_rows] (tile-major tiles). */
 int omgsr_groupnorm_apply_shared(const void* x, void* y, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, int32_t rows, int64_t HW, int32_t C,
                                  int32_t G, int32_t act, int32_t stat_rows, int32_t x_el, int32_t y_el, void* y2, int32_t y2_el,
-                                 void* stream);
+                                 uint32_t* overflow_flag, void* stream);
 
 /*
  * K9/K10 — LayerNorm over the last dim (replaces F.layer_norm and the AdaLN-Zero modulate chain of
@@ -194,7 +203,7 @@ int omgsr_layernorm(const void* x, void* y, const float* a, const float* b, int6
 /* Stream tensor -> MFMA operand: y = x rounded to the compute type (y_el OMGSR_EL_16) or its two-term split
  * (OMGSR_EL_SPLIT); x f32 [rows][C], C % 8 == 0. (Inputs of convs that no norm precedes: up / down-sampling convs,
  * 1x1 shortcuts, conv_in, proj_out, post_quant_conv.) */
-int omgsr_to_operand(const float* x, void* y, int64_t rows, int32_t C, int32_t y_el, void* stream);
+int omgsr_to_operand(const float* x, void* y, int64_t rows, int32_t C, int32_t y_el, uint32_t* overflow_flag, void* stream);
 
 /*
  * K7/K8 — fused softmax(Q K^T * scale) V on MFMA (replaces F.scaled_dot_product_attention).
@@ -317,7 +326,7 @@ int omgsr_timing_reset(void);
 /* Synchronises, then fills up to `cap` entries; returns the number of recorded launches. */
 /* kind: 1 igemm, 2 attention, 3 groupnorm, 4 layernorm, 5 elementwise, 6 softmax. variant (igemm only): which kernel
  * the dispatcher launched - 1 igemm_kernel (register staged), 2 igemm_dma_kernel, 3 igemm_halo_kernel, 4 igemm_dma_kernel
- * split-K + splitk_reduce_kernel. flops / bytes: ALGORITHMIC work of the launch (a two-term split operand's duplicated
+ * split-K + splitk_reduce_kernel, 5 igemm_p8_kernel, 6 igemm_halo_kernel in its phase-decomposed upsampling form. flops / bytes: ALGORITHMIC work of the launch (a two-term split operand's duplicated
  * channels count once). */
 typedef struct omgsr_timing_entry { int32_t kind; float ms; double flops; double bytes; int64_t m, n, k; int32_t variant; int32_t stage; } omgsr_timing_entry;
 int omgsr_timing_collect(omgsr_timing_entry* out, int cap);

@@ -37,7 +37,7 @@ class IgemmArgs(C.Structure):
         ("alpha", C.c_float), ("weight_cm", C.c_void_p), ("workspace", C.c_void_p),
         ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32), ("gn_entries", C.c_int32),
         ("res_el", C.c_int32), ("in_split", C.c_int32), ("sample_rows", C.c_int64), ("out_lo_off", C.c_int32),
-        ("in_ld", C.c_int32), ("w_split", C.c_int32),
+        ("in_ld", C.c_int32), ("w_split", C.c_int32), ("weight_ph", C.c_void_p), ("overflow_flag", C.c_void_p),
     ]
 
 
@@ -83,15 +83,15 @@ SIGNATURES = {
     "omgsr_groupnorm_finalize": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, C.c_double, _F, _P]),
     "omgsr_groupnorm_partial": (C.c_int, [_P, _P, _I, _L, _I, _I, _I, _P]),
     "omgsr_groupnorm_finalize_merged": (C.c_int, [C.POINTER(GnMergeArgs), _P, _P, _P, _I, _I, _F, _P]),
-    "omgsr_groupnorm_apply_shared": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "omgsr_groupnorm_apply_shared": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "omgsr_image_to_model_input": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "omgsr_colorfix_workspace_bytes": (C.c_int64, [_I, _I, _I, _I]),
     "omgsr_colorfix": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "omgsr_groupnorm_nchunk": (C.c_int, [_L]),
     "omgsr_groupnorm_stats": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P]),
-    "omgsr_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "omgsr_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "omgsr_layernorm": (C.c_int, [_P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
-    "omgsr_to_operand": (C.c_int, [_P, _P, _L, _I, _I, _P]),
+    "omgsr_to_operand": (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
     "omgsr_attention": (C.c_int, [C.POINTER(AttnArgs), _P]),
     "omgsr_softmax_rows": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "omgsr_rmsnorm_rope": (C.c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _I, _F, _P]),

@@ -4,6 +4,7 @@
 #include "../../include/omgsr_hip.h"
 #include "timing.hip.h"
 #include <string.h>
+#include <type_traits>
 
 namespace omgsr {
 TimingState& timing_state() { static TimingState s; return s; }
@@ -63,15 +64,24 @@ __global__ void copy_channels_kernel(const u32x4_t* __restrict__ src, u32x4_t* _
 
 // stream (fp32) -> operand (compute type, plain or two-term split [hi | lo])
 template <typename T, int YEL>
-__global__ void to_operand_kernel(const float* __restrict__ x, void* __restrict__ y, int64_t rows, int C) {
+__global__ void to_operand_kernel(const float* __restrict__ x, void* __restrict__ y, int64_t rows, int C, unsigned* __restrict__ ovf) {
     const int ng = C >> 3;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * ng) return;
-    const int g = (int)(i % ng);
-    const int64_t r = i / ng;
-    float f[8];
-    load8<T, true>(x, r * C + g * 8, f);
-    store8<T, YEL>(y, r * (YEL == 2 ? 2 * C : C) + g * 8, C, f);
+    float amax = 0.0f;
+    if (i < rows * ng) {
+        const int g = (int)(i % ng);
+        const int64_t r = i / ng;
+        float f[8];
+        load8<T, true>(x, r * C + g * 8, f);
+        store8<T, YEL>(y, r * (YEL == 2 ? 2 * C : C) + g * 8, C, f);
+        if constexpr (std::is_same<T, f16_t>::value) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+        }
+    }
+    if constexpr (std::is_same<T, f16_t>::value) {           // fp16 range guard (see omgsr_igemm_args.overflow_flag)
+        if (ovf && __any(amax > 65504.0f) && (threadIdx.x & 63) == 0) atomicOr(ovf, 1u);
+    }
 }
 
 // z = ((mu + exp(0.5*clamp(logvar,-30,20)) * eps) - shift) * scale, fp32 math, one rounding.
@@ -252,13 +262,13 @@ extern "C" int omgsr_copy_channels(const void* src, void* dst, int64_t rows, int
     return (int)hipGetLastError();
 }
 
-extern "C" int omgsr_to_operand(const float* x, void* y, int64_t rows, int32_t C, int32_t y_el, void* stream) {
+extern "C" int omgsr_to_operand(const float* x, void* y, int64_t rows, int32_t C, int32_t y_el, uint32_t* overflow_flag, void* stream) {
     if (!x || !y || rows <= 0 || C <= 0 || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT)) return OMGSR_E_BADARG;
     if (C & 7) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, (y_el == OMGSR_EL_SPLIT ? 8.0 : 6.0) * rows * C, st);
-    if (y_el == OMGSR_EL_SPLIT) OMGSR_DISPATCH_T(hipLaunchKernelGGL((to_operand_kernel<T, 2>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C));
-    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((to_operand_kernel<T, 0>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C));
+    if (y_el == OMGSR_EL_SPLIT) OMGSR_DISPATCH_T(hipLaunchKernelGGL((to_operand_kernel<T, 2>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C, overflow_flag));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((to_operand_kernel<T, 0>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C, overflow_flag));
     return (int)hipGetLastError();
 }
 

@@ -26,11 +26,11 @@
 
 namespace omgsr {
 int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
-int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
+int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, bool phase = false);
 bool igemm_p8_wanted(const omgsr_igemm_args& a, const IgemmGeo& g);
 int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
-int igemm_halo_tiles(const omgsr_igemm_args& a);
-int igemm_halo_gn_slots(const omgsr_igemm_args& a);
+int igemm_halo_tiles(const omgsr_igemm_args& a, bool phase = false);
+int igemm_halo_gn_slots(const omgsr_igemm_args& a, bool phase = false);
 }
 
 namespace omgsr { static int g_batch_invariant = 0; }
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
 }
 
 bool use_halo(const omgsr_igemm_args& a);
+bool use_halo_phase(const omgsr_igemm_args& a);
 
 // Split-K policy: small-M problems whose 256x128 tiles cannot fill the 256 CUs but whose contraction is long.
 int splitk_plan(const omgsr_igemm_args& a_real, int64_t M64) {
@@ -266,7 +267,7 @@ int splitk_plan(const omgsr_igemm_args& a_real, int64_t M64) {
     if (omgsr::g_batch_invariant) M64 = (int64_t)a.N * a.Ho * a.Wo;
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || (a.in_ld % 32) || logical_cols < 96) return 1;
-    if (use_halo(a)) return 1;                  // the halo-tile kernel takes the problem (and owns the fused GroupNorm statistics)
+    if (use_halo(a) || use_halo_phase(a)) return 1;   // the halo-tile kernel takes the problem (and owns the fused GroupNorm statistics)
     const int nk = a.K_pad / 32;
     const int64_t tiles = ((M64 + 255) / 256) * ((logical_cols + 127) / 128);
     const int slots = 512;                                             // two 256 x 128 workgroups per CU
@@ -294,6 +295,21 @@ bool use_halo(const omgsr_igemm_args& a_real) {
     return omgsr::igemm_halo_tiles(a) >= 192;
 }
 
+// Nearest-2x upsampling + 3x3 conv as four 2 x 2 convolutions of the low-res map (weight_ph: phase-summed kernels), 4 / 9 of the MFMA work
+bool use_halo_phase(const omgsr_igemm_args& a_real) {
+    const omgsr_igemm_args a = policy_view(a_real);
+    static const char* off = getenv("OMGSR_UPSAMPLE_PHASES");        // A/B runs: "0" = the gather form (nine taps on the virtual map)
+    static const char* mode = getenv("OMGSR_IGEMM_MODE");
+    if ((off && off[0] == '0') || (mode && (!strcmp(mode, "reg") || !strcmp(mode, "dma")))) return false;
+    const bool ok = a.weight_ph && a.upsample == 1 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 &&
+                    (a.Cin % 32) == 0 && (a.in_ld % 32) == 0 && a.batch == 1 && a.Ho == 2 * a.H && a.Wo == 2 * a.W && a.W >= 16 &&
+                    a.Cout >= 96 && (a.Cout & 7) == 0 && a.act != OMGSR_ACT_GEGLU && a.out_layout == OMGSR_LAYOUT_NHWC && !a.residual;
+    if (!ok) return false;
+    const int padded_w = ((a.W + 31) / 32) * 32;
+    if (padded_w * 3 > a.W * 4) return false;
+    return omgsr::igemm_halo_tiles(a, true) >= 192;
+}
+
 }  // namespace
 
 namespace {
@@ -306,6 +322,11 @@ void gn_plan(const omgsr_igemm_args& a, int* nslot, int* entries) {
     const int64_t ldo = a.out_ld > 0 ? a.out_ld : a.Cout;
     if ((a.Cout & 7) || (ldo & 7) || a.act == OMGSR_ACT_GEGLU || a.out_layout != OMGSR_LAYOUT_NHWC || a.batch != 1) return;   // the epilogue's 16-byte-row fast path
     const int64_t M64 = (int64_t)a.N * a.Ho * a.Wo;
+    if (use_halo_phase(a)) {
+        *nslot = omgsr::igemm_halo_gn_slots(a, true);            // one slot per (wave tile, phase)
+        *entries = pow2 ? a.gn_groups : a.Cout;
+        return;
+    }
     if (use_halo(a)) {
         if (a.Cout < 96) return;                                 // the narrow halo shape does not emit statistics
         *nslot = omgsr::igemm_halo_gn_slots(a);                  // one slot per wave tile (it lies in one image)
@@ -415,6 +436,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         gn_plan(a, &nslot, &entries);
         if (nslot <= 0 || a.gn_entries != entries) return OMGSR_E_BADARG;
     }
+    if (use_halo_phase(a)) { ts.rec.variant = 6; return omgsr::igemm_halo_launch(a, g, st, true); }
     if (use_halo(a)) { ts.rec.variant = 3; return omgsr::igemm_halo_launch(a, g, st); }
     {
         static const char* dbg = getenv("OMGSR_DEBUG_DISPATCH");      // one line per conv-shaped problem that did NOT take the halo kernel

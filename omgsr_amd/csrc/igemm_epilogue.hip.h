@@ -23,7 +23,9 @@ OMGSR_DEVINL void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "me
 template <typename T, int WTN, int FM, int FN, bool RES32>
 OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
                                       const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
-                                      float* gn_dst, const int gn_howo) {
+                                      float* gn_dst, const int gn_howo, const int pxs) {
+    // pxs: distance in output pixels between consecutive rows of a fragment row block (1; 2 when the block is one phase of a
+    // phase-decomposed upsampling conv: its pixels land on every other column). A residual is not supported with pxs != 1.
     constexpr int EPI_LD = WTN + 4;
     static_assert(WTN == FN * 32, "wave tile width");
     const int half = lane >> 5, px = lane & 31;
@@ -40,6 +42,21 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
     const res_t* resb = p.residual ? (const res_t*)p.residual + (int64_t)bz * p.out_bstride : nullptr;
     const int64_t ldo = p.out_ld > 0 ? p.out_ld : p.Cout;
     const bool osplit = p.out_lo_off > 0 && p.out_dtype == OMGSR_OUT_BF16;        // two-term split: lo out_lo_off columns after hi
+    // fp16 range guard: the largest magnitude this lane writes as a 16-bit value; a wave that saw one past 65504 (pack2 saturates
+    // there) ORs 1 into p.overflow_flag so the host can fall back instead of returning a silently clipped result
+    constexpr bool OVF_CHK = std::is_same<T, f16_t>::value;
+    float amax = 0.0f;
+    auto note8 = [&](const float (&v)[8]) {
+        if constexpr (OVF_CHK) {
+            amax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                         fmaxf(fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))), amax));
+        }
+    };
+    auto flush_ovf = [&]() {
+        if constexpr (OVF_CHK) {
+            if (p.overflow_flag && p.out_dtype == OMGSR_OUT_BF16 && __any(amax > 65504.0f) && lane == 0) atomicOr(p.overflow_flag, 1u);
+        }
+    };
     const bool vec_ok = (p.Cout & 7) == 0 && (ldo & 7) == 0;
 
     // a lane's output columns are the same for every row pass: fetch bias / gate ONCE (per-pass scalar
@@ -197,17 +214,19 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
                         for (int e = 0; e < 8; ++e) v[e] += rf[e];
                     }
                     if (row < nvalid[i] && col_ok) {
-                        const int64_t o = (int64_t)(mb[i] + row) * ldo + n_out;
+                        const int64_t o = (int64_t)(mb[i] + row * pxs) * ldo + n_out;
                         if (gn_on) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
                         }
                         if (osplit) {
                             u32x4_t hi, lo;
+                            note8(v);
                             split8<T>(v, hi, lo);
                             *reinterpret_cast<u32x4_t*>(outb + o) = hi;
                             *reinterpret_cast<u32x4_t*>(outb + o + p.out_lo_off) = lo;
                         } else if (p.out_dtype == OMGSR_OUT_BF16) {
+                            note8(v);
                             *reinterpret_cast<u32x4_t*>(outb + o) = pack8<T>(v);
                         } else {
                             *reinterpret_cast<f32x4_t*>(outf + o) = (f32x4_t){v[0], v[1], v[2], v[3]};
@@ -224,6 +243,7 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
                 wave_lds_fence();       // this wave's reads are done before the next row block overwrites the region
             }
             if (gn_dst) gn_flush(gn_dst);
+            flush_ovf();
             return;
         }
     }
@@ -270,11 +290,13 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
                             else if (p.act == OMGSR_ACT_GELU_TANH) x = gelu_tanh_f(x);
                             v[e] = x * gt[ps];
                         }
+                        note8(v);
                         *reinterpret_cast<u32x4_t*>(outb + ((int64_t)blk * p.Cout + n) * p.t_ld + mr0 + g8) = pack8<T>(v);
                     }
                 }
                 wave_lds_fence();
             }
+            flush_ovf();
             return;
         }
     }
@@ -290,7 +312,7 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
         wave_lds_fence();
         for (int rb = 0; rb < 32; rb += rows_per_pass) {
             const int row = rb + lrow;
-            const int m = mb[i] + row;
+            const int m = mb[i] + row * pxs;
             float v[8];
             int n;  // first logical output column of this lane
             if (geglu) {
@@ -322,6 +344,7 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= gate8[e];
             }
+            if (!resb) note8(v);            // (with a residual the stored value is v + r: a 16-bit residual output is a fast-tier form)
             if (p.out_layout == OMGSR_LAYOUT_NHWC) {
                 const int64_t o = (int64_t)m * ldo + n;
                 const int64_t ro = (int64_t)m * p.Cout + n;
@@ -355,14 +378,15 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
         }
         wave_lds_fence();       // this wave's reads are done before the next row block overwrites the region
     }
+    flush_ovf();
 }
 
 template <typename T, int WTN, int FM, int FN>
 OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
                                  const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
-                                 float* gn_dst = nullptr, const int gn_howo = 0) {
-    if (p.res_el == OMGSR_EL_F32 && p.residual) igemm_epilogue_impl<T, WTN, FM, FN, true>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo);
-    else igemm_epilogue_impl<T, WTN, FM, FN, false>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo);
+                                 float* gn_dst = nullptr, const int gn_howo = 0, const int pxs = 1) {
+    if (p.res_el == OMGSR_EL_F32 && p.residual) igemm_epilogue_impl<T, WTN, FM, FN, true>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo, pxs);
+    else igemm_epilogue_impl<T, WTN, FM, FN, false>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo, pxs);
 }
 
 // linear-M helper for the GEMM-shaped kernels: row block i starts at m_base + 32*i

@@ -16,6 +16,12 @@
 //  * 4 waves, 128 x 64 per wave (4 tile rows x 64 couts), one raw s_barrier per K-step, counted vmcnt
 //  * image borders / ragged W,H: patch pixels outside the image come from the zero page, output columns
 //    past W and rows past H are dropped in the epilogue (tiled-VAE tiles are 86, 172, 320 ... wide)
+//  * TAPS = 4: nearest-2x upsampling + 3x3 conv WITHOUT the redundant taps. Output pixel (2y + a, 2x + b) of conv3x3(up2(in)) only
+//    ever sees the 2 x 2 input pixels rows {y - 1 + a, y + a} x cols {x - 1 + b, x + b}: taps that land on the same input pixel
+//    have their weights SUMMED at pack time (phase a = 0: row y - 1 <- w[0], row y <- w[1] + w[2]; a = 1: row y <- w[0] + w[1],
+//    row y + 1 <- w[2]; same along x), so each of the four output phases is a 2 x 2 convolution of the LOW-resolution map: 4 / 9 of
+//    the MFMA work of the gather form. One launch, blockIdx.y = phase; the tile is 8 x 32 low-res pixels whose outputs land at
+//    stride 2 in the high-res map; patch (8+1) x (32+1), weight ring of 4 stages (stage = tap).
 #include "common.hip.h"
 #include "../../include/omgsr_hip.h"
 #include "igemm_epilogue.hip.h"
@@ -24,13 +30,22 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, PROWS = PH * PW;   // 340 patch pixels
-constexpr int APIECES = 22, APW = 6;        // 1-KiB DMA pieces (16 patch rows): 22 real ones; every wave issues 6 so the
-                                            // vmcnt arithmetic is uniform - pieces 22, 23 copy the zero page to a dummy KiB
-constexpr int A_BYTES = APIECES * 1024;
-constexpr int DUMMY_OFF = 2 * A_BYTES, B_OFF = DUMMY_OFF + 2048;
-constexpr int BN = 128, B_BYTES = BN * 64, BPW = 2, NB = 3;       // BN / B_BYTES: the wide shape; the narrow one uses 2 KB of each stage
-constexpr int LDS_BYTES = B_OFF + NB * B_BYTES;                              // 70 KB: two workgroups per CU
+constexpr int TH = 8, TW = 32;
+// Geometry of the two tap sets. 3 x 3: patch (8+2) x (32+2) = 340 pixels = 22 1-KiB DMA pieces (16 patch rows each), every wave
+// issues 6 so the vmcnt arithmetic is uniform (pieces 22, 23 copy the zero page to a dummy KiB), weight ring 3 deep (9 % 3 == 0:
+// stage = tap % 3). 2 x 2 (phase-decomposed upsampling): patch 9 x 33 = 297 pixels = 19 pieces, 5 per wave, ring 4 deep (stage = tap).
+template <int TAPS> struct HaloGeo {
+    static constexpr int KS = TAPS == 9 ? 3 : 2;
+    static constexpr int PW = TW + KS - 1, PH = TH + KS - 1, PROWS = PH * PW;
+    static constexpr int APIECES = (PROWS + 15) / 16, APW = (APIECES + 3) / 4;
+    static constexpr int A_BYTES = APIECES * 1024;
+    static constexpr int NB = TAPS == 9 ? 3 : 4;
+    static constexpr int DUMMY_OFF = 2 * A_BYTES, B_OFF = DUMMY_OFF + 2048;
+    static constexpr int LDS_BYTES = B_OFF + NB * 128 * 64;
+};
+constexpr int BN = 128, B_BYTES = BN * 64, BPW = 2;       // BN / B_BYTES: the wide shape; the narrow one uses 2 KB of each stage
+constexpr int LDS_BYTES = HaloGeo<9>::LDS_BYTES > HaloGeo<4>::LDS_BYTES ? HaloGeo<9>::LDS_BYTES : HaloGeo<4>::LDS_BYTES;   // <= 72 KB: two workgroups per CU
+static_assert(HaloGeo<9>::APIECES == 22 && HaloGeo<9>::APW == 6 && HaloGeo<4>::APIECES == 19 && HaloGeo<4>::APW == 5, "piece counts");
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_h[4] = {0u, 0u, 0u, 0u};
 
@@ -53,9 +68,15 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 // NARROW: Cout <= 32 (the VAE's conv_out, 128 -> 3): the four waves split the 8 tile rows (2 each) over ONE 32-column
 // fragment instead of 2 x 2 waves over 128 columns. The im2col kernels gather every input pixel nine times out of L2
 // (3.2 GB for a 1.4 MPixel x 128-channel map: 350 us, L2-bound at 70 TFLOP/s); here the patch is read once.
-template <typename T, int ABL, bool PRIO, bool NARROW = false>
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     constexpr int WTN = NARROW ? 32 : 64, FM = NARROW ? 2 : 4, FN = NARROW ? 1 : 2, BNK = NARROW ? 32 : 128;
+    using HG = HaloGeo<TAPS>;
+    constexpr int KS = HG::KS, PW = HG::PW, PROWS = HG::PROWS, APIECES = HG::APIECES, APW = HG::APW, A_BYTES = HG::A_BYTES;
+    constexpr int NB = HG::NB, DUMMY_OFF = HG::DUMMY_OFF, B_OFF = HG::B_OFF;
+    constexpr bool PHASE = TAPS == 4;
+    static_assert(!(PHASE && NARROW), "the phase-decomposed form has no narrow shape");
+    const int ph_a = PHASE ? (int)(blockIdx.y >> 1) : 0, ph_b = PHASE ? (int)(blockIdx.y & 1) : 0;    // output phase (row, column parity)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int t = threadIdx.x;
@@ -72,7 +93,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BNK;
 
     const T* __restrict__ in = (const T*)p.in;
-    const T* __restrict__ wt = (const T*)p.weight_cm;
+    // phase form: weight_ph holds the four phase-summed 2 x 2 kernels back to back, [4][Cin/32][4 taps][Cout_pad][32]
+    const T* __restrict__ wt = PHASE ? (const T*)p.weight_ph + (int64_t)blockIdx.y * (p.Cin / 32) * 4 * p.Cout_pad * 32 : (const T*)p.weight_cm;
     typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
     const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;
 
@@ -88,10 +110,11 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     for (int i = 0; i < APW; ++i) {
         const int pr = 16 * (wave * APW + i) + lrow;
         const int py = pr / PW, px = pr - py * PW;
-        // (vy, vx): coordinates in the virtual (optionally nearest-2x upsampled) input = output coordinates
-        const int vy = y0 - 1 + py, vx = x0 - 1 + px;
-        const bool ok = (wave * APW + i) < APIECES && pr < PROWS && (unsigned)vy < (unsigned)p.Ho && (unsigned)vx < (unsigned)p.Wo;
-        const int iy = vy >> p.upsample, ix = vx >> p.upsample;
+        // (vy, vx): coordinates in the virtual (optionally nearest-2x upsampled) input = output coordinates; phase form: the tile
+        // lives on the LOW-res grid and phase (a, b) reads input rows y - 1 + a, y + a (columns likewise)
+        const int vy = y0 - 1 + (PHASE ? ph_a : 0) + py, vx = x0 - 1 + (PHASE ? ph_b : 0) + px;
+        const bool ok = (wave * APW + i) < APIECES && pr < PROWS && (unsigned)vy < (unsigned)(PHASE ? p.H : p.Ho) && (unsigned)vx < (unsigned)(PHASE ? p.W : p.Wo);
+        const int iy = PHASE ? vy : (vy >> p.upsample), ix = PHASE ? vx : (vx >> p.upsample);
         const int64_t pix = ((int64_t)img * p.H + iy) * p.W + ix;
         a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * ild + kc * 8)
                       : reinterpret_cast<const unsigned char*>(g_zero_page_h);
@@ -138,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int ncc = g.nk;                  // 32-channel chunks
-    const int nsteps = ncc * 9;            // >= 9
+    const int nsteps = ncc * TAPS;         // >= TAPS
 
     // The first versions of this loop were instruction-issue bound (profiles/r01_pmc_igemm.md §6: 5.3 VALU +
     // 4.4 SALU per MFMA, mostly LDS address arithmetic and tap bookkeeping). Everything is now static:
@@ -151,12 +174,12 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     const int bsw = (frow >> 2) & 3;
     const int boff0 = (wn * WTN) * 64 + frow * 64 + ((half) ^ bsw) * 16;
     const int boff1 = (wn * WTN) * 64 + frow * 64 + ((2 + half) ^ bsw) * 16;
-    int aoff[9][FM];
+    int aoff[TAPS][FM];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+    for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int row = (FM * wm + i) * PW + frow + (tp / 3) * PW + (tp % 3);
+            const int row = (FM * wm + i) * PW + frow + (tp / KS) * PW + (tp % KS);
             aoff[tp][i] = row * 64 + ((half ^ ((row >> 2) & 3)) << 4);
         }
 
@@ -176,9 +199,10 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
         // the bit-repeatability test; the s_setprio variant pins the MFMAs and never showed it)
         if constexpr (ABL == 2) {
         } else if constexpr (tap == 1) {
-            if (cc + 1 < ncc) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            // the previous step (tap 0) issued the next chunk's patch (APW pieces) and one weight slice (2)
+            if (cc + 1 < ncc) { if constexpr (APW == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        } else if constexpr (tap == 8) {
+        } else if constexpr (tap == TAPS - 1) {
             if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else {
@@ -231,16 +255,18 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto chunk = [&](auto par_c, const int cc) {
-        const int s0 = cc * 9;
+        const int s0 = cc * TAPS;
         step(std::integral_constant<int, 0>{}, par_c, cc, s0 + 0);
         step(std::integral_constant<int, 1>{}, par_c, cc, s0 + 1);
         step(std::integral_constant<int, 2>{}, par_c, cc, s0 + 2);
         step(std::integral_constant<int, 3>{}, par_c, cc, s0 + 3);
-        step(std::integral_constant<int, 4>{}, par_c, cc, s0 + 4);
-        step(std::integral_constant<int, 5>{}, par_c, cc, s0 + 5);
-        step(std::integral_constant<int, 6>{}, par_c, cc, s0 + 6);
-        step(std::integral_constant<int, 7>{}, par_c, cc, s0 + 7);
-        step(std::integral_constant<int, 8>{}, par_c, cc, s0 + 8);
+        if constexpr (TAPS == 9) {
+            step(std::integral_constant<int, 4>{}, par_c, cc, s0 + 4);
+            step(std::integral_constant<int, 5>{}, par_c, cc, s0 + 5);
+            step(std::integral_constant<int, 6>{}, par_c, cc, s0 + 6);
+            step(std::integral_constant<int, 7>{}, par_c, cc, s0 + 7);
+            step(std::integral_constant<int, 8>{}, par_c, cc, s0 + 8);
+        }
     };
     for (int cc = 0; cc < ncc; cc += 2) {
         chunk(std::integral_constant<int, 0>{}, cc);
@@ -248,19 +274,22 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     }
 
     int mb[FM], nv[FM];
-    int colsv = p.Wo - x0; colsv = colsv > TW ? TW : colsv;
+    int colsv = (PHASE ? p.W : p.Wo) - x0; colsv = colsv > TW ? TW : colsv;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int y = y0 + FM * wm + i;
-        mb[i] = (img * p.Ho + y) * p.Wo + x0;
-        nv[i] = (y < p.Ho) ? colsv : 0;
+        // phase form: low-res pixel (y, x0 + j) of phase (a, b) is output pixel (2y + a, 2 (x0 + j) + b): stride 2 along the row
+        mb[i] = PHASE ? (img * p.Ho + 2 * y + ph_a) * p.Wo + 2 * x0 + ph_b : (img * p.Ho + y) * p.Wo + x0;
+        nv[i] = (y < (PHASE ? p.H : p.Ho)) ? colsv : 0;
     }
     if constexpr (ABL == 1) { if (p.alpha != 12345.0f) return; }      // timing experiment: no epilogue (never true at run time)
     {
         float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
         // fused GroupNorm statistics: slot = (spatial tile, upper / lower 4 tile rows), [N][2*tiles][G][2]
-        float* gn_dst = (p.gn_partial && !NARROW) ? p.gn_partial + ((int64_t)(img * per_img + trem) * 2 + wm) * p.gn_entries * 2 : nullptr;
-        igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0, gn_dst);
+        // ... phase form: four launches' worth of slots per spatial tile, [N][tiles][2][4 phases][G][2]
+        const int64_t slot = PHASE ? ((int64_t)(img * per_img + trem) * 2 + wm) * 4 + blockIdx.y : (int64_t)(img * per_img + trem) * 2 + wm;
+        float* gn_dst = (p.gn_partial && !NARROW) ? p.gn_partial + slot * p.gn_entries * 2 : nullptr;
+        igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0, gn_dst, 0, PHASE ? 2 : 1);
     }
 }
 
@@ -275,13 +304,13 @@ static int prio_min_cin() {
     return v;
 }
 
-int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
+int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, const bool phase) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     g.nk = a.Cin / 32;
-    g.tiles_x = (a.Wo + TW - 1) / TW;
-    g.tiles_y = (a.Ho + TH - 1) / TH;
+    g.tiles_x = ((phase ? a.W : a.Wo) + TW - 1) / TW;          // phase form: tiles of the LOW-res map, four phases each
+    g.tiles_y = ((phase ? a.H : a.Ho) + TH - 1) / TH;
     g.ntm = a.N * g.tiles_x * g.tiles_y;
-    const bool narrow = logical_cols <= 32;
+    const bool narrow = logical_cols <= 32 && !phase;
     g.ntn = narrow ? 1 : (logical_cols + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
@@ -297,13 +326,19 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
                              reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, false, true>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, true>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 5, false>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 5, false>)};
+                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 5, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, false, false, 4>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, false, 4>)};
         for (const void* f : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid(g.ntm * g.ntn, 1, 1);
+    dim3 grid(g.ntm * g.ntn, phase ? 4 : 1, 1);
+    if (phase) {
+        OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false, false, 4>), grid, dim3(256), LDS_BYTES, st, a, g));
+        return (int)hipGetLastError();
+    }
     static const char* abl = ablation_env("OMGSR_HALO_ABLATE");      // timing experiments only: results are garbage (needs OMGSR_ABLATION_OK=1)
     static const char* var = getenv("OMGSR_HALO_VARIANT");     // A/B runs: "0" = LDS-DMA issued in front of the step's MFMAs
     if (var && var[0] == '0' && !narrow) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 5, false>), grid, dim3(256), LDS_BYTES, st, a, g));
@@ -315,11 +350,13 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     else OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false>), grid, dim3(256), LDS_BYTES, st, a, g));
     return (int)hipGetLastError();
 }
-int igemm_halo_gn_slots(const omgsr_igemm_args& a) {
+int igemm_halo_gn_slots(const omgsr_igemm_args& a, const bool phase) {
+    if (phase) return 2 * 4 * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     return 2 * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
 }
-int igemm_halo_tiles(const omgsr_igemm_args& a) {
+int igemm_halo_tiles(const omgsr_igemm_args& a, const bool phase) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    if (phase) return a.N * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * ((logical_cols + BN - 1) / BN) * 4;
     return a.N * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH) * ((logical_cols + BN - 1) / BN);
 }
 }  // namespace omgsr

@@ -1,6 +1,7 @@
 // GroupNorm / LayerNorm / row-softmax / RMSNorm+RoPE for gfx950. All HBM-bound: 16-byte loads,
 // fp32 statistics, wave64 shuffles + LDS for reductions.
 #include "common.hip.h"
+#include <type_traits>
 #include "../../include/omgsr_hip.h"
 #include "timing.hip.h"
 #include <stdlib.h>
@@ -171,8 +172,15 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             int64_t HW, int C, int G, int act, int64_t px_per_block, int stat_rows,
-                                                            void* __restrict__ y2 = nullptr) {
+                                                            void* __restrict__ y2 = nullptr, unsigned* __restrict__ ovf = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float gn_lds[];
+    float amax = 0.0f;          // fp16 range guard of the raw cast y2 (see omgsr_igemm_args.overflow_flag)
+    auto note8 = [&](const float (&v)[8]) {
+        if constexpr (Y2EL >= 0 && std::is_same<T, f16_t>::value) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+        }
+    };
     float* sc = gn_lds;
     float* sh = gn_lds + C;
     const int t = threadIdx.x, n = blockIdx.y;
@@ -217,6 +225,7 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
         load8<T, XF32>(x, (pix0 + px) * C + c8 * 8, f);
         load8<T, XF32>(x, (pix0 + pxb) * C + c8b * 8, h);
         if constexpr (Y2EL >= 0) {
+            note8(f); note8(h);
             store8<T, Y2EL>(y2, (pix0 + px) * (Y2EL == 2 ? 2 * C : C) + c8 * 8, C, f);
             store8<T, Y2EL>(y2, (pix0 + pxb) * (Y2EL == 2 ? 2 * C : C) + c8b * 8, C, h);
         }
@@ -230,10 +239,13 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
     for (; i < total; i += 256) {
         float f[8];
         load8<T, XF32>(x, (pix0 + px) * C + c8 * 8, f);
-        if constexpr (Y2EL >= 0) store8<T, Y2EL>(y2, (pix0 + px) * (Y2EL == 2 ? 2 * C : C) + c8 * 8, C, f);
+        if constexpr (Y2EL >= 0) { note8(f); store8<T, Y2EL>(y2, (pix0 + px) * (Y2EL == 2 ? 2 * C : C) + c8 * 8, C, f); }
         transform(f, c8);
         store8<T, YEL>(y, (pix0 + px) * ldy + c8 * 8, C, f);
         advance(c8, px);
+    }
+    if constexpr (Y2EL >= 0 && std::is_same<T, f16_t>::value) {
+        if (ovf && __any(amax > 65504.0f) && (t & 63) == 0) atomicOr(ovf, 1u);
     }
 }
 
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(256) void gn_finalize_merged_kernel(const omgsr_gn_
 namespace {
 int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, int32_t x_el,
-                    int32_t y_el, void* y2, int32_t y2_el, void* stream);
+                    int32_t y_el, void* y2, int32_t y2_el, uint32_t* ovf, void* stream);
 }
 
 extern "C" int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t x_el, void* stream) {
@@ -577,21 +589,22 @@ extern "C" int omgsr_groupnorm_finalize_merged(const omgsr_gn_merge_args* a, flo
 
 extern "C" int omgsr_groupnorm_apply_shared(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                                             const float* beta, int32_t rows, int64_t HW, int32_t C, int32_t G, int32_t act,
-                                            int32_t stat_rows, int32_t x_el, int32_t y_el, void* y2, int32_t y2_el, void* stream) {
+                                            int32_t stat_rows, int32_t x_el, int32_t y_el, void* y2, int32_t y2_el, uint32_t* overflow_flag,
+                                            void* stream) {
     if (stat_rows <= 0 || rows % stat_rows) return OMGSR_E_BADARG;
-    return gn_apply_launch(x, y, mean, rstd, gamma, beta, rows, HW, C, G, act, stat_rows, x_el, y_el, y2, y2_el, stream);
+    return gn_apply_launch(x, y, mean, rstd, gamma, beta, rows, HW, C, G, act, stat_rows, x_el, y_el, y2, y2_el, overflow_flag, stream);
 }
 
 extern "C" int omgsr_groupnorm_apply(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                                      const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act,
-                                     int32_t x_el, int32_t y_el, void* y2, int32_t y2_el, void* stream) {
-    return gn_apply_launch(x, y, mean, rstd, gamma, beta, N, HW, C, G, act, N, x_el, y_el, y2, y2_el, stream);
+                                     int32_t x_el, int32_t y_el, void* y2, int32_t y2_el, uint32_t* overflow_flag, void* stream) {
+    return gn_apply_launch(x, y, mean, rstd, gamma, beta, N, HW, C, G, act, N, x_el, y_el, y2, y2_el, overflow_flag, stream);
 }
 
 namespace {
 int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, int32_t x_el,
-                    int32_t y_el, void* y2, int32_t y2_el, void* stream) {
+                    int32_t y_el, void* y2, int32_t y2_el, uint32_t* ovf, void* stream) {
     if (!x || !y || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
     if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT)) return OMGSR_E_BADARG;
     if (y2 && (x_el != OMGSR_EL_F32 || (y2_el != OMGSR_EL_16 && y2_el != OMGSR_EL_SPLIT))) return OMGSR_E_BADARG;
@@ -608,7 +621,7 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
                                              (y2 ? (y2_el == OMGSR_EL_SPLIT ? 4.0 : 2.0) : 0.0)) * N * (double)HW * C, st);
     const size_t lds = 2 * C * sizeof(float);
     const dim3 grid(nblk, N);
-#define OMGSR_GN_ANY2(YE, Y2) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, true, YE, Y2>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2))
+#define OMGSR_GN_ANY2(YE, Y2) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, true, YE, Y2>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf))
 #define OMGSR_GN_ANY(XF, YE) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, XF, YE>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows))
     if (y2) {
         if (y_el == OMGSR_EL_SPLIT && y2_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY2(2, 2);

@@ -84,6 +84,7 @@ class Upsample2D(nn.Module):
     def __init__(self, channels: int):
         super().__init__()
         self.conv = Conv2d(channels, channels, 3, padding=1)
+        self.conv.phase_upsample = True
 
     def nhwc(self, x, gn_groups: int = 0):
         """gn_groups: groups of the GroupNorm that consumes the result directly (VAE decoder: the next block's norm1)."""

@@ -81,10 +81,15 @@ class _Operand:
 
 
 class Conv2d(nn.Conv2d, _Packed, _Operand):
+    # set by Upsample2D: this 3x3 conv is applied to a nearest-2x upsampled map, so its packed weight also carries the four
+    # phase-summed 2 x 2 kernels (ops.pack_conv_weight upsample_phases) and runs with 4 / 9 of the MFMA work
+    phase_upsample = False
+
     def packed(self) -> ops.PackedWeight:
         # logical Cout widened to a multiple of 8 (zero rows): 3/4-channel heads write 16-byte NHWC rows
-        sp, wsp = self.in_split(), self.in_wsplit()
-        return self._packed(lambda: ops.pack_conv_weight(self.weight, self.bias, cout_multiple=8, split=sp, w_split=wsp), self.weight, self.bias, sp, wsp)
+        sp, wsp, ph = self.in_split(), self.in_wsplit(), self.phase_upsample
+        return self._packed(lambda: ops.pack_conv_weight(self.weight, self.bias, cout_multiple=8, split=sp, w_split=wsp, upsample_phases=ph),
+                            self.weight, self.bias, sp, wsp, ph)
 
     def nhwc(self, x, *, pad=None, upsample=False, act=ops.ACT_NONE, residual=None, bias_override=None, stride=None, gn_groups=0,
              out_dtype=ops.OUT_STREAM, out_split=1):

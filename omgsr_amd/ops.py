@@ -52,20 +52,60 @@ def mode_key() -> tuple:
     return (_ACT, _PRECISE)
 
 
-def set_compute_dtype(dtype: torch.dtype) -> None:
+def set_compute_dtype(dtype: torch.dtype, operand_dtype: Optional[torch.dtype] = None) -> None:
     """Process-wide tier switch; packed-weight caches are keyed on it and rebuild lazily. Mirrors the reference's
     --weight_dtype (infer/infer_omgsr_s.py:134-149):
       bf16 / fp16  fast tiers: operands AND stream tensors in that 16-bit type (omgsr_set_compute_dtype)
       fp32         accurate tier: fp32 stream tensors, fp16 MFMA operands with fp32 accumulation, two-term split
-                   operands on the layers a precision policy names (omgsr_amd.precision)"""
+                   operands / weights on the layers a precision policy names (omgsr_amd.precision)
+    operand_dtype (accurate tier only): torch.bfloat16 runs the same tier with bf16 operands - fp32's exponent range, 8-bit
+    mantissas (16 with the two-term split): the range-safe fallback the fp16 range guard (overflow_seen) switches to."""
     global _ACT, _PRECISE
     if dtype not in (torch.bfloat16, torch.float16, torch.float32):
         raise TypeError(f"compute dtype must be bfloat16, float16 or float32, got {dtype}")
-    act = torch.bfloat16 if dtype == torch.bfloat16 else torch.float16
+    if operand_dtype is not None and (dtype != torch.float32 or operand_dtype not in (torch.float16, torch.bfloat16)):
+        raise TypeError("operand_dtype applies to the accurate tier (dtype float32) and must be float16 or bfloat16")
+    act = torch.bfloat16 if dtype == torch.bfloat16 else (operand_dtype or torch.float16)
     check(_lib.load().omgsr_set_compute_dtype(0 if act == torch.bfloat16 else 1), "set_compute_dtype")
     # fast tiers: deferred softmax maximum (+5 % attention); accurate tier: exact running maximum
     check(_lib.load().omgsr_set_attention_defer_max(0.0 if dtype == torch.float32 else 8.0), "set_attention_defer_max")
     _ACT, _PRECISE = act, dtype == torch.float32
+
+
+# ---- fp16 range guard (accurate tier) -----------------------------------------------------------------------------------------
+# fp16 operands saturate at +-65504 (pack2 clips instead of producing inf). Every kernel that writes a 16-bit operand from values
+# that are not normalised - GEMM / conv epilogues (q, k, v, FF hidden, operand-only outputs), stream -> operand casts - ORs 1 into a
+# device word when it clips one. The pipelines read the word once per call, at the synchronisation the reference's forward() already
+# has, and fall back to bf16 operands for that call instead of returning a silently clipped image.
+_GUARD = True
+_ovf_words: dict = {}
+
+
+def set_range_guard(on: bool) -> None:
+    global _GUARD
+    _GUARD = bool(on)
+
+
+def _ovf(device) -> Optional[int]:
+    """Device pointer of the overflow word when the guard applies (accurate tier with fp16 operands), else None."""
+    if not (_GUARD and _PRECISE and _ACT == torch.float16):
+        return None
+    key = str(device)
+    t = _ovf_words.get(key)
+    if t is None:
+        t = _ovf_words[key] = torch.zeros(1, device=device, dtype=torch.int32)
+    return t.data_ptr()
+
+
+def overflow_seen(reset: bool = True) -> bool:
+    """True when a kernel clipped an fp16 operand since the last reset (synchronises: one 4-byte read per device in use)."""
+    seen = False
+    for t in _ovf_words.values():
+        if bool(t.item()):
+            seen = True
+            if reset:
+                t.zero_()
+    return seen
 
 
 def set_batch_invariant(on: bool) -> None:
@@ -156,6 +196,8 @@ class PackedWeight:
     w_split: int = 1   # 2: the weight itself is carried as w_hi + w_lo: one more K segment [w_lo] that re-reads the operand's
                        # first (hi) half - the contraction WRAPS (omgsr_igemm_args.in_ld); `cin` counts every segment
     in_ld: int = 0     # physical channels of the operand row this weight expects (split * padded Cin); 0 = cin
+    w_ph: Optional[torch.Tensor] = None   # 3x3 convs applied to a nearest-2x upsampled map: the four phase-summed 2 x 2 kernels,
+                                          # [4][Kc/32][4 taps][Cout_pad][32] (omgsr_igemm_args.weight_ph): 4 / 9 of the MFMA work
 
     @property
     def cout_pad(self) -> int:
@@ -171,8 +213,36 @@ class PackedWeight:
         return self.in_ld or self.cin
 
 
+def _segments(w: torch.Tensor, split: int, w_split: int) -> torch.Tensor:
+    """[..., Cin8] fp32 -> [..., Kc]: the K-concatenation of pack_conv_weight ([w_hi] * split, then [w_lo] when w_split 2), every value
+    already rounded to the compute type."""
+    w_hi = w.to(act_dtype()).float()
+    segs = [w_hi] * split           # [hi (cin8) | lo (cin8)] operand rows: both halves meet the same (rounded) weights
+    if w_split == 2:
+        segs.append((w - w_hi).to(act_dtype()).float())      # ... and the operand's hi half meets the weights' low halves
+    return torch.cat(segs, dim=-1) if len(segs) > 1 else w_hi
+
+
+def _phase_kernels(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, 3, 3, C] -> [4, Cout, 2, 2, C]: conv3x3(nearest_up2(x)) at output pixel (2y + a, 2x + b) only sees input rows
+    y - 1 + a, y + a (columns likewise): the taps that land on one input pixel are summed (in fp64), phase index 2a + b."""
+    rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+    w64 = w.double()
+    out = []
+    for a in (0, 1):
+        for b in (0, 1):
+            k = torch.zeros((w.shape[0], 2, 2, w.shape[3]), dtype=torch.float64, device=w.device)
+            for dy, rs in enumerate(rows[a]):
+                for dx, ss in enumerate(rows[b]):
+                    for r in rs:
+                        for s_ in ss:
+                            k[:, dy, dx] += w64[:, r, s_]
+            out.append(k.float())
+    return torch.stack(out, 0)
+
+
 def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, cout_multiple: int = 1,
-                     split: int = 1, w_split: int = 1) -> PackedWeight:
+                     split: int = 1, w_split: int = 1, upsample_phases: bool = False) -> PackedWeight:
     """[Cout, Cin, R, S] (torch conv layout) -> [Cout_pad, roundup(R*S*Kc, 32)] in the compute type, k = (r*S+s)*Kc + c.
     cout_multiple=8 widens the LOGICAL output to a multiple of 8 channels (zero weights, zero bias) so a
     3/4-channel conv writes 16-byte rows that the next kernel can consume directly.
@@ -197,11 +267,8 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
     if split not in (1, 2) or w_split not in (1, 2):
         raise ValueError("split / w_split must be 1 or 2")
     in_ld = cin8 * split
-    w_hi = w.to(act_dtype()).float()
-    segs = [w_hi] * split           # [hi (cin8) | lo (cin8)] operand rows: both halves meet the same (rounded) weights
-    if w_split == 2:
-        segs.append((w - w_hi).to(act_dtype()).float())      # ... and the operand's hi half meets the weights' low halves
-    w = torch.cat(segs, dim=-1) if len(segs) > 1 else w_hi
+    w_raw = w
+    w = _segments(w, split, w_split)
     cin8 = w.shape[-1]
     w = w.reshape(cout, R * S * cin8)
     k_pad = _round_up(w.shape[1], 32)
@@ -214,7 +281,13 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
         # slice-major: [Cin/32][9 taps][Cout_pad][32] - the 128 x 32 weight slice of one (chunk, tap) K-step is one
         # contiguous 8 KB run, so every LDS-DMA wave instruction reads 8 full 128-B lines
         w_cm = out.view(cout_pad, 9, cin8 // 32, 32).permute(2, 1, 0, 3).contiguous()
-    return PackedWeight(out, b, cout, cin8, R, S, w_cm=w_cm, split=split, w_split=w_split, in_ld=in_ld)
+    w_ph = None
+    if upsample_phases and w_cm is not None and in_ld % 32 == 0:
+        ph = _segments(_phase_kernels(w_raw), split, w_split).reshape(4, cout, 4 * cin8)          # k = (2 dy + dx) * Kc + c
+        full = torch.zeros((4, cout_pad, 4 * cin8), device=dev, dtype=act_dtype())
+        full[:, :cout] = ph.to(act_dtype())
+        w_ph = full.view(4, cout_pad, 4, cin8 // 32, 32).permute(0, 3, 2, 1, 4).contiguous()         # [phase][chunk][tap][Cout_pad][32]
+    return PackedWeight(out, b, cout, cin8, R, S, w_cm=w_cm, split=split, w_split=w_split, in_ld=in_ld, w_ph=w_ph)
 
 
 def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, split: int = 1, w_split: int = 1) -> PackedWeight:
@@ -254,8 +327,8 @@ def to_operand(x: torch.Tensor, split: int = 1) -> torch.Tensor:
     _req(x, torch.float32, "x")
     Cc = x.shape[-1]
     y = torch.empty((*x.shape[:-1], split * Cc), device=x.device, dtype=_ACT)
-    check(_lib.load().omgsr_to_operand(x.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc, EL_SPLIT if split == 2 else EL_16, _stream()),
-          "omgsr_to_operand")
+    check(_lib.load().omgsr_to_operand(x.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc, EL_SPLIT if split == 2 else EL_16, _ovf(x.device),
+                                       _stream()), "omgsr_to_operand")
     return y
 
 
@@ -272,6 +345,7 @@ def _out_tensor(shape, cout: int, out_dtype: int, out_split: int, device) -> tor
 def _fill_k(a: IgemmArgs, pw: PackedWeight) -> None:
     """Contraction geometry of a packed weight: Cin = every K segment of a tap, in_ld = the operand row it wraps over."""
     a.Cin = pw.cin
+    a.overflow_flag = _ovf(pw.w.device)
     a.in_ld = pw.row_channels if pw.row_channels != pw.cin else 0
     a.in_split = int(pw.split == 2)
     a.w_split = int(pw.w_split == 2)
@@ -317,6 +391,7 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     a.in_, a.weight, a.bias, a.gate = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
     _fill_out(a, out, out_split, residual, pw.cout)
     a.weight_cm = _ptr(pw.w_cm)
+    a.weight_ph = _ptr(pw.w_ph) if upsample else None
     a.N, a.H, a.W = N, H, W
     _fill_k(a, pw)
     a.Cout, a.Cout_pad, a.K_pad = pw.cout, pw.cout_pad, pw.k_pad
@@ -635,7 +710,7 @@ def group_norm_apply_shared(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Ten
     check(_lib.load().omgsr_groupnorm_apply_shared(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
                                                    _ptr(beta), rows, HW, Cc, groups, act, mean.shape[0], xel,
                                                    EL_SPLIT if split == 2 else EL_16, y2.data_ptr() if fused else None,
-                                                   EL_SPLIT if also_cast == 2 else EL_16, _stream()),
+                                                   EL_SPLIT if also_cast == 2 else EL_16, _ovf(x.device) if fused else None, _stream()),
           "omgsr_groupnorm_apply_shared")
     return (y, y2) if also_cast else y
 
@@ -653,7 +728,8 @@ def group_norm_apply(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, ga
     fused = y2 is not None and y2 is not x
     check(_lib.load().omgsr_groupnorm_apply(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
                                             _ptr(beta), N, HW, Cc, groups, act, xel, EL_SPLIT if split == 2 else EL_16,
-                                            y2.data_ptr() if fused else None, EL_SPLIT if also_cast == 2 else EL_16, _stream()),
+                                            y2.data_ptr() if fused else None, EL_SPLIT if also_cast == 2 else EL_16,
+                                            _ovf(x.device) if fused else None, _stream()),
           "omgsr_groupnorm_apply")
     return (y, y2) if also_cast else y
 

@@ -120,11 +120,20 @@ class OMGSR_F_Infer(torch.nn.Module):
     def forward(self, lq_img, prompt_embeds, pooled_prompt_embeds, text_ids, latent_image_ids, tile_size, tile_overlap):
         torch.cuda.synchronize()
         start_time = time.time()
-        x = ops.nchw_to_nhwc(lq_img.contiguous(), 8)
-        img = self.sr_nhwc(x, prompt_embeds, pooled_prompt_embeds, text_ids, latent_image_ids, tile_size, tile_overlap)
-        out_dtype = ops.io_dtype(lq_img)
-        pred_img = ops.nhwc_to_nchw(img, channels=3, dtype=out_dtype)
+        def run():
+            x = ops.nchw_to_nhwc(lq_img.contiguous(), 8)
+            img = self.sr_nhwc(x, prompt_embeds, pooled_prompt_embeds, text_ids, latent_image_ids, tile_size, tile_overlap)
+            return ops.nhwc_to_nchw(img, channels=3, dtype=ops.io_dtype(lq_img))
+        pred_img = run()
         torch.cuda.synchronize()
+        if ops.precise() and ops.overflow_seen():
+            # FLUX activations are why the reference defaults to bf16: an fp16 operand left the fp16 range in this call - redo it range-safe
+            import warnings
+            from ..precision import bf16_operand_fallback
+            warnings.warn("OMGSR-F accurate tier: an fp16 MFMA operand exceeded 65504; this call is recomputed with bf16 operands")
+            with bf16_operand_fallback(self.vae, self.flux_transformer):
+                pred_img = run()
+                torch.cuda.synchronize()
         t = time.time() - start_time
         if self.verbose:
             print(f"Inference time per image: {t}s")

@@ -99,11 +99,20 @@ class OMGSR_S_Infer(torch.nn.Module):
     def forward(self, lq_img: torch.Tensor, prompt_embeds: torch.Tensor, tile_size: int, tile_overlap: int):
         torch.cuda.synchronize()
         start_time = time.time()
-        x = ops.nchw_to_nhwc(lq_img.contiguous(), 8)
-        img = self.sr_nhwc(x, prompt_embeds, tile_size, tile_overlap)
-        out_dtype = ops.io_dtype(lq_img)
-        pred_img = ops.nhwc_to_nchw(img, channels=3, dtype=out_dtype, clamp=(-1.0, 1.0))
+        def run():
+            x = ops.nchw_to_nhwc(lq_img.contiguous(), 8)
+            img = self.sr_nhwc(x, prompt_embeds, tile_size, tile_overlap)
+            return ops.nhwc_to_nchw(img, channels=3, dtype=ops.io_dtype(lq_img), clamp=(-1.0, 1.0))
+        pred_img = run()
         torch.cuda.synchronize()
+        if ops.precise() and ops.overflow_seen():
+            # an fp16 operand left the fp16 range somewhere in this call (the stores saturate at +-65504): redo it range-safe
+            import warnings
+            from ..precision import bf16_operand_fallback
+            warnings.warn("OMGSR-S accurate tier: an fp16 MFMA operand exceeded 65504; this call is recomputed with bf16 operands")
+            with bf16_operand_fallback(self.vae, self.unet):
+                pred_img = run()
+                torch.cuda.synchronize()
         t = time.time() - start_time
         if self.verbose:
             print(f"Inference time per image: {t}s")

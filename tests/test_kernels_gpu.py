@@ -113,6 +113,39 @@ def test_conv3x3(case):
     assert_close(to_nchw(y), ref, f"conv{case}")
 
 
+# N, Cin, Cout, H, W (low-res), bias, act: nearest-2x upsampling convs on the phase-decomposed form (four 2 x 2 convolutions of the
+# low-res map with phase-summed kernels, igemm_halo_kernel<.., 4>): decoder / UNet upsamplers, ragged tiled-VAE tile sizes
+UPS_PHASE_CASES = [(2, 128, 128, 64, 96, True, 0), (1, 64, 128, 43, 150, False, 0), (4, 512, 512, 32, 32, True, 0), (1, 256, 256, 86, 86, True, 1),
+                   (2, 512, 512, 43, 43, True, 0), (9, 640, 640, 32, 32, True, 0), (1, 256, 96, 19, 40, False, 0)]
+
+
+@pytest.mark.parametrize("case", UPS_PHASE_CASES)
+def test_upsample_conv_phase_form(case, monkeypatch):
+    ops = _ops()
+    N, Cin, Cout, H, W, use_bias, act = case
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    b = rnd(Cout, seed=3) if use_bias else None
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    if act == 1:
+        ref = F.silu(ref)
+    pw = ops.pack_conv_weight(w, b, device=DEV, upsample_phases=True)
+    assert pw.w_ph is not None and tuple(pw.w_ph.shape) == (4, Cin // 32, 4, pw.cout_pad, 32)
+    y = ops.conv2d(nhwc(x), pw, pad=1, upsample=True, act=act, gn_groups=32)
+    assert tuple(y.shape) == (N, 2 * H, 2 * W, Cout)
+    assert_close(to_nchw(y), ref, f"upsample-phase{case}")
+    # the GroupNorm statistics its epilogue left (one slot per wave tile and phase) describe the stored tensor
+    assert getattr(y, "_omgsr_gn", None) is not None
+    mean, rstd, var = ops.group_norm_stats(y, 32, 1e-6)
+    r = y.float().cpu().reshape(N, 4 * H * W, 32, Cout // 32)
+    assert torch.allclose(mean.cpu(), r.mean(dim=(1, 3)), atol=2e-3, rtol=2e-3)
+    assert torch.allclose(var.cpu(), r.var(dim=(1, 3), unbiased=False), atol=2e-3, rtol=5e-3)
+    # ... and the gather form (nine taps on the virtual map) agrees to the output rounding
+    pw9 = ops.pack_conv_weight(w, b, device=DEV)
+    y9 = ops.conv2d(nhwc(x), pw9, pad=1, upsample=True, act=act)
+    assert_close(to_nchw(y), to_nchw(y9), f"phase vs gather {case}", max_ulps=6.0)     # two independently rounded 16-bit results
+
+
 @pytest.mark.parametrize("M,K,Nout", [(64, 320, 320), (4096, 320, 960), (1000, 1280, 1280), (77, 1024, 640), (300, 64, 3072)])
 def test_linear(M, K, Nout):
     ops = _ops()

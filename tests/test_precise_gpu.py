@@ -139,6 +139,23 @@ def test_conv_weight_split_upsample_stride(split, w_split):
     assert _rel(dn, ref) < 3e-6
 
 
+@pytest.mark.parametrize("split,w_split", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_upsample_conv_phase_form_accurate_tier(split, w_split):
+    """The phase-decomposed upsampling conv with split operands / split (phase-summed) weights and fp32 output."""
+    from omgsr_amd import ops
+    x = torch.randn(2, 43, 86, 256, generator=_g(31))
+    if split == 1:
+        x = x.to(torch.float16).float()
+    w = torch.randn(256, 256, 3, 3, generator=_g(32)) * (9 * 256) ** -0.5
+    b = 0.1 * torch.randn(256, generator=_g(33))
+    pw = ops.pack_conv_weight(w, b, device=DEV, split=split, w_split=w_split, upsample_phases=True)
+    assert pw.w_ph is not None
+    y = ops.conv2d(x.to(DEV), pw, pad=1, upsample=True)
+    assert y.dtype == torch.float32
+    ref = F.conv2d(F.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert _rel(y, ref) < (3e-6 if w_split == 2 else 4e-4)
+
+
 @pytest.mark.parametrize("M,K,Nn", [(4608, 3072, 3072), (9216, 1536, 512), (300, 320, 1280), (147456, 320, 320)])
 @pytest.mark.parametrize("split,w_split", [(1, 2), (2, 2)])
 def test_linear_weight_split(M, K, Nn, split, w_split):
@@ -312,3 +329,85 @@ def test_tiled_vae_accurate_tier(fast):
         got_e, got_d = p.encoder(img.to(DEV)), p.decoder(z.to(DEV))
     _report(f"tiled encoder accurate ({'fast' if fast else 'exact'})", got_e, ref_e, 1e-3)
     _report(f"tiled decoder accurate ({'fast' if fast else 'exact'})", got_d, ref_d, 1e-3)
+
+
+# ---- fp16 range guard ------------------------------------------------------------------------------------------------------------
+def test_range_guard_flags_clipped_operands():
+    """A 16-bit operand written past +-65504 (GEMM epilogue, stream -> operand cast, the GroupNorm pass's raw cast) raises the
+    overflow word; values inside the range, fp32 outputs and the guard switched off do not."""
+    from omgsr_amd import ops
+    ops.overflow_seen()
+    x = torch.randn(1, 300, 320, generator=_g(40)).to(DEV)
+    w = torch.randn(640, 320, generator=_g(41)) * 320 ** -0.5
+    pw = ops.pack_linear_weight(w, None, device=DEV)
+    big = ops.pack_linear_weight(w * 3e4, None, device=DEV)           # outputs ~ 3e4 x N(0,1): some beyond 65504
+    ops.linear(x, pw, out_dtype=ops.OUT_BF16)
+    assert not ops.overflow_seen()
+    ops.linear(x, big, out_dtype=ops.OUT_F32)                         # an fp32 output cannot clip
+    assert not ops.overflow_seen()
+    y = ops.linear(x, big, out_dtype=ops.OUT_BF16)
+    assert ops.overflow_seen() and not ops.overflow_seen()            # read resets
+    assert y.float().abs().max().item() == 65504.0                    # the stores saturate, they do not make inf
+    ops.linear(x, big, out_dtype=ops.OUT_BF16, out_split=2)
+    assert ops.overflow_seen()
+    ops.linear(x * 1e5, pw, out_dtype=ops.OUT_F32)                    # the INPUT cast (fp32 stream -> fp16 operand) clips
+    assert ops.overflow_seen()
+    huge = torch.full((2, 16, 64), 7e4, device=DEV)
+    ops.to_operand(huge, 2)
+    assert ops.overflow_seen()
+    ops.group_norm(torch.randn(1, 64, 1, 64, generator=_g(42)).to(DEV) * 1e5, None, None, 8, 1e-6, also_cast=1)
+    assert ops.overflow_seen()
+    ops.set_range_guard(False)
+    try:
+        ops.to_operand(huge, 1)
+        assert not ops.overflow_seen()
+    finally:
+        ops.set_range_guard(True)
+
+
+def test_pipeline_falls_back_to_bf16_operands_on_fp16_overflow():
+    """Activations past 65504 inside the model: every attention V projection of the UNet is scaled by 2e5 and its output projection
+    by 1 / 2e5 - the same function (attention is linear in V) whose V operand no longer fits fp16. The accurate tier notices (one
+    flag read at forward()'s sync), recomputes the call with bf16 operands and warns; the result stays close to the fp32 oracle
+    where the clipped fp16 result is far off."""
+    import warnings
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api import AutoencoderKL, UNet2DConditionModel
+    from omgsr_amd.pipelines.omgsr_s import OMGSR_S_Infer
+    from omgsr_amd.testing import rel_l2, seeded_init_, synthetic_lq
+    from oracle import diffusers_ref as R
+    from oracle.pipeline_ref import OmgsrSRef
+    vcfg = dict(block_out_channels=[32, 64, 128, 128], layers_per_block=1)
+    ucfg = dict(block_out_channels=[64, 128, 256, 256], attention_head_dim=[1, 2, 4, 4], cross_attention_dim=128)
+    ov, ou = seeded_init_(R.AutoencoderKL(**vcfg), 1).eval(), seeded_init_(R.UNet2DConditionModel(**ucfg), 2).eval()
+    with torch.no_grad():
+        for n, m in ou.named_modules():
+            if n.endswith("attn1") or n.endswith("attn2"):
+                m.to_v.weight.mul_(2.0 ** 18)
+                m.to_out[0].weight.mul_(2.0 ** -18)
+    pv, pu = AutoencoderKL(**vcfg), UNet2DConditionModel(**ucfg)
+    pv.load_state_dict(ov.state_dict()); pu.load_state_dict(ou.state_dict())
+    g = _g(3)
+    x = synthetic_lq(1, 128, 128)
+    ehs = torch.randn(1, 77, 128, generator=g)
+    eps = torch.randn(1, 4, 16, 16, generator=g)
+    ov.posterior_noise = eps; pv.posterior_noise = eps
+    with torch.no_grad():
+        ref = OmgsrSRef(ov, ou, R.DDPMScheduler().alphas_cumprod[273], 273)(x, ehs, 16, 8)
+    pipe = OMGSR_S_Infer(None, None, 273, DEV, torch.float32, vae=pv, unet=pu)
+    snap = [(m.op_split, m.w_split) for m in pipe.unet.modules() if hasattr(m, "op_split")]
+    with torch.no_grad():
+        ops.set_range_guard(False)
+        try:
+            clipped, _ = pipe(x.to(DEV), ehs.to(DEV), 16, 8)
+        finally:
+            ops.set_range_guard(True)
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            got, _ = pipe(x.to(DEV), ehs.to(DEV), 16, 8)
+    assert any("65504" in str(w.message) for w in wlist)
+    assert ops.precise() and ops.act_dtype() == torch.float16                     # tier and policy are back
+    assert snap == [(m.op_split, m.w_split) for m in pipe.unet.modules() if hasattr(m, "op_split")]
+    e_clip, e = rel_l2(clipped, ref), rel_l2(got, ref)
+    print(f"fp16 operands clipped: rel-L2 {e_clip:.3e}; bf16-operand fallback: rel-L2 {e:.3e}")
+    assert torch.isfinite(got).all() and e <= 1e-2 and e_clip > 3 * e
