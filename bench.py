@@ -46,7 +46,7 @@ WORKLOADS = {
     "f1024": ("F", 1024, 8, 128, 64, 89.8),        # configs[3] (and the per-GPU share of configs[4]: 64 images over 8 GPUs)
 }
 DTYPES = {"fp32": "float32", "fp16": "float16", "bf16": "bfloat16"}
-IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel"}
+IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel", 6: "igemm_halo_kernel(upsample phases)"}
 
 
 def parse(argv=None):
@@ -104,7 +104,8 @@ def build_s(device, rank, world, wdtype, reduced=False):
     vcfg = dict(block_out_channels=[32, 64, 128, 128], layers_per_block=1) if reduced else {}
     ucfg = dict(block_out_channels=[64, 128, 256, 256], attention_head_dim=[1, 2, 4, 4], cross_attention_dim=128) if reduced else {}
     if rank == 0 or world == 1:
-        vae, unet = seeded_init_(AutoencoderKL(**vcfg), 101), seeded_init_(UNet2DConditionModel(**ucfg), 202)
+        # full-mantissa fp32 values (nothing pre-rounded to 16 bits): what a checkpoint holds after the reference's fp32 LoRA merge
+        vae, unet = seeded_init_(AutoencoderKL(**vcfg), 101, rounded=False), seeded_init_(UNet2DConditionModel(**ucfg), 202, rounded=False)
     else:   # peers allocate uninitialised memory and receive rank 0's weights over RCCL
         with torch.device("meta"):
             vae, unet = AutoencoderKL(**vcfg), UNet2DConditionModel(**ucfg)
@@ -131,7 +132,7 @@ def build_f(device, rank, world, wdtype):
         flux = FluxTransformer2DModel()
     flux = flux.to_empty(device=device).to(wdtype)
     if rank == 0 or world == 1:
-        vae = seeded_init_(AutoencoderKL(**FLUX_VAE_CONFIG), 303)
+        vae = seeded_init_(AutoencoderKL(**FLUX_VAE_CONFIG), 303, rounded=False)
         seeded_init_device_(flux, 404)
     else:
         with torch.device("meta"):
@@ -329,7 +330,7 @@ def make_inputs(family, side, B, tile, rank, device, wdtype):
     inp = {"lq_cpu": lq_cpu, "lq": lq_cpu.to(device=device, dtype=wdtype),
            "eps": torch.randn(B, lat_c, side // 8, side // 8, generator=torch.Generator().manual_seed(99 + rank))}
     if family == "S":
-        inp["prompt_cpu"] = torch.randn(1, 77, 1024, generator=g).to(torch.bfloat16).float()
+        inp["prompt_cpu"] = torch.randn(1, 77, 1024, generator=g)
         inp["prompt"] = inp["prompt_cpu"].to(device=device, dtype=wdtype)
     else:
         from omgsr_amd.pipelines.omgsr_f import prepare_latent_image_ids
@@ -442,7 +443,7 @@ def cpu_leg(inp, hip_out_nchw, tile, overlap, side, tiled_vae=False, runs=3):
     # tools/cpu_threads_probe.py: 16 thr 1.13 TFLOP/s, 32 thr 0.77, 64 thr 0.52, 128 thr 0.24)
     cores = int(os.environ.get("OMGSR_CPU_THREADS", min(16, os.cpu_count() or 1)))
     torch.set_num_threads(cores)
-    vae, unet = seeded_init_(R.AutoencoderKL(), 101).eval(), seeded_init_(R.UNet2DConditionModel(), 202).eval()
+    vae, unet = seeded_init_(R.AutoencoderKL(), 101, rounded=False).eval(), seeded_init_(R.UNet2DConditionModel(), 202, rounded=False).eval()
     vae.posterior_noise = inp["eps"][:1]
     ref = OmgsrSRef(TiledVaeRef(vae, 256, 64) if tiled_vae else vae, unet, R.DDPMScheduler().alphas_cumprod[273], 273)
     times = []

@@ -248,19 +248,39 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
         self.round_timestep_to_weight_dtype = True
 
     # ---- constant folding ------------------------------------------------------------------
+    def _host_scalar(self, slot: str, t: Optional[torch.Tensor]):
+        """First element of a (device) tensor as a Python float, read ONCE per tensor object and version: OMGSR calls the DiT with the
+        same timestep / guidance tensors on every image (the pipelines keep them), so the device -> host read (a stream
+        synchronisation) happens on the first call only."""
+        if t is None:
+            return None
+        hit = self.__dict__.get("_scalar_" + slot)
+        if hit is not None and hit[0] is t and hit[1] == t._version:
+            return hit[2]
+        v = float(t.reshape(-1)[0].float())
+        self.__dict__["_scalar_" + slot] = (t, t._version, v)
+        return v
+
+    def _mod_deps(self):
+        deps = self.__dict__.get("_mod_dep_list")
+        if deps is None:            # the parameter OBJECTS never change (load_state_dict / .to() / LoRA merges write in place or bump _version)
+            deps = [p for m in (self.time_text_embed, self.norm_out) for p in m.parameters()]
+            for b in list(self.transformer_blocks) + list(self.single_transformer_blocks):
+                for nm in ("norm1", "norm1_context", "norm"):
+                    if hasattr(b, nm):
+                        deps += list(getattr(b, nm).parameters())
+            self.__dict__["_mod_dep_list"] = deps
+        return deps
+
     def _mod_key(self, timestep, guidance) -> tuple:
         """(scaled timestep, scaled guidance, identity of every parameter the modulation tables depend on)."""
         wd = self.x_embedder.weight.dtype
         rt = (lambda v: float((torch.tensor(v, dtype=torch.float32).to(wd) * 1000).float())) if (wd != torch.float32 and self.round_timestep_to_weight_dtype) \
             else (lambda v: v * 1000.0)
-        t = rt(float(timestep.reshape(-1)[0]))
-        g = None if guidance is None else rt(float(guidance.reshape(-1)[0].float()))
-        deps = [p for m in (self.time_text_embed, self.norm_out) for p in m.parameters()]
-        for b in list(self.transformer_blocks) + list(self.single_transformer_blocks):
-            for nm in ("norm1", "norm1_context", "norm"):
-                if hasattr(b, nm):
-                    deps += list(getattr(b, nm).parameters())
-        return (t, g, _key(*deps))
+        t = rt(self._host_scalar("t", timestep))
+        g = None if guidance is None else rt(self._host_scalar("g", guidance))
+        # address + version + dtype of ~360 parameters: the version bump of an in-place LoRA merge or a .to() re-keys the tables
+        return (t, g, ops.mode_key(), tuple((p.data_ptr(), p._version, p.dtype) for p in self._mod_deps()))
 
     @torch.no_grad()
     def _modulation(self, timestep: torch.Tensor, guidance: Optional[torch.Tensor], pooled: torch.Tensor):

@@ -84,8 +84,13 @@ class OMGSR_F_Infer(torch.nn.Module):
         C = self.vae.config.latent_channels
         tok = ops.flux_pack(z_nhwc, C)
         B = tok.shape[0]
-        timestep = torch.tensor([self.t_curr], device=tok.device)
-        guidance = torch.full((B,), self.guidance_scale, device=tok.device, dtype=torch.float32)
+        # the same two tensors on every call (the DiT reads their value once per tensor: no per-image host synchronisation)
+        key = (str(tok.device), B)
+        if self.__dict__.get("_tg_key") != key:
+            self.__dict__["_tg"] = (torch.tensor([self.t_curr], device=tok.device),
+                                    torch.full((B,), self.guidance_scale, device=tok.device, dtype=torch.float32))
+            self.__dict__["_tg_key"] = key
+        timestep, guidance = self.__dict__["_tg"]
         vel = self.flux_transformer.tokens(tok, timestep, guidance, pooled, prompt_embeds, text_ids, image_ids)
         return tok, vel
 

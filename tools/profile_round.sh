@@ -1,17 +1,17 @@
 #!/bin/bash
 # Round profile of the default bench (run on the GPU box from the repo root): kernel trace + the two HBM-traffic PMC passes +
 # one MFMA / LDS counter pass. Writes under gpurun_out/prof_$1; summaries are then copied into profiles/ by hand.
-#   bash tools/profile_round.sh r02 [extra bench.py flags]
+#   bash tools/profile_round.sh r03 [extra bench.py flags]
 set -u
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-tiers $*"
+BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-tiers --no-f1024 $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
 DB=$(find $OUT/trace -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB $OUT/kernel_stats.md > /dev/null
-ONE="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-tiers $*"
+ONE="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-tiers --no-f1024 $*"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 $ONE > /dev/null 2> $OUT/pmc_$C.log
 done

@@ -11,7 +11,7 @@ fam = traffic["families"]
 lines = []
 lines.append(f"# rocprofv3 --kernel-trace --stats of the default bench: {title}\n")
 lines.append(f"Command (GPU box, `tools/profile_round.sh`): `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 "
-             f"--no-cpu-baseline --no-fast-tiers`; config {json.dumps(bench['config'])}, dtype {bench['dtype']}. "
+             f"--no-cpu-baseline --no-fast-tiers --no-f1024`; config {json.dumps(bench['config'])}, dtype {bench['dtype']}. "
              f"5 pipeline passes in the trace (1 warm-up + 3 timed + 1 roofline pass).")
 lines.append(f"bench line under the profiler: {bench['ms_per_step']} ms/step ({bench['value']} {bench['unit']}). bench.py's HIP-event leg in the "
              f"same run: igemm family {roof['kernel_ms']} ms / {roof['launches']} launches; per kernel (total ms per pass, algorithmic TFLOP/s): "
@@ -30,5 +30,8 @@ lines += [l for l in ks if not any(t in l for t in ("at::native", "__amd_rocclr"
 os.makedirs("profiles", exist_ok=True)
 open(f"profiles/{tag}_kernel_stats.md", "w").write("\n".join(lines) + "\n")
 traffic.update(bench.get("args", {}))            # bench.py matches the file to its own run by (workload, weight_dtype, batch)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omgsr_amd.build import _source_digest        # noqa: E402
+traffic["source_digest"] = _source_digest()      # bench.py reports whether the kernels changed since these PMC passes
 json.dump(traffic, open(f"profiles/{ttag}.json", "w"), indent=1)
 print(f"profiles/{tag}_kernel_stats.md", len(lines), "lines")
