@@ -46,7 +46,7 @@ WORKLOADS = {
     "f1024": ("F", 1024, 8, 128, 64, 89.8),        # configs[3] (and the per-GPU share of configs[4]: 64 images over 8 GPUs)
 }
 DTYPES = {"fp32": "float32", "fp16": "float16", "bf16": "bfloat16"}
-IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel", 6: "igemm_halo_kernel(upsample phases)"}
+IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel", 6: "igemm_halo_kernel<TAPS=4>", 7: "igemm_halo_multi_kernel", 8: "igemm_halo_multi_kernel<TAPS=4>"}
 
 
 def parse(argv=None):
@@ -402,6 +402,10 @@ def roofline_leg(_lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, 
                     "traffic": None,
                     "launches": ig["launches"], "kernel_ms": round(ig["ms"], 3),
                     "algorithmic_tflop": round(alg_igemm, 3), "executed_tflop": round(ig["flops"] / 1e12, 3),
+                    # `frac` divides the §8(d) ALGORITHMIC FLOPs by the kernels' time: the accurate tier's extra K segments (split operands /
+                    # weights: up to 3 MFMA passes per layer) and the tiled VAE's overlap recompute are overhead there, not work. The
+                    # kernels' own rate on the work they were handed (per-launch FLOPs incl. tile overlap, split segments counted once):
+                    "frac_of_launched_work": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12 / PEAK_DENSE_TFLOPS, 4),
                     "algorithmic_basis": f"{tflop_per_img} TFLOP/image x {B} images (SURVEY 8(d), untiled VAE) minus {attn_tflop:.3f} TFLOP run by attn_kernel",
                     "achieved_all_mfma_kernels": round(tflop_per_img * B / (mfma_ms * 1e-3), 2),
                     "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"]),

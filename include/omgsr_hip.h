@@ -51,6 +51,12 @@ extern "C" {
 #define OMGSR_EL_16 0
 #define OMGSR_EL_F32 1
 #define OMGSR_EL_SPLIT 2
+/* OMGSR_EL_MX (outputs of the GroupNorm apply / cast kernels only; fp16 compute type): the three-part operand of the mixed-precision
+ * split. A row of C logical channels (C % 64 == 0) is 4C bytes = 2C 16-bit slots: [a_hi fp16 | a_lo' fp8 e4m3 | a_hi' fp8 e4m3] with
+ * a_lo' = (a - a_hi) * 2^11 and a_hi' = a_hi, both clamped to +-448. Its consumer (omgsr_igemm_args.mx_chunks16 > 0, halo-tile
+ * kernel) multiplies the first half by fp16 weights in fp16 MFMAs and the fp8 parts by fp8 copies of w_hi / w_lo in block-scaled MFMAs
+ * (v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 rate), all into one fp32 accumulator. */
+#define OMGSR_EL_MX 3
 
 #define OMGSR_DT_BF16 0
 #define OMGSR_DT_F16 1
@@ -126,11 +132,27 @@ typedef struct omgsr_igemm_args {
                               (2y + a, 2x + b) reads input rows y - 1 + a + dy and columns x - 1 + b + dx with the 3 x 3 taps that land on the same
                               input pixel summed: the conv then runs as four 2 x 2 convolutions of the low-res map (4 / 9 of the MFMA work of
                               gathering nine taps from the virtual high-res map). Same K layout per tap as `weight` (split segments included) | NULL */
+    int32_t mx_chunks16;   /* > 0: `in` is an OMGSR_EL_MX operand and `weight_cm` (/ `weight_ph`) its mixed-precision weight: per tap the first
+                              mx_chunks16 32-channel chunks are fp16 x fp16, the remaining (Cin / 32 - mx_chunks16) 64-byte chunks hold 64 fp8
+                              channels each - first the a_lo' x w_hi' segment, then a_hi' x w_lo' - and run as block-scaled fp8 MFMAs with
+                              the E8M0 scales below (weight / operand, per segment). 3x3 stride 1 pad 1 (or the phase form) only: these
+                              problems always take the halo-tile kernel. Cin = 2 x logical channels (16-bit slots), in_ld = 0. */
+    int32_t mx_scale_w1, mx_scale_a1, mx_scale_w2, mx_scale_a2;   /* E8M0 exponents (127 = 2^0): the instruction multiplies each product by 2^(w - 127) 2^(a - 127) */
+    int32_t group_tiles;   /* written by omgsr_igemm_multi_plan: halo-kernel tiles of the whole launch group this problem belongs to (0 = alone);
+                              kernel choice and the GroupNorm-statistics layout use max(own tiles, group_tiles) */
     uint32_t* overflow_flag; /* optional (fp16 compute type only): a device word the epilogue ORs 1 into when a value it writes as a 16-bit
                               output lies beyond +-65504 (the stores saturate there). The accurate tier's range guard: the pipelines
                               check it once per call, at the sync the reference's forward() already has | NULL */
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
+/* The problems of ONE layer that differ only in tensors and spatial extents (the tiled VAE runs every layer once per tile-shape group:
+ * corner / edge / interior tiles are separate dense tensors; infer/vaehook.py:537-829 walks them one tile at a time). Call
+ * omgsr_igemm_multi_plan first: it writes `group_tiles` into every problem, so that omgsr_igemm_gn_slots / _gn_entries /
+ * _workspace_bytes answer for the group. omgsr_igemm_multi then runs the problems that take the halo-tile kernel in one shape as ONE
+ * launch (a prefix table of tile counts in the kernel arguments, <= 8 problems per launch) and everything else in order, one launch
+ * each: same results as `count` omgsr_igemm calls, fewer partial last rounds of workgroups. */
+int omgsr_igemm_multi_plan(omgsr_igemm_args* args, int32_t count);
+int omgsr_igemm_multi(const omgsr_igemm_args* args, int32_t count, void* stream);
 /* Batch-invariant dispatch (process-wide, default off). The dispatcher normally picks the kernel family (halo-tile conv vs GEMM-shaped)
  * and a split-K factor from the TOTAL tile count, so the summation order of a layer - and with it the last bits of the result - can change
  * with the batch size. With the flag on those two decisions use `sample_rows`: batch-B == B x batch-1 bit for bit (the reference's
@@ -326,7 +348,8 @@ int omgsr_timing_reset(void);
 /* Synchronises, then fills up to `cap` entries; returns the number of recorded launches. */
 /* kind: 1 igemm, 2 attention, 3 groupnorm, 4 layernorm, 5 elementwise, 6 softmax. variant (igemm only): which kernel
  * the dispatcher launched - 1 igemm_kernel (register staged), 2 igemm_dma_kernel, 3 igemm_halo_kernel, 4 igemm_dma_kernel
- * split-K + splitk_reduce_kernel, 5 igemm_p8_kernel, 6 igemm_halo_kernel in its phase-decomposed upsampling form. flops / bytes: ALGORITHMIC work of the launch (a two-term split operand's duplicated
+ * split-K + splitk_reduce_kernel, 5 igemm_p8_kernel, 6 igemm_halo_kernel in its phase-decomposed upsampling form, 7 / 8
+ * igemm_halo_multi_kernel (several problems of one layer in one launch: nine-tap / phase-decomposed form). flops / bytes: ALGORITHMIC work of the launch (a two-term split operand's duplicated
  * channels count once). */
 typedef struct omgsr_timing_entry { int32_t kind; float ms; double flops; double bytes; int64_t m, n, k; int32_t variant; int32_t stage; } omgsr_timing_entry;
 int omgsr_timing_collect(omgsr_timing_entry* out, int cap);

@@ -37,7 +37,8 @@ class IgemmArgs(C.Structure):
         ("alpha", C.c_float), ("weight_cm", C.c_void_p), ("workspace", C.c_void_p),
         ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32), ("gn_entries", C.c_int32),
         ("res_el", C.c_int32), ("in_split", C.c_int32), ("sample_rows", C.c_int64), ("out_lo_off", C.c_int32),
-        ("in_ld", C.c_int32), ("w_split", C.c_int32), ("weight_ph", C.c_void_p), ("overflow_flag", C.c_void_p),
+        ("in_ld", C.c_int32), ("w_split", C.c_int32), ("weight_ph", C.c_void_p), ("mx_chunks16", C.c_int32), ("mx_scale_w1", C.c_int32), ("mx_scale_a1", C.c_int32),
+        ("mx_scale_w2", C.c_int32), ("mx_scale_a2", C.c_int32), ("group_tiles", C.c_int32), ("overflow_flag", C.c_void_p),
     ]
 
 
@@ -75,6 +76,8 @@ SIGNATURES = {
     "omgsr_get_compute_dtype": (C.c_int, []),
     "omgsr_error_string": (C.c_char_p, [C.c_int]),
     "omgsr_igemm": (C.c_int, [C.POINTER(IgemmArgs), _P]),
+    "omgsr_igemm_multi_plan": (C.c_int, [C.POINTER(IgemmArgs), _I]),
+    "omgsr_igemm_multi": (C.c_int, [C.POINTER(IgemmArgs), _I, _P]),
     "omgsr_set_batch_invariant": (C.c_int, [C.c_int]),
     "omgsr_set_attention_defer_max": (C.c_int, [C.c_float]),
     "omgsr_igemm_workspace_bytes": (C.c_int64, [C.POINTER(IgemmArgs)]),

@@ -34,6 +34,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
 
 #define OMGSR_DEVINL __device__ __forceinline__
 
@@ -115,6 +116,40 @@ template <typename T> OMGSR_DEVINL void split8(const float (&v)[8], u32x4_t& hi,
         lo[i] = pack2<T>(v[2 * i] - lo_of<T>(h2, 0), v[2 * i + 1] - lo_of<T>(h2, 1));
     }
 }
+// ---- the MX operand form (OMGSR_EL_MX, fp16 compute type): a row of C logical channels is 4C bytes,
+//   [a_hi fp16 (2C B) | a_lo' fp8 e4m3 (C B) | a_hi' fp8 e4m3 (C B)],   a_lo' = (a - a_hi) * 2^OMGSR_MX_LO_SHIFT,  a_hi' = a_hi
+// The hi half meets the fp16 weights in fp16 MFMAs; the two fp8 thirds meet fp8 copies of w_hi / w_lo in block-scaled MFMAs
+// (v_mfma_scale_f32_32x32x64_f8f6f4: 64 channels per instruction at twice the fp16 rate, the E8M0 scale operands put the 2^-11 back),
+// all into one fp32 accumulator: a_hi w_hi + a_lo w_hi + a_hi w_lo with the two correction terms carried to 2^-4 of THEIR size
+// (2^-16 of the product) for one third less MFMA time and operand traffic than three fp16 segments.
+// v_cvt_pk_fp8_f32 (gfx950: OCP e4m3fn, round to nearest even) turns |x| >= 464 into NaN: clamp to +-448 first.
+#define OMGSR_MX_LO_SHIFT 11
+OMGSR_DEVINL unsigned int pack4_fp8(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned int)v;
+}
+// 8 channels c .. c + 7 of the row that starts at byte `row_byte0` and holds C logical channels
+template <typename T> OMGSR_DEVINL void store8_mx(void* base, const int64_t row_byte0, const int C, const int c, const float (&f)[8]) {
+    unsigned char* row = reinterpret_cast<unsigned char*>(base) + row_byte0;
+    u32x4_t hi;
+    float lo[8], hf[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned int h2 = pack2<T>(f[2 * i], f[2 * i + 1]);
+        hi[i] = h2;
+        hf[2 * i] = lo_of<T>(h2, 0); hf[2 * i + 1] = lo_of<T>(h2, 1);
+        lo[2 * i] = (f[2 * i] - hf[2 * i]) * (float)(1 << OMGSR_MX_LO_SHIFT);
+        lo[2 * i + 1] = (f[2 * i + 1] - hf[2 * i + 1]) * (float)(1 << OMGSR_MX_LO_SHIFT);
+    }
+    *reinterpret_cast<u32x4_t*>(row + 2 * c) = hi;
+    *reinterpret_cast<u32x2_t*>(row + 2 * C + c) = (u32x2_t){pack4_fp8(lo[0], lo[1], lo[2], lo[3]), pack4_fp8(lo[4], lo[5], lo[6], lo[7])};
+    *reinterpret_cast<u32x2_t*>(row + 3 * C + c) = (u32x2_t){pack4_fp8(hf[0], hf[1], hf[2], hf[3]), pack4_fp8(hf[4], hf[5], hf[6], hf[7])};
+}
+
 // store: EL 0 = 16-bit at base[idx]; 1 = fp32 at base[idx]; 2 = split, hi at base[idx], lo at base[idx + lo_off]
 template <typename T, int EL> OMGSR_DEVINL void store8(void* base, const int64_t idx, const int64_t lo_off, const float (&f)[8]) {
     if constexpr (EL == 1) {

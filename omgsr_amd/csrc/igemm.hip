@@ -27,6 +27,7 @@
 namespace omgsr {
 int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, bool phase = false);
+int igemm_halo_launch_multi(const omgsr_igemm_args* a, const IgemmGeo* g0, int count, hipStream_t st, bool phase);
 bool igemm_p8_wanted(const omgsr_igemm_args& a, const IgemmGeo& g);
 int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 int igemm_halo_tiles(const omgsr_igemm_args& a, bool phase = false);
@@ -266,7 +267,7 @@ int splitk_plan(const omgsr_igemm_args& a_real, int64_t M64) {
     const omgsr_igemm_args a = policy_view(a_real);
     if (omgsr::g_batch_invariant) M64 = (int64_t)a.N * a.Ho * a.Wo;
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
-    if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || (a.in_ld % 32) || logical_cols < 96) return 1;
+    if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || (a.in_ld % 32) || logical_cols < 96 || a.mx_chunks16 > 0) return 1;
     if (use_halo(a) || use_halo_phase(a)) return 1;   // the halo-tile kernel takes the problem (and owns the fused GroupNorm statistics)
     const int nk = a.K_pad / 32;
     const int64_t tiles = ((M64 + 255) / 256) * ((logical_cols + 127) / 128);
@@ -278,8 +279,17 @@ int splitk_plan(const omgsr_igemm_args& a_real, int64_t M64) {
     return splits < 2 ? 1 : splits;
 }
 
+// A mixed-precision (MX) problem: fp16 chunks followed by block-scaled fp8 chunks. Only the halo-tile kernel's wide nine-tap shape runs it.
+bool mx_geometry_ok(const omgsr_igemm_args& a) {
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    return a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 && a.upsample == 0 && (a.Cin % 128) == 0 &&
+           a.in_ld == 0 && a.batch == 1 && a.Ho == a.H && a.Wo == a.W && logical_cols >= 96 && a.act != OMGSR_ACT_GEGLU &&
+           a.out_layout == OMGSR_LAYOUT_NHWC && a.mx_chunks16 == a.Cin / 64 && omgsr::compute_dtype() == 1;
+}
+
 // the halo-tile kernel's preconditions + the "enough tiles to fill the chip" policy
 bool use_halo(const omgsr_igemm_args& a_real) {
+    if (a_real.mx_chunks16 > 0) return mx_geometry_ok(a_real);   // no other kernel understands the format
     const omgsr_igemm_args a = policy_view(a_real);              // geometry tests below do not involve N; the tile count does
     static const char* mode = getenv("OMGSR_IGEMM_MODE");
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
@@ -292,7 +302,8 @@ bool use_halo(const omgsr_igemm_args& a_real) {
     // the halo tile is 32 pixels wide: on narrow maps (the UNet's 16 x 16 level) half of every tile would be padding
     const int padded_w = ((a.Wo + 31) / 32) * 32;
     if (padded_w * 3 > a.Wo * 4) return false;      // > 1/3 of the columns wasted
-    return omgsr::igemm_halo_tiles(a) >= 192;
+    const int tiles = omgsr::igemm_halo_tiles(a);
+    return (tiles > a.group_tiles ? tiles : a.group_tiles) >= 192;          // group_tiles: the launch group this problem belongs to (omgsr_igemm_multi_plan)
 }
 
 // Nearest-2x upsampling + 3x3 conv as four 2 x 2 convolutions of the low-res map (weight_ph: phase-summed kernels), 4 / 9 of the MFMA work
@@ -307,7 +318,8 @@ bool use_halo_phase(const omgsr_igemm_args& a_real) {
     if (!ok) return false;
     const int padded_w = ((a.W + 31) / 32) * 32;
     if (padded_w * 3 > a.W * 4) return false;
-    return omgsr::igemm_halo_tiles(a, true) >= 192;
+    const int tiles = omgsr::igemm_halo_tiles(a, true);
+    return (tiles > a.group_tiles ? tiles : a.group_tiles) >= 192;
 }
 
 }  // namespace
@@ -367,9 +379,10 @@ extern "C" int64_t omgsr_igemm_workspace_bytes(const omgsr_igemm_args* ap) {
     return (int64_t)splits * M64 * (((logical_cols + 127) / 128) * 128) * 4;
 }
 
-extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
-    if (!ap || !ap->in || !ap->weight || !ap->out) return OMGSR_E_BADARG;
-    omgsr_igemm_args a = *ap;
+namespace {
+// argument checks shared by omgsr_igemm and omgsr_igemm_multi; normalises in_ld (in_ld == Cin -> 0)
+int validate_args(omgsr_igemm_args& a) {
+    if (!a.in || !a.weight || !a.out) return OMGSR_E_BADARG;
     if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.Cin <= 0 || a.Cout <= 0 || a.Ho <= 0 || a.Wo <= 0 ||
         a.R <= 0 || a.S <= 0 || a.stride <= 0 || a.batch <= 0) return OMGSR_E_BADARG;
     if ((a.Cin & 7) || (a.Cout_pad & 127) || (a.K_pad % BK) || a.K_pad < a.R * a.S * a.Cin) return OMGSR_E_SHAPE;
@@ -391,6 +404,112 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     if (a.in_ld == a.Cin) a.in_ld = 0;
     const int ksegs = 1 + (a.in_split ? 1 : 0) + (a.w_split ? 1 : 0);      // K-concat segments of one logical channel set
     if (a.Cin % (8 * ksegs)) return OMGSR_E_SHAPE;
+    if (a.mx_chunks16 < 0 || (a.mx_chunks16 > 0 && !mx_geometry_ok(a))) return OMGSR_E_SHAPE;
+    if (a.gn_partial) {                            // must be exactly what omgsr_igemm_gn_slots / _gn_entries promised
+        int nslot, entries;
+        gn_plan(a, &nslot, &entries);
+        if (nslot <= 0 || a.gn_entries != entries) return OMGSR_E_BADARG;
+    }
+    return 0;
+}
+
+void work_of(const omgsr_igemm_args& a, double* flops, double* bytes) {
+    const int64_t M64 = (int64_t)a.N * a.Ho * a.Wo;
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    const int ksegs = 1 + (a.in_split ? 1 : 0) + (a.w_split ? 1 : 0);
+    // algorithmic work: a split operand's / weight's extra K segments are precision overhead, not useful FLOPs
+    *flops = 2.0 * (double)M64 * (double)a.R * a.S * (a.Cin / ksegs) * (double)logical_cols * a.batch;
+    const double out_b = (a.out_dtype == OMGSR_OUT_F32 ? 4.0 : (a.out_lo_off ? 4.0 : 2.0)), res_b = a.residual ? (a.res_el == OMGSR_EL_F32 ? 4.0 : 2.0) : 0.0;
+    *bytes = (2.0 * ((double)a.N * a.H * a.W * (a.in_ld > 0 ? a.in_ld : a.Cin) + (double)a.Cout_pad * a.K_pad) + (double)M64 * a.Cout * (out_b + res_b)) * a.batch;
+}
+
+Geo geo_of(const omgsr_igemm_args& a) {
+    Geo g;
+    g.M = (int)((int64_t)a.N * a.Ho * a.Wo);
+    g.HoWo = a.Ho * a.Wo;
+    g.Hv = a.H << a.upsample;
+    g.Wv = a.W << a.upsample;
+    g.nk = a.K_pad / BK;
+    g.splits = 1; g.nk_total = g.nk;
+    return g;
+}
+}  // namespace
+
+// Problems of ONE layer that differ only in their tensors and spatial extents (the tiled VAE's tile-shape groups): plan first
+// (omgsr_igemm_multi_plan writes each problem's `group_tiles` so that kernel choice and GroupNorm-statistics layout are decided for
+// the GROUP), then launch. Problems that take the halo-tile kernel in the same shape run as one launch; the rest one by one.
+extern "C" int omgsr_igemm_multi_plan(omgsr_igemm_args* args, int32_t count) {
+    if (!args || count <= 0) return OMGSR_E_BADARG;
+    static const char* off = getenv("OMGSR_MULTI");           // A/B runs: "0" = every problem its own launch
+    int total = 0, total_ph = 0;
+    for (int i = 0; i < count; ++i) {
+        args[i].group_tiles = 0;
+        total += omgsr::igemm_halo_tiles(args[i], false);
+        total_ph += omgsr::igemm_halo_tiles(args[i], true);
+    }
+    if ((off && off[0] == '0') || omgsr::g_batch_invariant) return 0;       // batch-invariant mode: every decision from one sample alone
+    for (int i = 0; i < count; ++i) args[i].group_tiles = (args[i].upsample && args[i].weight_ph) ? total_ph : total;
+    return 0;
+}
+
+extern "C" int omgsr_igemm_multi(const omgsr_igemm_args* args, int32_t count, void* stream) {
+    if (!args || count <= 0) return OMGSR_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int MAXG = 8;
+    omgsr_igemm_args grp[MAXG];
+    Geo geo[MAXG];
+    int ng = 0, mode = -1;          // mode of the open group: 0 = halo 9 taps, 1 = phase form
+    double gf = 0.0, gb = 0.0;
+    long long gm = 0;
+    auto flush = [&]() -> int {
+        if (ng == 0) return 0;
+        int rc;
+        {
+            const int logical_cols = (grp[0].act == OMGSR_ACT_GEGLU) ? 2 * grp[0].Cout : grp[0].Cout;
+            omgsr::TimingScope ts(OMGSR_TK_IGEMM, gf, gb, st, gm, logical_cols, (long long)grp[0].R * grp[0].S * grp[0].Cin);
+            ts.rec.variant = ng == 1 ? (mode == 1 ? 6 : 3) : (mode == 1 ? 8 : 7);      // 7 / 8: igemm_halo_multi_kernel (gather / phase form)
+            rc = ng == 1 ? omgsr::igemm_halo_launch(grp[0], geo[0], st, mode == 1) : omgsr::igemm_halo_launch_multi(grp, geo, ng, st, mode == 1);
+        }
+        ng = 0; gf = gb = 0.0; gm = 0;
+        return rc;
+    };
+    for (int i = 0; i < count; ++i) {
+        omgsr_igemm_args a = args[i];
+        int rc = validate_args(a);
+        if (rc != 0) { flush(); return rc; }
+        const int m = (a.workspace && splitk_plan(a, (int64_t)a.N * a.Ho * a.Wo) > 1) ? -1 : use_halo_phase(a) ? 1 : use_halo(a) ? 0 : -1;
+        const bool same = ng > 0 && m == mode && a.weight == grp[0].weight && a.Cin == grp[0].Cin && a.in_ld == grp[0].in_ld && a.Cout == grp[0].Cout &&
+                          a.act == grp[0].act && a.out_dtype == grp[0].out_dtype && a.out_lo_off == grp[0].out_lo_off && a.out_ld == grp[0].out_ld &&
+                          a.res_el == grp[0].res_el && (a.residual != nullptr) == (grp[0].residual != nullptr) &&
+                          (a.gn_partial != nullptr) == (grp[0].gn_partial != nullptr) && a.gn_entries == grp[0].gn_entries && a.bias == grp[0].bias &&
+                          a.gate == grp[0].gate && a.alpha == grp[0].alpha && a.upsample == grp[0].upsample && a.mx_chunks16 == grp[0].mx_chunks16 &&
+                          ((a.Cout <= 32) == (grp[0].Cout <= 32));
+        if (m < 0) {                     // not a halo problem: its own launch, in order
+            rc = flush();
+            if (rc == 0) rc = omgsr_igemm(&args[i], stream);
+            if (rc != 0) return rc;
+            continue;
+        }
+        if (ng > 0 && (!same || ng == MAXG)) { rc = flush(); if (rc != 0) return rc; }
+        mode = m;
+        double f, b;
+        work_of(a, &f, &b);
+        gf += f; gb += b; gm += (long long)a.N * a.Ho * a.Wo;
+        geo[ng] = geo_of(a);
+        grp[ng++] = a;
+    }
+    return flush();
+}
+
+extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
+    if (!ap) return OMGSR_E_BADARG;
+    omgsr_igemm_args a = *ap;
+    {
+        const int rc = validate_args(a);
+        if (rc != 0) return rc;
+    }
+    const int64_t M64 = (int64_t)a.N * a.Ho * a.Wo;
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     Geo g;
     g.M = (int)M64;
     g.HoWo = a.Ho * a.Wo;
@@ -398,11 +517,8 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     g.Wv = a.W << a.upsample;
     g.nk = a.K_pad / BK;
     hipStream_t st = (hipStream_t)stream;
-    // algorithmic work: a split operand's duplicated channels are precision overhead, not useful FLOPs
-    const int cin_logical = a.Cin / ksegs;
-    const double flops = 2.0 * (double)M64 * (double)a.R * a.S * cin_logical * (double)logical_cols * a.batch;
-    const double out_b = (a.out_dtype == OMGSR_OUT_F32 ? 4.0 : (a.out_lo_off ? 4.0 : 2.0)), res_b = a.residual ? (a.res_el == OMGSR_EL_F32 ? 4.0 : 2.0) : 0.0;
-    const double bytes = (2.0 * ((double)a.N * a.H * a.W * (a.in_ld > 0 ? a.in_ld : a.Cin) + (double)a.Cout_pad * a.K_pad) + (double)M64 * a.Cout * (out_b + res_b)) * a.batch;
+    double flops, bytes;
+    work_of(a, &flops, &bytes);
     omgsr::TimingScope ts(OMGSR_TK_IGEMM, flops, bytes, st, M64 * a.batch, logical_cols, (long long)a.R * a.S * a.Cin);
     // Tile choice: the 128x128 tile is the MFMA-efficient default; narrow outputs use 128x32 so
     // padded columns do not burn MFMA cycles; small problems drop to 64x64 to fill the 256 CUs.
@@ -431,11 +547,6 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         }
     }
     // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
-    if (a.gn_partial) {                            // must be exactly what omgsr_igemm_gn_slots / _gn_entries promised
-        int nslot, entries;
-        gn_plan(a, &nslot, &entries);
-        if (nslot <= 0 || a.gn_entries != entries) return OMGSR_E_BADARG;
-    }
     if (use_halo_phase(a)) { ts.rec.variant = 6; return omgsr::igemm_halo_launch(a, g, st, true); }
     if (use_halo(a)) { ts.rec.variant = 3; return omgsr::igemm_halo_launch(a, g, st); }
     {

@@ -22,279 +22,10 @@
 //    row y + 1 <- w[2]; same along x), so each of the four output phases is a 2 x 2 convolution of the LOW-resolution map: 4 / 9 of
 //    the MFMA work of the gather form. One launch, blockIdx.y = phase; the tile is 8 x 32 low-res pixels whose outputs land at
 //    stride 2 in the high-res map; patch (8+1) x (32+1), weight ring of 4 stages (stage = tap).
-#include "common.hip.h"
-#include "../../include/omgsr_hip.h"
-#include "igemm_epilogue.hip.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "igemm_halo_body.hip.h"
 
-namespace {
-
-constexpr int TH = 8, TW = 32;
-// Geometry of the two tap sets. 3 x 3: patch (8+2) x (32+2) = 340 pixels = 22 1-KiB DMA pieces (16 patch rows each), every wave
-// issues 6 so the vmcnt arithmetic is uniform (pieces 22, 23 copy the zero page to a dummy KiB), weight ring 3 deep (9 % 3 == 0:
-// stage = tap % 3). 2 x 2 (phase-decomposed upsampling): patch 9 x 33 = 297 pixels = 19 pieces, 5 per wave, ring 4 deep (stage = tap).
-template <int TAPS> struct HaloGeo {
-    static constexpr int KS = TAPS == 9 ? 3 : 2;
-    static constexpr int PW = TW + KS - 1, PH = TH + KS - 1, PROWS = PH * PW;
-    static constexpr int APIECES = (PROWS + 15) / 16, APW = (APIECES + 3) / 4;
-    static constexpr int A_BYTES = APIECES * 1024;
-    static constexpr int NB = TAPS == 9 ? 3 : 4;
-    static constexpr int DUMMY_OFF = 2 * A_BYTES, B_OFF = DUMMY_OFF + 2048;
-    static constexpr int LDS_BYTES = B_OFF + NB * 128 * 64;
-};
-constexpr int BN = 128, B_BYTES = BN * 64, BPW = 2;       // BN / B_BYTES: the wide shape; the narrow one uses 2 KB of each stage
-constexpr int LDS_BYTES = HaloGeo<9>::LDS_BYTES > HaloGeo<4>::LDS_BYTES ? HaloGeo<9>::LDS_BYTES : HaloGeo<4>::LDS_BYTES;   // <= 72 KB: two workgroups per CU
-static_assert(HaloGeo<9>::APIECES == 22 && HaloGeo<9>::APW == 6 && HaloGeo<4>::APIECES == 19 && HaloGeo<4>::APW == 5, "piece counts");
-
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page_h[4] = {0u, 0u, 0u, 0u};
-
-OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
-
-// PRIO: raise the wave's priority around its MFMA cluster. Measured +6..10 % on K-heavy layers (Cin >= 512) and
-// -3..5 % on the epilogue-heavy 128/256-channel layers with row-major weights; with the slice-major packing it no longer
-// pays anywhere (S-1024 step 136.3 with it on Cin >= 384, 135.7 without): off by default, OMGSR_HALO_PRIO_CIN=<n> for A/B.
-// NARROW: Cout <= 32 (the VAE's conv_out, 128 -> 3): the four waves split the 8 tile rows (2 each) over ONE 32-column
-// fragment instead of 2 x 2 waves over 128 columns. The im2col kernels gather every input pixel nine times out of L2
-// (3.2 GB for a 1.4 MPixel x 128-channel map: 350 us, L2-bound at 70 TFLOP/s); here the patch is read once.
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9>
-__global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
-    constexpr int WTN = NARROW ? 32 : 64, FM = NARROW ? 2 : 4, FN = NARROW ? 1 : 2, BNK = NARROW ? 32 : 128;
-    using HG = HaloGeo<TAPS>;
-    constexpr int KS = HG::KS, PW = HG::PW, PROWS = HG::PROWS, APIECES = HG::APIECES, APW = HG::APW, A_BYTES = HG::A_BYTES;
-    constexpr int NB = HG::NB, DUMMY_OFF = HG::DUMMY_OFF, B_OFF = HG::B_OFF;
-    constexpr bool PHASE = TAPS == 4;
-    static_assert(!(PHASE && NARROW), "the phase-decomposed form has no narrow shape");
-    const int ph_a = PHASE ? (int)(blockIdx.y >> 1) : 0, ph_b = PHASE ? (int)(blockIdx.y & 1) : 0;    // output phase (row, column parity)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = NARROW ? wave : (wave >> 1), wn = NARROW ? 0 : (wave & 1);
-
-    const int tile = xcd_remap(blockIdx.x, g.ntm * g.ntn);
-    const int tn = tile % g.ntn, tm = tile / g.ntn;
-    const int per_img = g.tiles_x * g.tiles_y;
-    const int img = tm / per_img;
-    const int trem = tm - img * per_img;
-    const int ty = trem / g.tiles_x, tx = trem - ty * g.tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BNK;
-
-    const T* __restrict__ in = (const T*)p.in;
-    // phase form: weight_ph holds the four phase-summed 2 x 2 kernels back to back, [4][Cin/32][4 taps][Cout_pad][32]
-    const T* __restrict__ wt = PHASE ? (const T*)p.weight_ph + (int64_t)blockIdx.y * (p.Cin / 32) * 4 * p.Cout_pad * 32 : (const T*)p.weight_cm;
-    typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
-    const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;
-
-    const int lrow = lane >> 2;
-    const int kc = (lane & 3) ^ ((lane >> 4) & 3);           // source chunk for LDS position (lane & 3)
-
-    // A patch pieces: piece j = wave*6 + i covers patch rows [16j, 16j+16); patch row -> (py, px)
-    const unsigned char* a_ptr[APW];
-    int a_inc[APW];
-    const int ild = p.in_ld > 0 ? p.in_ld : p.Cin;      // physical channels per pixel row
-    const int wrap_at = ild / 32;                       // chunk index at which the patch pointer returns to channel 0 (w_lo segment)
-#pragma unroll
-    for (int i = 0; i < APW; ++i) {
-        const int pr = 16 * (wave * APW + i) + lrow;
-        const int py = pr / PW, px = pr - py * PW;
-        // (vy, vx): coordinates in the virtual (optionally nearest-2x upsampled) input = output coordinates; phase form: the tile
-        // lives on the LOW-res grid and phase (a, b) reads input rows y - 1 + a, y + a (columns likewise)
-        const int vy = y0 - 1 + (PHASE ? ph_a : 0) + py, vx = x0 - 1 + (PHASE ? ph_b : 0) + px;
-        const bool ok = (wave * APW + i) < APIECES && pr < PROWS && (unsigned)vy < (unsigned)(PHASE ? p.H : p.Ho) && (unsigned)vx < (unsigned)(PHASE ? p.W : p.Wo);
-        const int iy = PHASE ? vy : (vy >> p.upsample), ix = PHASE ? vx : (vx >> p.upsample);
-        const int64_t pix = ((int64_t)img * p.H + iy) * p.W + ix;
-        a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * ild + kc * 8)
-                      : reinterpret_cast<const unsigned char*>(g_zero_page_h);
-        a_inc[i] = ok ? 64 : 0;
-    }
-    const unsigned char* b_ptr[BPW];
-#pragma unroll
-    for (int i = 0; i < BPW; ++i)       // narrow shape: only pieces 0, 1 are real, the rest copy the zero page to the dummy KiB (uniform vmcnt arithmetic)
-        b_ptr[i] = (wave * BPW + i) * 16 < BNK
-                       ? reinterpret_cast<const unsigned char*>(wt + (int64_t)(n0 + 16 * (wave * BPW + i) + lrow) * 32 + kc * 8)
-                       : reinterpret_cast<const unsigned char*>(g_zero_page_h);
-    const int64_t b_step = (int64_t)p.Cout_pad * 64;       // bytes between consecutive (chunk, tap) slices
-
-    auto issue_a = [&](int buf, const int chunk) {
-        if (chunk == wrap_at) {
-#pragma unroll
-            for (int i = 0; i < APW; ++i) a_ptr[i] -= (int64_t)a_inc[i] * wrap_at;
-        }
-#pragma unroll
-        for (int i = 0; i < APW; ++i) {
-            const int piece = wave * APW + i;
-            const unsigned dst = piece < APIECES ? lds_base + buf * A_BYTES + piece * 1024
-                                                 : lds_base + DUMMY_OFF + (piece - APIECES) * 1024;
-            glds16(a_ptr[i], __builtin_amdgcn_readfirstlane(dst));
-            a_ptr[i] += a_inc[i];
-        }
-    };
-    auto issue_b = [&](int stage) {
-        const unsigned dst = lds_base + B_OFF + stage * B_BYTES + (wave * BPW) * 1024;
-#pragma unroll
-        for (int i = 0; i < BPW; ++i) {
-            const bool real = (wave * BPW + i) * 16 < BNK;
-            glds16(b_ptr[i], __builtin_amdgcn_readfirstlane(real ? dst + i * 1024 : lds_base + DUMMY_OFF));
-            if (real) b_ptr[i] += b_step;
-        }
-    };
-
-    f32x16_t acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int ncc = g.nk;                  // 32-channel chunks
-    const int nsteps = ncc * TAPS;         // >= TAPS
-
-    // The first versions of this loop were instruction-issue bound (profiles/r01_pmc_igemm.md §6: 5.3 VALU +
-    // 4.4 SALU per MFMA, mostly LDS address arithmetic and tap bookkeeping). Everything is now static:
-    //   * the 9 taps are unrolled; the weight-ring stage of step (cc, tap) is tap % 3 because 9 % 3 == 0
-    //   * chunks are unrolled by 2 so the patch buffer parity is an immediate offset
-    //   * the swizzled LDS offset of each lane's A fragment is precomputed per (tap, tile row): 36 VGPRs;
-    //     the second half-K fragment is the same address ^ 32
-    const int frow = lane & 31;
-    const int half = lane >> 5;
-    const int bsw = (frow >> 2) & 3;
-    const int boff0 = (wn * WTN) * 64 + frow * 64 + ((half) ^ bsw) * 16;
-    const int boff1 = (wn * WTN) * 64 + frow * 64 + ((2 + half) ^ bsw) * 16;
-    int aoff[TAPS][FM];
-#pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int row = (FM * wm + i) * PW + frow + (tp / KS) * PW + (tp % KS);
-            aoff[tp][i] = row * 64 + ((half ^ ((row >> 2) & 3)) << 4);
-        }
-
-    if constexpr (ABL != 2) {
-        issue_a(0, 0);
-        issue_b(0);
-        issue_b(1);
-    }
-
-    // one K-step with compile-time tap and patch parity
-    auto step = [&](auto tap_c, auto par_c, const int cc, const int s) {
-        constexpr int tap = decltype(tap_c)::value, par = decltype(par_c)::value;
-        // wait for slice s: only what the PREVIOUS step issued may still be in flight. lgkmcnt(0): every fragment read of the
-        // previous step has RETURNED before this wave passes the barrier that lets the others overwrite that stage - hipcc
-        // is free to sink MFMAs (and the lgkmcnt wait in front of them) below the barrier, and a ds_read still queued
-        // there raced the next LDS-DMA write about once per 10^5 tiles (one wave, a few weight rows of one K-step: found by
-        // the bit-repeatability test; the s_setprio variant pins the MFMAs and never showed it)
-        if constexpr (ABL == 2) {
-        } else if constexpr (tap == 1) {
-            // the previous step (tap 0) issued the next chunk's patch (APW pieces) and one weight slice (2)
-            if (cc + 1 < ncc) { if constexpr (APW == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        } else if constexpr (tap == TAPS - 1) {
-            if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // LATE: this step's LDS-DMA pieces are issued after the first half of its MFMAs instead of in front of them, so their
-        // issue slots (60-185 cycles per piece) overlap matrix-pipe time: +1.5...3 % on every VAE shape (profiles/r02_halo_late.md;
-        // ABL 5 = the early schedule, OMGSR_HALO_VARIANT=0, for A/B). Safe: the stage they fill was last read in the previous
-        // step, and every wave passed this step's barrier with those reads retired (lgkmcnt(0) above).
-        constexpr bool LATE = (ABL == 0) && !PRIO && !NARROW;
-        auto issue_dma = [&]() {
-            if constexpr (ABL != 2) {
-                if constexpr (tap == 0) { if (cc + 1 < ncc) issue_a(par ^ 1, cc + 1); }
-                if (s + 2 < nsteps) issue_b((tap + 2) % NB);
-            }
-        };
-        if constexpr (!LATE) issue_dma();
-        if constexpr (ABL == 3) return;
-
-        const unsigned char* As = lds + par * A_BYTES;
-        const unsigned char* Bs = lds + B_OFF + (tap % NB) * B_BYTES;
-        x8_t<T> af[2][FM], bf[2][FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            af[0][i] = *reinterpret_cast<const x8_t<T>*>(As + aoff[tap][i]);
-            af[1][i] = *reinterpret_cast<const x8_t<T>*>(As + (aoff[tap][i] ^ 32));
-        }
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            bf[0][j] = *reinterpret_cast<const x8_t<T>*>(Bs + j * 32 * 64 + boff0);
-            bf[1][j] = *reinterpret_cast<const x8_t<T>*>(Bs + j * 32 * 64 + boff1);
-        }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);   // transposed tile
-            if constexpr (LATE) {
-                if (ks == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_dma();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-    };
-    auto chunk = [&](auto par_c, const int cc) {
-        const int s0 = cc * TAPS;
-        step(std::integral_constant<int, 0>{}, par_c, cc, s0 + 0);
-        step(std::integral_constant<int, 1>{}, par_c, cc, s0 + 1);
-        step(std::integral_constant<int, 2>{}, par_c, cc, s0 + 2);
-        step(std::integral_constant<int, 3>{}, par_c, cc, s0 + 3);
-        if constexpr (TAPS == 9) {
-            step(std::integral_constant<int, 4>{}, par_c, cc, s0 + 4);
-            step(std::integral_constant<int, 5>{}, par_c, cc, s0 + 5);
-            step(std::integral_constant<int, 6>{}, par_c, cc, s0 + 6);
-            step(std::integral_constant<int, 7>{}, par_c, cc, s0 + 7);
-            step(std::integral_constant<int, 8>{}, par_c, cc, s0 + 8);
-        }
-    };
-    for (int cc = 0; cc < ncc; cc += 2) {
-        chunk(std::integral_constant<int, 0>{}, cc);
-        if (cc + 1 < ncc) chunk(std::integral_constant<int, 1>{}, cc + 1);
-    }
-
-    int mb[FM], nv[FM];
-    int colsv = (PHASE ? p.W : p.Wo) - x0; colsv = colsv > TW ? TW : colsv;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int y = y0 + FM * wm + i;
-        // phase form: low-res pixel (y, x0 + j) of phase (a, b) is output pixel (2y + a, 2 (x0 + j) + b): stride 2 along the row
-        mb[i] = PHASE ? (img * p.Ho + 2 * y + ph_a) * p.Wo + 2 * x0 + ph_b : (img * p.Ho + y) * p.Wo + x0;
-        nv[i] = (y < (PHASE ? p.H : p.Ho)) ? colsv : 0;
-    }
-    if constexpr (ABL == 1) { if (p.alpha != 12345.0f) return; }      // timing experiment: no epilogue (never true at run time)
-    {
-        float* epi = reinterpret_cast<float*>(lds) + wave * 32 * (WTN + 4);
-        // fused GroupNorm statistics: slot = (spatial tile, upper / lower 4 tile rows), [N][2*tiles][G][2]
-        // ... phase form: four launches' worth of slots per spatial tile, [N][tiles][2][4 phases][G][2]
-        const int64_t slot = PHASE ? ((int64_t)(img * per_img + trem) * 2 + wm) * 4 + blockIdx.y : (int64_t)(img * per_img + trem) * 2 + wm;
-        float* gn_dst = (p.gn_partial && !NARROW) ? p.gn_partial + slot * p.gn_entries * 2 : nullptr;
-        igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0, gn_dst, 0, PHASE ? 2 : 1);
-    }
-}
-
-}  // namespace
-
+// This translation unit launches ONE problem per grid (igemm_halo_kernel). The several-problems-per-launch and mixed-precision
+// instantiations of the same body live in igemm_halo_multi.hip (two files so that hipcc compiles them in parallel).
 namespace omgsr {
 // Preconditions (checked by the dispatcher): R = S = 3, stride 1, pad 1 (on the virtual, optionally 2x-upsampled input), Cin % 32 == 0,
 // weight_cm != NULL, batch == 1, W >= 16.
@@ -304,52 +35,43 @@ static int prio_min_cin() {
     return v;
 }
 
+int igemm_halo_launch_mx(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
+int igemm_halo_launch_f16(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, bool phase, bool narrow);      // igemm_halo_f16.hip
+
+// one problem per grid, bf16 compute type (the fp16 instantiations are a translation unit of their own: hipcc compiles the files in parallel)
 int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, const bool phase) {
-    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
-    g.nk = a.Cin / 32;
-    g.tiles_x = ((phase ? a.W : a.Wo) + TW - 1) / TW;          // phase form: tiles of the LOW-res map, four phases each
-    g.tiles_y = ((phase ? a.H : a.Ho) + TH - 1) / TH;
-    g.ntm = a.N * g.tiles_x * g.tiles_y;
-    const bool narrow = logical_cols <= 32 && !phase;
-    g.ntn = narrow ? 1 : (logical_cols + BN - 1) / BN;
+    if (a.mx_chunks16 > 0) return igemm_halo_launch_mx(a, g, st);
+    const bool narrow = halo_geo(a, g, phase);
+    if (omgsr::compute_dtype() == 1) return igemm_halo_launch_f16(a, g, st, phase, narrow);
+    using T = bf16_t;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipSuccess;
-        const void* fns[] = {reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, false>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, true>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 1, false>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 2, false>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 3, false>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, true>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 1, false>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, false, true>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, true>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 5, false>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 5, false>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, false, false, 4>),
-                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, false, 4>)};
-        for (const void* f : fns)
-            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
+        const void* fns[] = {reinterpret_cast<const void*>(igemm_halo_kernel<T, 0, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<T, 0, true>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<T, 1, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<T, 2, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<T, 3, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<T, 0, false, true>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<T, 5, false>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<T, 0, false, false, 4>)};
+        const int rc = halo_set_lds_attr(fns, (int)(sizeof(fns) / sizeof(fns[0])));
+        if (rc != 0) return rc;
         attr_set = true;
     }
     dim3 grid(g.ntm * g.ntn, phase ? 4 : 1, 1);
-    if (phase) {
-        OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false, false, 4>), grid, dim3(256), LDS_BYTES, st, a, g));
-        return (int)hipGetLastError();
-    }
-    static const char* abl = ablation_env("OMGSR_HALO_ABLATE");      // timing experiments only: results are garbage (needs OMGSR_ABLATION_OK=1)
+    static const char* abl = ablation_env("OMGSR_HALO_ABLATE");      // timing experiments only: results are garbage (needs OMGSR_ABLATION_OK=1; bf16 only)
     static const char* var = getenv("OMGSR_HALO_VARIANT");     // A/B runs: "0" = LDS-DMA issued in front of the step's MFMAs
-    if (var && var[0] == '0' && !narrow) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 5, false>), grid, dim3(256), LDS_BYTES, st, a, g));
-    else if (abl && abl[0] == '1') OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 1, false>), grid, dim3(256), LDS_BYTES, st, a, g));
-    else if (abl && abl[0] == '2') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 2, false>), grid, dim3(256), LDS_BYTES, st, a, g);
-    else if (abl && abl[0] == '3') hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 3, false>), grid, dim3(256), LDS_BYTES, st, a, g);
-    else if (narrow) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false, true>), grid, dim3(256), LDS_BYTES, st, a, g));
-    else if (a.Cin >= prio_min_cin()) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, true>), grid, dim3(256), LDS_BYTES, st, a, g));
-    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false>), grid, dim3(256), LDS_BYTES, st, a, g));
+    if (phase) hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false, false, 4>), grid, dim3(256), LDS_BYTES, st, a, g);
+    else if (var && var[0] == '0' && !narrow) hipLaunchKernelGGL((igemm_halo_kernel<T, 5, false>), grid, dim3(256), LDS_BYTES, st, a, g);
+    else if (abl && abl[0] == '1') hipLaunchKernelGGL((igemm_halo_kernel<T, 1, false>), grid, dim3(256), LDS_BYTES, st, a, g);
+    else if (abl && abl[0] == '2') hipLaunchKernelGGL((igemm_halo_kernel<T, 2, false>), grid, dim3(256), LDS_BYTES, st, a, g);
+    else if (abl && abl[0] == '3') hipLaunchKernelGGL((igemm_halo_kernel<T, 3, false>), grid, dim3(256), LDS_BYTES, st, a, g);
+    else if (narrow) hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false, true>), grid, dim3(256), LDS_BYTES, st, a, g);
+    else if (a.Cin >= prio_min_cin()) hipLaunchKernelGGL((igemm_halo_kernel<T, 0, true>), grid, dim3(256), LDS_BYTES, st, a, g);
+    else hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false>), grid, dim3(256), LDS_BYTES, st, a, g);
     return (int)hipGetLastError();
 }
+
 int igemm_halo_gn_slots(const omgsr_igemm_args& a, const bool phase) {
     if (phase) return 2 * 4 * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     return 2 * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);

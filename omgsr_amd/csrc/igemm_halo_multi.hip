@@ -1,0 +1,52 @@
+// The halo-tile kernel body (igemm_halo_body.hip.h) as (1) igemm_halo_multi_kernel: several problems that share weights and epilogue
+// options in ONE launch (the tiled VAE's tile-shape groups: corner / edge / interior tiles are separate dense tensors); (2) the
+// mixed-precision instantiations (fp16 chunks + block-scaled fp8 chunks of an OMGSR_EL_MX operand) are in igemm_halo_mx.hip.
+#include "igemm_halo_body.hip.h"
+
+namespace omgsr {
+static int multi_attrs() {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void* fns[] = {reinterpret_cast<const void*>(igemm_halo_multi_kernel<bf16_t, false, 9>),
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 9>),
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<bf16_t, true, 9>),
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, true, 9>),
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<bf16_t, false, 4>),
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 4>)};
+        const int rc = halo_set_lds_attr(fns, (int)(sizeof(fns) / sizeof(fns[0])));
+        if (rc != 0) return rc;
+        attr_set = true;
+    }
+    return 0;
+}
+
+int igemm_halo_launch_multi_mx(const void* halo_multi, unsigned blocks, hipStream_t st);       // igemm_halo_mx.hip (HaloMulti has no linkage: same header, opaque pointer)
+
+// `count` problems (<= HALO_MULTI_MAX) in one launch; all of them take the same kernel shape (the caller checks: same weights,
+// Cin / Cout, epilogue options; `phase`, narrow-ness and the mixed-precision form therefore agree). The workgroup looks its problem up
+// in a prefix table of tile counts; each problem's range starts on a multiple of 8 blocks so the XCD remap of its local index keeps
+// its meaning (the filler blocks exit).
+int igemm_halo_launch_multi(const omgsr_igemm_args* a, const IgemmGeo* g0, const int count, hipStream_t st, const bool phase) {
+    HaloMulti m;
+    m.count = count;
+    int at = 0;
+    bool narrow = false;
+    for (int i = 0; i < count; ++i) {
+        m.p[i] = a[i];
+        m.g[i] = g0[i];
+        narrow = halo_geo(a[i], m.g[i], phase);
+        m.start[i] = at;
+        at += (m.g[i].ntm * m.g[i].ntn + 7) & ~7;
+    }
+    m.start[count] = at;
+    const int rc = multi_attrs();
+    if (rc != 0) return rc;
+    dim3 grid(at, phase ? 4 : 1, 1);
+    if (a[0].mx_chunks16 > 0) return igemm_halo_launch_multi_mx(&m, (unsigned)at, st);
+    if (phase) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_multi_kernel<T, false, 4>), grid, dim3(256), LDS_BYTES, st, m));
+    else if (narrow) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_multi_kernel<T, true, 9>), grid, dim3(256), LDS_BYTES, st, m));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_multi_kernel<T, false, 9>), grid, dim3(256), LDS_BYTES, st, m));
+    return (int)hipGetLastError();
+}
+
+}  // namespace omgsr

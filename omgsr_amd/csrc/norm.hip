@@ -216,6 +216,11 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
             f[e] = (act == OMGSR_ACT_SILU) ? silu_f(v) : v;
         }
     };
+    // YEL 3 = OMGSR_EL_MX: [hi fp16 | lo' fp8 | hi' fp8], 4C bytes per pixel (common.hip.h store8_mx)
+    auto put = [&](const int64_t pix, const int cc8, const float (&v)[8]) {
+        if constexpr (YEL == 3) store8_mx<T>(y, pix * 4 * C, C, cc8 * 8, v);
+        else store8<T, YEL>(y, pix * ldy + cc8 * 8, C, v);
+    };
     // two chunks (4 x 16-byte loads of an fp32 row) in flight per thread
     int i = t;
     for (; i + 256 < total; i += 512) {
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
         }
         transform(f, c8);
         transform(h, c8b);
-        store8<T, YEL>(y, (pix0 + px) * ldy + c8 * 8, C, f);
-        store8<T, YEL>(y, (pix0 + pxb) * ldy + c8b * 8, C, h);
+        put(pix0 + px, c8, f);
+        put(pix0 + pxb, c8b, h);
         c8 = c8b; px = pxb;
         advance(c8, px);
     }
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
         load8<T, XF32>(x, (pix0 + px) * C + c8 * 8, f);
         if constexpr (Y2EL >= 0) { note8(f); store8<T, Y2EL>(y2, (pix0 + px) * (Y2EL == 2 ? 2 * C : C) + c8 * 8, C, f); }
         transform(f, c8);
-        store8<T, YEL>(y, (pix0 + px) * ldy + c8 * 8, C, f);
+        put(pix0 + px, c8, f);
         advance(c8, px);
     }
     if constexpr (Y2EL >= 0 && std::is_same<T, f16_t>::value) {
@@ -606,7 +611,8 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
                     const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, int32_t x_el,
                     int32_t y_el, void* y2, int32_t y2_el, uint32_t* ovf, void* stream) {
     if (!x || !y || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
-    if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT)) return OMGSR_E_BADARG;
+    if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT && y_el != OMGSR_EL_MX)) return OMGSR_E_BADARG;
+    if (y_el == OMGSR_EL_MX && ((C & 63) || omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;        // fp16 compute type, whole 64-channel fp8 chunks
     if (y2 && (x_el != OMGSR_EL_F32 || (y2_el != OMGSR_EL_16 && y2_el != OMGSR_EL_SPLIT))) return OMGSR_E_BADARG;
     if ((C & 7) || (C % G) || C > 8192) return OMGSR_E_SHAPE;
     if (act != OMGSR_ACT_NONE && act != OMGSR_ACT_SILU) return OMGSR_E_BADARG;
@@ -617,13 +623,19 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
     int64_t ppb = (belems + C - 1) / C;      // ~32 KB of activations per block (5.6 TB/s; 64 KB 5.4, 128 KB 4.9, 256 KB 30 % slower)
     if (ppb < 1) ppb = 1;
     const int nblk = (int)((HW + ppb - 1) / ppb);
-    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, ((x_el == OMGSR_EL_F32 ? 4.0 : 2.0) + (y_el == OMGSR_EL_SPLIT ? 4.0 : 2.0) +
+    omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, ((x_el == OMGSR_EL_F32 ? 4.0 : 2.0) + (y_el == OMGSR_EL_16 ? 2.0 : 4.0) +
                                              (y2 ? (y2_el == OMGSR_EL_SPLIT ? 4.0 : 2.0) : 0.0)) * N * (double)HW * C, st);
     const size_t lds = 2 * C * sizeof(float);
     const dim3 grid(nblk, N);
 #define OMGSR_GN_ANY2(YE, Y2) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, true, YE, Y2>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf))
 #define OMGSR_GN_ANY(XF, YE) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, XF, YE>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows))
-    if (y2) {
+    if (y_el == OMGSR_EL_MX) {
+        using T = f16_t;
+        if (y2 && y2_el == OMGSR_EL_SPLIT) hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 3, 2>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf);
+        else if (y2) hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 3, 0>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf);
+        else if (x_el == OMGSR_EL_F32) hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 3>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, nullptr, nullptr);
+        else hipLaunchKernelGGL((gn_apply_any_kernel<T, false, 3>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, nullptr, nullptr);
+    } else if (y2) {
         if (y_el == OMGSR_EL_SPLIT && y2_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY2(2, 2);
         else if (y_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY2(2, 0);
         else if (y2_el == OMGSR_EL_SPLIT) OMGSR_GN_ANY2(0, 2);

@@ -104,6 +104,16 @@ class Conv2d(nn.Conv2d, _Packed, _Operand):
         return ops.conv2d(x, pw, stride=stride or self.stride[0], pad=p, upsample=upsample, act=act, residual=residual,
                           gn_groups=gn_groups, out_dtype=out_dtype, out_split=out_split)
 
+    def nhwc_multi(self, xs, *, pad=None, upsample=False, act=ops.ACT_NONE, residuals=None, stride=None, gn_groups=0,
+                   out_dtype=ops.OUT_STREAM, out_split=1):
+        """nhwc() of several inputs (the tile-shape groups of a tiled-VAE layer) in one launch where the kernel allows (ops.conv2d_multi)."""
+        pw = self.packed()
+        p = self.padding[0] if pad is None else pad
+        if out_dtype == ops.OUT_STREAM and self.out_inner16 and ops.precise():
+            out_dtype = ops.OUT_BF16
+        return ops.conv2d_multi(list(xs), pw, stride=stride or self.stride[0], pad=p, upsample=upsample, act=act, residuals=residuals,
+                                gn_groups=gn_groups, out_dtype=out_dtype, out_split=out_split)
+
     def forward(self, x):  # NCHW compat
         y = self.nhwc(ops.nchw_to_nhwc(x.contiguous(), ops._round_up(self.in_channels, 8)))
         return ops.nhwc_to_nchw(y, channels=self.out_channels,

@@ -26,7 +26,14 @@ from ._lib import AttnArgs, IgemmArgs, check
 ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_GEGLU = 0, 1, 2, 3
 OUT_STREAM, OUT_BF16, OUT_F32 = -1, 0, 1      # conv / linear outputs: stream tensor (default) | 16-bit operand | fp32
 LAYOUT_NHWC, LAYOUT_T = 0, 1
-EL_16, EL_F32, EL_SPLIT = 0, 1, 2
+EL_16, EL_F32, EL_SPLIT, EL_MX = 0, 1, 2, 3
+MX_LO_SHIFT = 11          # OMGSR_MX_LO_SHIFT (csrc/common.hip.h): a_lo' = (a - a_hi) * 2^11 as fp8
+
+
+def _el_of_split(split: int) -> int:
+    """Operand form of a `split` code: 1 plain, 2 two-term split [hi | lo] (both fp16), 3 the mixed-precision form
+    [hi fp16 | lo' fp8 | hi' fp8] (OMGSR_EL_MX: same row width as 2, its correction segments run as block-scaled fp8 MFMAs)."""
+    return {1: EL_16, 2: EL_SPLIT, 3: EL_MX}[split]
 
 
 _ACT = torch.bfloat16
@@ -192,7 +199,9 @@ class PackedWeight:
     S: int
     geglu: bool = False
     w_cm: Optional[torch.Tensor] = None   # chunk-major second packing (3x3, Cin % 32 == 0): halo-tile kernel
-    split: int = 1     # 2: the input is a two-term split operand [hi | lo]: every input channel packed twice ([w | w])
+    split: int = 1     # 2: the input is a two-term split operand [hi | lo]: every input channel packed twice ([w | w]);
+                       # 3: the mixed-precision form (OMGSR_EL_MX operand; fp16 [w_hi] + fp8 [w_hi' | w_lo'] per tap, `mx`)
+    mx: Optional[tuple] = None      # split 3: (fp16 chunks per tap, E8M0 scale of w_hi', of a_lo', of w_lo', of a_hi')
     w_split: int = 1   # 2: the weight itself is carried as w_hi + w_lo: one more K segment [w_lo] that re-reads the operand's
                        # first (hi) half - the contraction WRAPS (omgsr_igemm_args.in_ld); `cin` counts every segment
     in_ld: int = 0     # physical channels of the operand row this weight expects (split * padded Cin); 0 = cin
@@ -221,6 +230,38 @@ def _segments(w: torch.Tensor, split: int, w_split: int) -> torch.Tensor:
     if w_split == 2:
         segs.append((w - w_hi).to(act_dtype()).float())      # ... and the operand's hi half meets the weights' low halves
     return torch.cat(segs, dim=-1) if len(segs) > 1 else w_hi
+
+
+def _fp8_scaled(t: torch.Tensor):
+    """t fp32 -> (uint8 e4m3 bytes of t * 2^s, E8M0 byte 127 - s) with s chosen so that max |t| * 2^s lies in [128, 256) (e4m3 tops out at
+    448; its 17 binades below that cover weights 5 orders of magnitude under the largest)."""
+    import math
+    m = float(t.abs().max())
+    s = 7 - math.floor(math.log2(m)) if m > 0 else 0
+    s = max(-100, min(100, s))
+    q = (t * (2.0 ** s)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), 127 - s
+
+
+def _pack_mx(w: torch.Tensor, bias, cout: int, cin: int, R: int, S: int, dev) -> "PackedWeight":
+    """[Cout, R, S, C] fp32 -> the mixed-precision weight of an OMGSR_EL_MX operand: per tap 4C bytes = 2C 16-bit slots,
+    [w_hi fp16 (2C B) | w_hi' fp8 (C B) | w_lo' fp8 (C B)] with w_hi = fp16(w), w_hi' = fp8(w_hi 2^s1), w_lo' = fp8((w - w_hi) 2^s2): the
+    first C / 32 chunks meet a_hi in fp16 MFMAs, then C / 64 fp8 chunks meet a_lo' (w_hi') and C / 64 meet a_hi' (w_lo') in block-scaled
+    fp8 MFMAs whose E8M0 scale operands undo s1 / s2 and the operand's 2^11."""
+    if R != 3 or S != 3 or cin % 64 or act_dtype() != torch.float16:
+        raise ValueError("the mixed-precision (MX) form serves 3x3 convolutions with Cin % 64 == 0 in the fp16 compute type")
+    w_hi = w.to(torch.float16)
+    hi8, e_w1 = _fp8_scaled(w_hi.float())
+    lo8, e_w2 = _fp8_scaled(w - w_hi.float())
+    rows = torch.cat([w_hi.contiguous().view(torch.uint8).reshape(cout, R, S, 2 * cin), hi8.reshape(cout, R, S, cin), lo8.reshape(cout, R, S, cin)], dim=-1)
+    kslots = 2 * cin                                           # 16-bit slots per tap
+    cout_pad = _round_up(cout, 256 if cout >= 256 else 128)
+    out = torch.zeros((cout_pad, R * S * kslots), device=dev, dtype=torch.float16)
+    out[:cout] = rows.reshape(cout, R * S * 4 * cin).contiguous().view(torch.float16)
+    w_cm = out.view(cout_pad, 9, kslots // 32, 32).permute(2, 1, 0, 3).contiguous()
+    b = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
+    return PackedWeight(out, b, cout, kslots, R, S, w_cm=w_cm, split=3, w_split=1, in_ld=kslots,
+                        mx=(cin // 32, e_w1, 127 - MX_LO_SHIFT, e_w2, 127))
 
 
 def _phase_kernels(w: torch.Tensor) -> torch.Tensor:
@@ -264,6 +305,10 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
     w = weight.detach().to(device=dev, dtype=torch.float32).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
     if cin8 != cin:
         w = torch.nn.functional.pad(w, (0, cin8 - cin))
+    if split == 3:
+        if cin8 != cin:
+            raise ValueError("the mixed-precision (MX) form needs Cin % 64 == 0")
+        return _pack_mx(w, bias if bias is None else bias.detach().to(dev), cout, cin, R, S, dev)
     if split not in (1, 2) or w_split not in (1, 2):
         raise ValueError("split / w_split must be 1 or 2")
     in_ld = cin8 * split
@@ -326,8 +371,8 @@ def to_operand(x: torch.Tensor, split: int = 1) -> torch.Tensor:
         return x
     _req(x, torch.float32, "x")
     Cc = x.shape[-1]
-    y = torch.empty((*x.shape[:-1], split * Cc), device=x.device, dtype=_ACT)
-    check(_lib.load().omgsr_to_operand(x.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc, EL_SPLIT if split == 2 else EL_16, _ovf(x.device),
+    y = torch.empty((*x.shape[:-1], min(split, 2) * Cc), device=x.device, dtype=_ACT)
+    check(_lib.load().omgsr_to_operand(x.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc, _el_of_split(split), _ovf(x.device),
                                        _stream()), "omgsr_to_operand")
     return y
 
@@ -347,8 +392,10 @@ def _fill_k(a: IgemmArgs, pw: PackedWeight) -> None:
     a.Cin = pw.cin
     a.overflow_flag = _ovf(pw.w.device)
     a.in_ld = pw.row_channels if pw.row_channels != pw.cin else 0
-    a.in_split = int(pw.split == 2)
+    a.in_split = int(pw.split >= 2)            # split 3 (MX): 2C slots per tap for C logical channels, like the two-term split
     a.w_split = int(pw.w_split == 2)
+    if pw.mx is not None:
+        a.mx_chunks16, a.mx_scale_w1, a.mx_scale_a1, a.mx_scale_w2, a.mx_scale_a2 = pw.mx
 
 
 def _fill_out(a: IgemmArgs, out: torch.Tensor, out_split: int, residual: Optional[torch.Tensor], cout: int) -> None:
@@ -360,15 +407,9 @@ def _fill_out(a: IgemmArgs, out: torch.Tensor, out_split: int, residual: Optiona
         a.res_el = _el(residual, "residual")
 
 
-def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, int, int] | int = 1,
-           upsample: bool = False, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
-           gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_STREAM, alpha: float = 1.0,
-           out: Optional[torch.Tensor] = None, gn_groups: int = 0, out_split: int = 1, sample_rows: int = 0) -> torch.Tensor:
-    """x [N,H,W,Cin] operand (or a stream tensor: cast / split here) -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on
-    the (virtual) input. out_dtype: OUT_STREAM (a stream tensor: default), OUT_BF16 (a 16-bit operand for the next GEMM,
-    `out_split` 2 = written as the two-term split) or OUT_F32. residual: a stream tensor of the output's shape.
-    gn_groups > 0: the caller will GroupNorm the result with that many groups; when the kernel can, it emits the
-    (sum, sum of squares) partials from its epilogue and group_norm_stats() skips its read pass over the tensor."""
+def _conv_args(a: IgemmArgs, x: torch.Tensor, pw: PackedWeight, stride, pad, upsample, act, residual, gate, out_dtype, alpha, out, out_split,
+               sample_rows):
+    """Fill `a` for one conv problem; returns (x as operand, out). Keep both alive until the launch."""
     if x.dtype == torch.float32:
         x = to_operand(x, pw.split)
     _req(x, act_dtype(), "x")
@@ -387,7 +428,6 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
         out = _out_tensor((N, Ho, Wo), pw.cout, out_dtype, out_split, x.device)
     if residual is not None and tuple(residual.shape) != (N, Ho, Wo, pw.cout):
         raise ValueError(f"residual shape {tuple(residual.shape)} != output {(N, Ho, Wo, pw.cout)}")
-    a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate = x.data_ptr(), pw.w.data_ptr(), _ptr(pw.bias), _ptr(gate)
     _fill_out(a, out, out_split, residual, pw.cout)
     a.weight_cm = _ptr(pw.w_cm)
@@ -403,20 +443,74 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     a.batch, a.in_bstride, a.w_bstride, a.out_bstride = 1, 0, 0, 0
     a.alpha = alpha
     a.sample_rows = sample_rows or Ho * Wo
-    partial = None
-    if gn_groups > 0 and out_split == 1:
-        a.gn_groups = gn_groups
-        lib = _lib.load()
-        # a problem that _igemm will split over K (it hands over the workspace) finishes in the reduce pass: no statistics there
-        nslot = 0 if lib.omgsr_igemm_workspace_bytes(C.byref(a)) > 0 else lib.omgsr_igemm_gn_slots(C.byref(a))
-        if nslot > 0:
-            a.gn_entries = lib.omgsr_igemm_gn_entries(C.byref(a))       # per group, or per channel for odd group sizes
-            partial = torch.empty((N, nslot, a.gn_entries, 2), device=x.device, dtype=torch.float32)
-            a.gn_partial = partial.data_ptr()
+    return x, out
+
+
+def _conv_gn(a: IgemmArgs, gn_groups: int, out_split: int, device):
+    """Ask the library whether this problem's epilogue can leave the GroupNorm statistics; allocates the partials if so."""
+    if gn_groups <= 0 or out_split != 1:
+        return None
+    a.gn_groups = gn_groups
+    lib = _lib.load()
+    # a problem that will be split over K (it is handed the workspace) finishes in the reduce pass: no statistics there
+    nslot = 0 if lib.omgsr_igemm_workspace_bytes(C.byref(a)) > 0 else lib.omgsr_igemm_gn_slots(C.byref(a))
+    if nslot <= 0:
+        return None
+    a.gn_entries = lib.omgsr_igemm_gn_entries(C.byref(a))       # per group, or per channel for odd group sizes
+    partial = torch.empty((a.N, nslot, a.gn_entries, 2), device=device, dtype=torch.float32)
+    a.gn_partial = partial.data_ptr()
+    return partial
+
+
+def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, int, int] | int = 1,
+           upsample: bool = False, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
+           gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_STREAM, alpha: float = 1.0,
+           out: Optional[torch.Tensor] = None, gn_groups: int = 0, out_split: int = 1, sample_rows: int = 0) -> torch.Tensor:
+    """x [N,H,W,Cin] operand (or a stream tensor: cast / split here) -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on
+    the (virtual) input. out_dtype: OUT_STREAM (a stream tensor: default), OUT_BF16 (a 16-bit operand for the next GEMM,
+    `out_split` 2 = written as the two-term split) or OUT_F32. residual: a stream tensor of the output's shape.
+    gn_groups > 0: the caller will GroupNorm the result with that many groups; when the kernel can, it emits the
+    (sum, sum of squares) partials from its epilogue and group_norm_stats() skips its read pass over the tensor."""
+    a = IgemmArgs()
+    x, out = _conv_args(a, x, pw, stride, pad, upsample, act, residual, gate, out_dtype, alpha, out, out_split, sample_rows)
+    partial = _conv_gn(a, gn_groups, out_split, x.device)
     _igemm(a, x.device, "omgsr_igemm(conv2d)")
     if partial is not None:
         out._omgsr_gn = (partial, gn_groups, out.data_ptr(), out._version)      # consumed by group_norm_stats(out)
     return out
+
+
+def conv2d_multi(xs, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, int, int] | int = 1, upsample: bool = False,
+                 act: int = ACT_NONE, residuals=None, out_dtype: int = OUT_STREAM, gn_groups: int = 0, out_split: int = 1):
+    """conv2d of several inputs with ONE weight (the tile-shape groups of a tiled-VAE layer: each x is its own dense [T*N, h, w, C]
+    tensor) through omgsr_igemm_multi: the problems that take the halo-tile kernel run as one launch, with the kernel choice and the
+    fused GroupNorm statistics planned for the group. Same results as a conv2d call per input. Returns the list of outputs."""
+    n = len(xs)
+    if n == 1:
+        return [conv2d(xs[0], pw, stride=stride, pad=pad, upsample=upsample, act=act, residual=None if residuals is None else residuals[0],
+                       out_dtype=out_dtype, gn_groups=gn_groups, out_split=out_split)]
+    lib = _lib.load()
+    arr = (IgemmArgs * n)()
+    keep, outs = [], []
+    for i in range(n):
+        x, out = _conv_args(arr[i], xs[i], pw, stride, pad, upsample, act, None if residuals is None else residuals[i], None, out_dtype, 1.0,
+                            None, out_split, 0)
+        keep.append(x)
+        outs.append(out)
+    check(lib.omgsr_igemm_multi_plan(arr, n), "omgsr_igemm_multi_plan")
+    partials = []
+    for i in range(n):
+        partials.append(_conv_gn(arr[i], gn_groups, out_split, outs[i].device))
+        need = lib.omgsr_igemm_workspace_bytes(C.byref(arr[i]))
+        if need > 0:
+            ws = torch.empty(need // 4, device=outs[i].device, dtype=torch.float32)
+            keep.append(ws)
+            arr[i].workspace = ws.data_ptr()
+    check(lib.omgsr_igemm_multi(arr, n, _stream()), "omgsr_igemm_multi(conv2d_multi)")
+    for out, partial in zip(outs, partials):
+        if partial is not None:
+            out._omgsr_gn = (partial, gn_groups, out.data_ptr(), out._version)
+    return outs
 
 
 def linear(x: torch.Tensor, pw: PackedWeight, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
@@ -680,9 +774,9 @@ def group_norm_stats_merged(tensors, tiles, N: int, groups: int, eps: float):
 
 
 def _operand_like(x: torch.Tensor, split: int) -> torch.Tensor:
-    if split not in (1, 2):
-        raise ValueError("split must be 1 or 2")
-    return torch.empty((*x.shape[:-1], x.shape[-1] * split), device=x.device, dtype=_ACT)
+    if split not in (1, 2, 3):
+        raise ValueError("split must be 1, 2 or 3 (MX)")
+    return torch.empty((*x.shape[:-1], x.shape[-1] * min(split, 2)), device=x.device, dtype=_ACT)
 
 
 def _cast_twin(x: torch.Tensor, xel: int, also_cast: int):
@@ -709,7 +803,7 @@ def group_norm_apply_shared(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Ten
     fused = y2 is not None and y2 is not x
     check(_lib.load().omgsr_groupnorm_apply_shared(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
                                                    _ptr(beta), rows, HW, Cc, groups, act, mean.shape[0], xel,
-                                                   EL_SPLIT if split == 2 else EL_16, y2.data_ptr() if fused else None,
+                                                   _el_of_split(split), y2.data_ptr() if fused else None,
                                                    EL_SPLIT if also_cast == 2 else EL_16, _ovf(x.device) if fused else None, _stream()),
           "omgsr_groupnorm_apply_shared")
     return (y, y2) if also_cast else y
@@ -727,7 +821,7 @@ def group_norm_apply(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, ga
     y2 = _cast_twin(x, xel, also_cast)
     fused = y2 is not None and y2 is not x
     check(_lib.load().omgsr_groupnorm_apply(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
-                                            _ptr(beta), N, HW, Cc, groups, act, xel, EL_SPLIT if split == 2 else EL_16,
+                                            _ptr(beta), N, HW, Cc, groups, act, xel, _el_of_split(split),
                                             y2.data_ptr() if fused else None, EL_SPLIT if also_cast == 2 else EL_16,
                                             _ovf(x.device) if fused else None, _stream()),
           "omgsr_groupnorm_apply")

@@ -4,7 +4,10 @@ with 288 GB of HBM:
 
   * the reference parks every tile but one on the CPU between its 22 (encoder) / 30 (decoder) GroupNorm
     barriers and walks a Python task queue per tile (PCIe-bound); here ALL tiles stay resident in HBM, tiles
-    of equal shape are stacked along the batch axis, and each layer runs as ONE kernel launch per shape group
+    of equal shape are stacked along the batch axis (one dense tensor per shape group: corner / edge / interior
+    tiles), and every conv layer runs as ONE launch over all groups (ops.conv2d_multi -> omgsr_igemm_multi: a
+    prefix table of the groups' tile counts in the kernel arguments) - no group pays its own partial last round
+    of workgroups, and small groups still take the halo-tile kernel
   * at every GroupNorm the per-tile (mean, biased var) come from the statistics kernel, are merged per image
     with pixel-count weights exactly like GroupNormParam.summary() (a weighted mean of variances, NOT the
     pooled variance), and the apply(+SiLU) kernel runs with the externally supplied statistics (eps 1e-6)
@@ -66,7 +69,8 @@ class VAEHook:
     # ---- op list (order of build_task_queue, infer/vaehook.py:332-359) ----------------------
     def _ops(self):
         net, dec = self.net, self.is_decoder
-        seq = [("f", lambda x: net.conv_in.nhwc(x, gn_groups=net.conv_norm_out.num_groups))]
+        # ("conv", module, kwargs): module.nhwc_multi over every shape group in one launch
+        seq = [("conv", net.conv_in, dict(gn_groups=net.conv_norm_out.num_groups))]
 
         # ("gn", norm, act, consumer): the normalised tensor is the consumer's MFMA operand (its in_split() picks the plain /
         # two-term split form in the accurate tier)
@@ -78,7 +82,7 @@ class VAEHook:
             if b.conv_shortcut is None:
                 seq.append(("res_push", None))
             seq.append(("gn", b.norm1, ops.ACT_SILU, b.conv1, b.conv_shortcut))
-            seq.append(("f", lambda x, b=b: b.conv1.nhwc(x, gn_groups=b.norm2.num_groups)))
+            seq.append(("conv", b.conv1, dict(gn_groups=b.norm2.num_groups)))
             seq.append(("gn", b.norm2, ops.ACT_SILU, b.conv2, None))
             seq.append(("conv_res", b.conv2, b.norm1.num_groups, out_for))  # conv2 + residual in the GEMM epilogue (+ next GN statistics)
 
@@ -100,11 +104,15 @@ class VAEHook:
             for j, r in enumerate(blk.resnets):
                 resblock(r, out_for=samp.conv if (samp is not None and j == len(blk.resnets) - 1) else None)
             if samp is not None:
-                seq.append(("f", (lambda x, s=samp, g=blk.resnets[0].norm1.num_groups: s.nhwc(x, gn_groups=g))))
+                g = blk.resnets[0].norm1.num_groups
+                if dec:     # Upsample2D: nearest-2x folded into the conv; Downsample2D (VAE): F.pad(x, (0, 1, 0, 1)) + a valid stride-2 conv
+                    seq.append(("conv", samp.conv, dict(upsample=True, gn_groups=g)))
+                else:
+                    seq.append(("conv", samp.conv, dict(pad=(0, 1, 0, 1) if samp.padding == 0 else samp.padding, gn_groups=g)))
         if not dec:
             mid()
         seq.append(("gn", net.conv_norm_out, ops.ACT_SILU, net.conv_out, None))
-        seq.append(("f", lambda x: net.conv_out.nhwc(x)))
+        seq.append(("conv", net.conv_out, {}))
         return seq
 
     # ---- public entry (NHWC bf16) -------------------------------------------------------------
@@ -141,18 +149,22 @@ class VAEHook:
                         res[k].append(op[4].nhwc(xc, pad=0))
                     else:
                         groups[k] = norm.apply_stats(groups[k], mean, rstd, act, split=op[3].in_split())
-            elif kind == "f":
-                for k in groups:
-                    groups[k] = op[1](groups[k])
+            elif kind == "conv":
+                keys = list(groups)
+                for k, y in zip(keys, op[1].nhwc_multi([groups[k] for k in keys], **op[2])):
+                    groups[k] = y
             elif kind == "res_push":
                 for k in groups:
                     res[k].append(op[1](groups[k]) if op[1] is not None else groups[k])
             elif kind == "conv_res":
-                for k in groups:
-                    if op[3] is not None:
-                        groups[k] = op[1].nhwc(groups[k], residual=res[k].pop(), out_dtype=ops.OUT_BF16, out_split=op[3].in_split())
-                    else:
-                        groups[k] = op[1].nhwc(groups[k], residual=res[k].pop(), gn_groups=op[2])
+                keys = list(groups)
+                xs, rs = [groups[k] for k in keys], [res[k].pop() for k in keys]
+                if op[3] is not None:
+                    outs = op[1].nhwc_multi(xs, residuals=rs, out_dtype=ops.OUT_BF16, out_split=op[3].in_split())
+                else:
+                    outs = op[1].nhwc_multi(xs, residuals=rs, gn_groups=op[2])
+                for k, y in zip(keys, outs):
+                    groups[k] = y
             elif kind == "attn_res":
                 for k in groups:
                     groups[k] = op[1].attend(groups[k], residual=res[k].pop())

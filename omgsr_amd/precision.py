@@ -75,6 +75,12 @@ _L16 = r"^(down_blocks\.2|up_blocks\.1)\."
 UNET_ACT = UNET_DEFAULT + [_L32 + r"resnets\.\d+\.conv[12]$", _L32 + r"attentions\.\d+\.transformer_blocks\.", _L16 + r"attentions\.\d+\.transformer_blocks\."]
 UNET_W = [r"."]
 FLUX_ACT, FLUX_W = FLUX_DEFAULT, FLUX_DEFAULT
+# Layers whose both-sides split runs in the MIXED-PRECISION form (op_split 3, OMGSR_EL_MX): the product a_hi w_hi in fp16 MFMAs and
+# the two correction terms a_lo w_hi, a_hi w_lo - which only need a few bits of their own - as block-scaled fp8 MFMAs at twice the
+# fp16 rate (v_mfma_scale_f32_32x32x64_f8f6f4): 2 instead of 3 segments of MFMA time and operand traffic. 3x3 stride-1 convs with
+# Cin % 64 == 0 whose operand a GroupNorm pass writes (ResnetBlock conv1 / conv2); they always take the halo-tile kernel.
+VAE_MX = [r"^encoder\..*resnets\.\d+\.conv[12]$", r"^decoder\.(mid_block|up_blocks\.0)\.resnets\.\d+\.conv[12]$"]
+UNET_MX = [_L64 + r"resnets\.\d+\.conv[12]$", _L32 + r"resnets\.\d+\.conv[12]$"]
 
 
 def set_operand_split(model: nn.Module, patterns: Iterable[str], split: int = 2) -> int:
@@ -105,6 +111,24 @@ def set_weight_split(model: nn.Module, patterns: Iterable[str], split: int = 2) 
             m.w_split = split if hit else 1
             n += int(hit)
     check_policy(model)
+    return n
+
+
+def set_mx(model: nn.Module, patterns: Iterable[str]) -> int:
+    """Move the both-sides split of the matching 3x3 stride-1 convolutions (Cin % 64 == 0, >= 96 output channels) to the
+    mixed-precision form (op_split 3); layers that do not qualify keep what they had. OMGSR_MX=0 switches the form off (A/B runs).
+    Returns how many layers were moved."""
+    import os
+    if os.environ.get("OMGSR_MX", "1") == "0":
+        return 0
+    regs = [re.compile(p) for p in patterns]
+    n = 0
+    for name, m in model.named_modules():
+        if isinstance(m, Conv2d) and any(r.search(name) for r in regs):
+            if m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.in_channels % 64 == 0 and m.out_channels >= 96 \
+                    and not m.phase_upsample and m.op_split == 2 and m.w_split == 2:
+                m.op_split = 3
+                n += 1
     return n
 
 
@@ -169,10 +193,12 @@ def apply_default_policy(vae: Optional[nn.Module] = None, unet: Optional[nn.Modu
     if vae is not None:
         set_operand_split(vae, VAE_ACT)
         set_weight_split(vae, VAE_W)
+        set_mx(vae, VAE_MX)
         set_inner16(vae, VAE_INNER16)
     if unet is not None:
         set_operand_split(unet, UNET_ACT)
         set_weight_split(unet, UNET_W)
+        set_mx(unet, UNET_MX)
     if flux is not None:
         set_operand_split(flux, FLUX_ACT)
         set_weight_split(flux, FLUX_W)

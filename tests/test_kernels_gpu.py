@@ -150,6 +150,44 @@ def test_upsample_conv_phase_form(case, monkeypatch):
     assert_close(to_nchw(y), to_nchw(y9), f"phase vs gather {case}", max_ulps=6.0)     # two independently rounded 16-bit results
 
 
+# shape groups of one tiled-VAE layer (rows, height, width) sharing one weight: one launch over all of them (omgsr_igemm_multi)
+MULTI_CASES = [
+    # Cin, Cout, upsample, residual, groups
+    (128, 128, False, True, [(36, 40, 40), (12, 40, 32), (12, 32, 40), (4, 32, 32)]),        # encoder groups at a deep level
+    (512, 512, False, False, [(4, 86, 86), (4, 86, 64), (4, 64, 86), (4, 64, 64)]),          # decoder groups, first level
+    (256, 256, True, False, [(4, 43, 43), (4, 43, 32), (4, 32, 43), (4, 32, 32)]),           # upsampling conv: phase form, merged
+    (128, 3, False, False, [(2, 96, 80), (2, 64, 80), (1, 64, 64)]),                         # conv_out: narrow shape
+    (64, 128, False, False, [(1, 9, 33), (2, 16, 16)]),                                      # too small for the halo kernel even together
+]
+
+
+@pytest.mark.parametrize("case", MULTI_CASES)
+def test_conv_multi_launch(case):
+    ops = _ops()
+    Cin, Cout, ups, use_res, groups = case
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    b = rnd(Cout, seed=3)
+    pw = ops.pack_conv_weight(w, b, device=DEV, cout_multiple=8, upsample_phases=ups)
+    xs, refs, ress = [], [], []
+    for i, (n, h, wd) in enumerate(groups):
+        x = rnd(n, Cin, h, wd, seed=10 + i)
+        xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+        ref = F.conv2d(xin, w, b, padding=1)
+        res = rnd(*ref.shape, seed=20 + i) if use_res else None
+        xs.append(nhwc(x)); ress.append(None if res is None else nhwc(res)); refs.append(ref if res is None else ref + res)
+    gn = 32 if Cout % 32 == 0 else 0
+    ys = ops.conv2d_multi(xs, pw, pad=1, upsample=ups, residuals=ress if use_res else None, gn_groups=gn)
+    singles = [ops.conv2d(x, pw, pad=1, upsample=ups, residual=r, gn_groups=gn) for x, r in zip(xs, ress)]
+    for y, y1, ref, (n, h, wd) in zip(ys, singles, refs, groups):
+        assert_close(to_nchw(y)[:, :Cout], ref, f"multi{case[:4]}{(n, h, wd)}", max_ulps=4.0 if ups else 3.0)
+        assert_close(to_nchw(y), to_nchw(y1), f"multi vs single {(n, h, wd)}", max_ulps=6.0)
+        if gn:      # statistics (fused by whichever kernel ran, or the stand-alone pass) describe the stored tensor
+            mean, rstd, var = ops.group_norm_stats(y, gn, 1e-6)
+            r = y.float().cpu().reshape(y.shape[0], -1, gn, Cout // gn)
+            assert torch.allclose(mean.cpu(), r.mean(dim=(1, 3)), atol=2e-3, rtol=2e-3)
+            assert torch.allclose(var.cpu(), r.var(dim=(1, 3), unbiased=False), atol=2e-3, rtol=5e-3)
+
+
 @pytest.mark.parametrize("M,K,Nout", [(64, 320, 320), (4096, 320, 960), (1000, 1280, 1280), (77, 1024, 640), (300, 64, 3072)])
 def test_linear(M, K, Nout):
     ops = _ops()

@@ -156,6 +156,74 @@ def test_upsample_conv_phase_form_accurate_tier(split, w_split):
     assert _rel(y, ref) < (3e-6 if w_split == 2 else 4e-4)
 
 
+def _fp8(u8):
+    return u8.contiguous().view(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("C,G,HW", [(128, 32, 4096), (320, 32, 1024), (512, 32, 300)])
+def test_group_norm_mx_operand(C, G, HW):
+    """The mixed-precision operand form (OMGSR_EL_MX): [a_hi fp16 | a_lo' fp8 | a_hi' fp8] per pixel, a_lo' = (a - a_hi) 2^11."""
+    from omgsr_amd import ops
+    x = torch.randn(2, HW, 1, C, generator=_g(2)) * 3 + 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=_g(3)), 0.1 * torch.randn(C, generator=_g(4))
+    y = ops.group_norm(x.to(DEV), gamma.to(DEV), beta.to(DEV), G, 1e-6, ops.ACT_SILU, split=3)
+    y2 = ops.group_norm(x.to(DEV), gamma.to(DEV), beta.to(DEV), G, 1e-6, ops.ACT_SILU, split=2)
+    assert y.dtype == torch.float16 and y.shape[-1] == 2 * C
+    ref = F.silu(F.group_norm(x.permute(0, 3, 1, 2).double(), G, gamma.double(), beta.double(), 1e-6)).permute(0, 2, 3, 1)
+    yb = y.cpu().view(torch.uint8).reshape(2, HW, 1, 4 * C)
+    hi = yb[..., :2 * C].contiguous().view(torch.float16).float()
+    lo, hi8 = _fp8(yb[..., 2 * C:3 * C]) * 2.0 ** -11, _fp8(yb[..., 3 * C:])
+    assert torch.equal(hi, y2[..., :C].float().cpu())                       # the fp16 half is the two-term split's hi
+    assert _rel(hi + lo, ref) < 2e-5                                         # lo' carries the residual to ~2^-4 of itself
+    assert _rel(hi8, ref) < 5e-2 and torch.isfinite(hi8).all()               # the fp8 copy of a_hi (3 mantissa bits)
+
+
+# N, H, W, C, Cout: halo-tile kernel with fp16 + block-scaled fp8 chunks; small and ragged maps included (MX problems always take it)
+_MX_CASES = [(2, 64, 64, 128, 128), (1, 64, 96, 320, 320), (2, 16, 16, 1280, 640), (1, 40, 43, 512, 512), (1, 32, 32, 960, 640), (1, 9, 33, 64, 128)]
+
+
+@pytest.mark.parametrize("N,H,W,C,Cout", _MX_CASES)
+def test_conv_mx(N, H, W, C, Cout):
+    """a w = a_hi w_hi (fp16 MFMAs) + a_lo w_hi + a_hi w_lo (block-scaled fp8 MFMAs, v_mfma_scale_f32_32x32x64_f8f6f4) with full-mantissa
+    inputs and weights: the correction terms are carried to ~2^-4 of their own size, i.e. 2^-16 of the product - against one fp16
+    rounding of each side at ~3e-4 and the three-segment fp16 form at ~1e-6."""
+    from omgsr_amd import ops
+    x = torch.randn(N, H, W, C, generator=_g(8))
+    w = torch.randn(Cout, C, 3, 3, generator=_g(9)) * (9 * C) ** -0.5
+    b = 0.1 * torch.randn(Cout, generator=_g(10))
+    res = torch.randn(N, H, W, Cout, generator=_g(11))
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+    pw = ops.pack_conv_weight(w, b, device=DEV, cout_multiple=8, split=3)
+    assert pw.mx is not None and pw.row_channels == 2 * C
+    y = ops.conv2d(x.to(DEV), pw, pad=1, residual=res.to(DEV), gn_groups=32)
+    e = _rel(y, ref)
+    pw1 = ops.pack_conv_weight(w, b, device=DEV, cout_multiple=8)
+    e1 = _rel(ops.conv2d(x.to(DEV), pw1, pad=1, residual=res.to(DEV)), ref)
+    print(f"conv MX {N, H, W, C, Cout}: rel {e:.2e} (single fp16 rounding of both sides {e1:.2e})")
+    assert e < 2e-5 and e1 > 10 * e
+    mean, rstd, var = ops.group_norm_stats(y, 32, 1e-6)           # statistics left by the halo epilogue
+    r = y.double().cpu().reshape(N, H * W, 32, Cout // 32)
+    assert torch.allclose(mean.double().cpu(), r.mean(dim=(1, 3)), atol=1e-5, rtol=1e-5)
+
+
+def test_conv_mx_multi_launch_and_saturation():
+    """Several MX problems of one layer in one launch; operands far outside fp8's range degrade gracefully (the fp8 parts clamp at
+    +-448: the correction is partly lost for those elements, nothing becomes NaN)."""
+    from omgsr_amd import ops
+    C, Cout = 128, 128
+    w = torch.randn(Cout, C, 3, 3, generator=_g(9)) * (9 * C) ** -0.5
+    pw = ops.pack_conv_weight(w, None, device=DEV, split=3)
+    xs = [torch.randn(n, h, wd, C, generator=_g(20 + i)) for i, (n, h, wd) in enumerate([(3, 40, 40), (1, 40, 32), (1, 32, 40), (1, 32, 32)])]
+    ys = ops.conv2d_multi([x.to(DEV) for x in xs], pw, pad=1)
+    for x, y in zip(xs, ys):
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+        assert _rel(y, ref) < 2e-5
+    big = xs[0] * 3000.0                                          # |a| up to ~1e4: a_hi' clamps at 448, a_lo' 2^11 clamps too
+    y = ops.conv2d(big.to(DEV), pw, pad=1)
+    ref = F.conv2d(big.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(y).all() and _rel(y, ref) < 1e-3
+
+
 @pytest.mark.parametrize("M,K,Nn", [(4608, 3072, 3072), (9216, 1536, 512), (300, 320, 1280), (147456, 320, 320)])
 @pytest.mark.parametrize("split,w_split", [(1, 2), (2, 2)])
 def test_linear_weight_split(M, K, Nn, split, w_split):
