@@ -138,6 +138,8 @@ typedef struct omgsr_igemm_args {
                               the E8M0 scales below (weight / operand, per segment). 3x3 stride 1 pad 1 (or the phase form) only: these
                               problems always take the halo-tile kernel. Cin = 2 x logical channels (16-bit slots), in_ld = 0. */
     int32_t mx_scale_w1, mx_scale_a1, mx_scale_w2, mx_scale_a2;   /* E8M0 exponents (127 = 2^0): the instruction multiplies each product by 2^(w - 127) 2^(a - 127) */
+    int32_t out_mx;        /* 1: the 16-bit output is written in the OMGSR_EL_MX form (4 Cout bytes per pixel; out_dtype OMGSR_OUT_BF16, NHWC,
+                              Cout % 64 == 0, fp16 compute type, no GroupNorm statistics): the operand of a following mixed-precision conv */
     int32_t group_tiles;   /* written by omgsr_igemm_multi_plan: halo-kernel tiles of the whole launch group this problem belongs to (0 = alone);
                               kernel choice and the GroupNorm-statistics layout use max(own tiles, group_tiles) */
     uint32_t* overflow_flag; /* optional (fp16 compute type only): a device word the epilogue ORs 1 into when a value it writes as a 16-bit

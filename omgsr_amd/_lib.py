@@ -38,7 +38,7 @@ class IgemmArgs(C.Structure):
         ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32), ("gn_entries", C.c_int32),
         ("res_el", C.c_int32), ("in_split", C.c_int32), ("sample_rows", C.c_int64), ("out_lo_off", C.c_int32),
         ("in_ld", C.c_int32), ("w_split", C.c_int32), ("weight_ph", C.c_void_p), ("mx_chunks16", C.c_int32), ("mx_scale_w1", C.c_int32), ("mx_scale_a1", C.c_int32),
-        ("mx_scale_w2", C.c_int32), ("mx_scale_a2", C.c_int32), ("group_tiles", C.c_int32), ("overflow_flag", C.c_void_p),
+        ("mx_scale_w2", C.c_int32), ("mx_scale_a2", C.c_int32), ("out_mx", C.c_int32), ("group_tiles", C.c_int32), ("overflow_flag", C.c_void_p),
     ]
 
 

@@ -48,13 +48,25 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc not found: cannot build libomgsr_hip.so")
     from concurrent.futures import ThreadPoolExecutor
 
+    hdr = hashlib.sha256()              # every header any source may include: a header edit recompiles everything, a .hip edit only itself
+    for n in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "omgsr_hip.h")]:
+        if n.endswith(".h"):
+            with open(os.path.join(CSRC, n), "rb") as f:
+                hdr.update(n.encode() + f.read())
+
     def compile_one(src: str) -> str:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        with open(os.path.join(CSRC, src), "rb") as f:
+            want = hashlib.sha256(hdr.digest() + f.read()).hexdigest()
+        if not force and os.path.isfile(obj) and os.path.isfile(obj + ".sha256") and open(obj + ".sha256").read().strip() == want:
+            return obj
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
+        with open(obj + ".sha256", "w") as f:
+            f.write(want)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:      # one hipcc per translation unit

@@ -136,18 +136,20 @@ OMGSR_DEVINL unsigned int pack4_fp8(float a, float b, float c, float d) {
 template <typename T> OMGSR_DEVINL void store8_mx(void* base, const int64_t row_byte0, const int C, const int c, const float (&f)[8]) {
     unsigned char* row = reinterpret_cast<unsigned char*>(base) + row_byte0;
     u32x4_t hi;
-    float lo[8], hf[8];
+    u32x2_t lo8, hi8;
+    // four values at a time (eight live temporaries: the igemm epilogue calls this with ~250 registers in use)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned int h2 = pack2<T>(f[2 * i], f[2 * i + 1]);
-        hi[i] = h2;
-        hf[2 * i] = lo_of<T>(h2, 0); hf[2 * i + 1] = lo_of<T>(h2, 1);
-        lo[2 * i] = (f[2 * i] - hf[2 * i]) * (float)(1 << OMGSR_MX_LO_SHIFT);
-        lo[2 * i + 1] = (f[2 * i + 1] - hf[2 * i + 1]) * (float)(1 << OMGSR_MX_LO_SHIFT);
+    for (int q = 0; q < 2; ++q) {
+        const unsigned int h0 = pack2<T>(f[4 * q], f[4 * q + 1]), h1 = pack2<T>(f[4 * q + 2], f[4 * q + 3]);
+        hi[2 * q] = h0; hi[2 * q + 1] = h1;
+        const float a0 = lo_of<T>(h0, 0), a1 = lo_of<T>(h0, 1), a2 = lo_of<T>(h1, 0), a3 = lo_of<T>(h1, 1);
+        const float s = (float)(1 << OMGSR_MX_LO_SHIFT);
+        lo8[q] = pack4_fp8((f[4 * q] - a0) * s, (f[4 * q + 1] - a1) * s, (f[4 * q + 2] - a2) * s, (f[4 * q + 3] - a3) * s);
+        hi8[q] = pack4_fp8(a0, a1, a2, a3);
     }
     *reinterpret_cast<u32x4_t*>(row + 2 * c) = hi;
-    *reinterpret_cast<u32x2_t*>(row + 2 * C + c) = (u32x2_t){pack4_fp8(lo[0], lo[1], lo[2], lo[3]), pack4_fp8(lo[4], lo[5], lo[6], lo[7])};
-    *reinterpret_cast<u32x2_t*>(row + 3 * C + c) = (u32x2_t){pack4_fp8(hf[0], hf[1], hf[2], hf[3]), pack4_fp8(hf[4], hf[5], hf[6], hf[7])};
+    *reinterpret_cast<u32x2_t*>(row + 2 * C + c) = lo8;
+    *reinterpret_cast<u32x2_t*>(row + 3 * C + c) = hi8;
 }
 
 // store: EL 0 = 16-bit at base[idx]; 1 = fp32 at base[idx]; 2 = split, hi at base[idx], lo at base[idx + lo_off]

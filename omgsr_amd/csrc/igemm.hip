@@ -267,7 +267,7 @@ int splitk_plan(const omgsr_igemm_args& a_real, int64_t M64) {
     const omgsr_igemm_args a = policy_view(a_real);
     if (omgsr::g_batch_invariant) M64 = (int64_t)a.N * a.Ho * a.Wo;
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
-    if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || (a.in_ld % 32) || logical_cols < 96 || a.mx_chunks16 > 0) return 1;
+    if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || (a.in_ld % 32) || logical_cols < 96 || a.mx_chunks16 > 0 || a.out_mx) return 1;      // (the reduce pass writes plain / split outputs only)
     if (use_halo(a) || use_halo_phase(a)) return 1;   // the halo-tile kernel takes the problem (and owns the fused GroupNorm statistics)
     const int nk = a.K_pad / 32;
     const int64_t tiles = ((M64 + 255) / 256) * ((logical_cols + 127) / 128);
@@ -282,14 +282,16 @@ int splitk_plan(const omgsr_igemm_args& a_real, int64_t M64) {
 // A mixed-precision (MX) problem: fp16 chunks followed by block-scaled fp8 chunks. Only the halo-tile kernel's wide nine-tap shape runs it.
 bool mx_geometry_ok(const omgsr_igemm_args& a) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
-    return a.weight_cm && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 && a.upsample == 0 && (a.Cin % 128) == 0 &&
-           a.in_ld == 0 && a.batch == 1 && a.Ho == a.H && a.Wo == a.W && logical_cols >= 96 && a.act != OMGSR_ACT_GEGLU &&
-           a.out_layout == OMGSR_LAYOUT_NHWC && a.mx_chunks16 == a.Cin / 64 && omgsr::compute_dtype() == 1;
+    const bool common = a.R == 3 && a.S == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 && (a.Cin % 128) == 0 && a.in_ld == 0 && a.batch == 1 &&
+                        logical_cols >= 96 && a.act != OMGSR_ACT_GEGLU && a.out_layout == OMGSR_LAYOUT_NHWC && a.mx_chunks16 == a.Cin / 64 &&
+                        omgsr::compute_dtype() == 1;
+    if (a.upsample) return common && a.weight_ph && a.Ho == 2 * a.H && a.Wo == 2 * a.W && (a.Cout & 7) == 0 && !a.residual;      // phase form
+    return common && a.weight_cm && a.Ho == a.H && a.Wo == a.W;
 }
 
 // the halo-tile kernel's preconditions + the "enough tiles to fill the chip" policy
 bool use_halo(const omgsr_igemm_args& a_real) {
-    if (a_real.mx_chunks16 > 0) return mx_geometry_ok(a_real);   // no other kernel understands the format
+    if (a_real.mx_chunks16 > 0) return !a_real.upsample && mx_geometry_ok(a_real);   // no other kernel understands the format
     const omgsr_igemm_args a = policy_view(a_real);              // geometry tests below do not involve N; the tile count does
     static const char* mode = getenv("OMGSR_IGEMM_MODE");
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
@@ -308,6 +310,7 @@ bool use_halo(const omgsr_igemm_args& a_real) {
 
 // Nearest-2x upsampling + 3x3 conv as four 2 x 2 convolutions of the low-res map (weight_ph: phase-summed kernels), 4 / 9 of the MFMA work
 bool use_halo_phase(const omgsr_igemm_args& a_real) {
+    if (a_real.mx_chunks16 > 0) return a_real.upsample && mx_geometry_ok(a_real);
     const omgsr_igemm_args a = policy_view(a_real);
     static const char* off = getenv("OMGSR_UPSAMPLE_PHASES");        // A/B runs: "0" = the gather form (nine taps on the virtual map)
     static const char* mode = getenv("OMGSR_IGEMM_MODE");
@@ -405,6 +408,8 @@ int validate_args(omgsr_igemm_args& a) {
     const int ksegs = 1 + (a.in_split ? 1 : 0) + (a.w_split ? 1 : 0);      // K-concat segments of one logical channel set
     if (a.Cin % (8 * ksegs)) return OMGSR_E_SHAPE;
     if (a.mx_chunks16 < 0 || (a.mx_chunks16 > 0 && !mx_geometry_ok(a))) return OMGSR_E_SHAPE;
+    if (a.out_mx && (a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cout & 63) || a.out_lo_off || a.out_ld || a.gn_partial ||
+                     a.act == OMGSR_ACT_GEGLU || omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
     if (a.gn_partial) {                            // must be exactly what omgsr_igemm_gn_slots / _gn_entries promised
         int nslot, entries;
         gn_plan(a, &nslot, &entries);
@@ -482,7 +487,7 @@ extern "C" int omgsr_igemm_multi(const omgsr_igemm_args* args, int32_t count, vo
                           a.act == grp[0].act && a.out_dtype == grp[0].out_dtype && a.out_lo_off == grp[0].out_lo_off && a.out_ld == grp[0].out_ld &&
                           a.res_el == grp[0].res_el && (a.residual != nullptr) == (grp[0].residual != nullptr) &&
                           (a.gn_partial != nullptr) == (grp[0].gn_partial != nullptr) && a.gn_entries == grp[0].gn_entries && a.bias == grp[0].bias &&
-                          a.gate == grp[0].gate && a.alpha == grp[0].alpha && a.upsample == grp[0].upsample && a.mx_chunks16 == grp[0].mx_chunks16 &&
+                          a.gate == grp[0].gate && a.alpha == grp[0].alpha && a.upsample == grp[0].upsample && a.mx_chunks16 == grp[0].mx_chunks16 && a.out_mx == grp[0].out_mx &&
                           ((a.Cout <= 32) == (grp[0].Cout <= 32));
         if (m < 0) {                     // not a halo problem: its own launch, in order
             rc = flush();

@@ -219,7 +219,10 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
 #pragma unroll
                             for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
                         }
-                        if (osplit) {
+                        if (p.out_mx) {          // the mixed-precision operand form of the next conv (OMGSR_EL_MX: 4 Cout bytes per pixel)
+                            note8(v);
+                            store8_mx<T>(outb, (int64_t)(mb[i] + row * pxs) * 4 * p.Cout, p.Cout, n_out, v);
+                        } else if (osplit) {
                             u32x4_t hi, lo;
                             note8(v);
                             split8<T>(v, hi, lo);

@@ -7,8 +7,10 @@ static int mx_attrs() {
     static bool attr_set = false;
     if (!attr_set) {
         const void* fns[] = {reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, false, 9, true>),
-                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 9, true>)};
-        const int rc = halo_set_lds_attr(fns, 2);
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 9, true>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, false, 4, true>),
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 4, true>)};
+        const int rc = halo_set_lds_attr(fns, 4);
         if (rc != 0) return rc;
         attr_set = true;
     }
@@ -18,14 +20,16 @@ int igemm_halo_launch_multi_mx(const void* halo_multi, unsigned blocks, hipStrea
     const HaloMulti& m = *reinterpret_cast<const HaloMulti*>(halo_multi);         // igemm_halo_multi.hip's struct of the same header
     const int rc = mx_attrs();
     if (rc != 0) return rc;
-    hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, true>), dim3(blocks), dim3(256), LDS_BYTES, st, m);
+    if (m.p[0].upsample) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 4, true>), dim3(blocks, 4), dim3(256), LDS_BYTES, st, m);
+    else hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, true>), dim3(blocks), dim3(256), LDS_BYTES, st, m);
     return (int)hipGetLastError();
 }
 int igemm_halo_launch_mx(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
-    halo_geo(a, g, false);
+    halo_geo(a, g, a.upsample != 0);
     const int rc = mx_attrs();
     if (rc != 0) return rc;
-    hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 9, true>), dim3(g.ntm * g.ntn), dim3(256), LDS_BYTES, st, a, g);
+    if (a.upsample) hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 4, true>), dim3(g.ntm * g.ntn, 4), dim3(256), LDS_BYTES, st, a, g);
+    else hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 9, true>), dim3(g.ntm * g.ntn), dim3(256), LDS_BYTES, st, a, g);
     return (int)hipGetLastError();
 }
 }  // namespace omgsr

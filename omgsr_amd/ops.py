@@ -232,36 +232,45 @@ def _segments(w: torch.Tensor, split: int, w_split: int) -> torch.Tensor:
     return torch.cat(segs, dim=-1) if len(segs) > 1 else w_hi
 
 
-def _fp8_scaled(t: torch.Tensor):
-    """t fp32 -> (uint8 e4m3 bytes of t * 2^s, E8M0 byte 127 - s) with s chosen so that max |t| * 2^s lies in [128, 256) (e4m3 tops out at
-    448; its 17 binades below that cover weights 5 orders of magnitude under the largest)."""
+def _mx_rows(w: torch.Tensor, s1: int, s2: int) -> torch.Tensor:
+    """[..., C] fp32 -> [..., 4C] uint8: [w_hi fp16 | fp8(w_hi 2^s1) | fp8((w - w_hi) 2^s2)]."""
+    w_hi = w.to(torch.float16)
+    hi8 = (w_hi.float() * 2.0 ** s1).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    lo8 = ((w - w_hi.float()) * 2.0 ** s2).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    return torch.cat([w_hi.contiguous().view(torch.uint8).reshape(*w.shape[:-1], 2 * w.shape[-1]), hi8, lo8], dim=-1)
+
+
+def _mx_shift(t: torch.Tensor) -> int:
+    """s with max |t| 2^s in [128, 256): e4m3 tops out at 448, its 17 binades below cover values 5 orders of magnitude under the largest."""
     import math
     m = float(t.abs().max())
-    s = 7 - math.floor(math.log2(m)) if m > 0 else 0
-    s = max(-100, min(100, s))
-    q = (t * (2.0 ** s)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
-    return q.view(torch.uint8), 127 - s
+    return max(-100, min(100, 7 - math.floor(math.log2(m)))) if m > 0 else 0
 
 
-def _pack_mx(w: torch.Tensor, bias, cout: int, cin: int, R: int, S: int, dev) -> "PackedWeight":
+def _pack_mx(w: torch.Tensor, bias, cout: int, cin: int, R: int, S: int, dev, upsample_phases: bool = False) -> "PackedWeight":
     """[Cout, R, S, C] fp32 -> the mixed-precision weight of an OMGSR_EL_MX operand: per tap 4C bytes = 2C 16-bit slots,
     [w_hi fp16 (2C B) | w_hi' fp8 (C B) | w_lo' fp8 (C B)] with w_hi = fp16(w), w_hi' = fp8(w_hi 2^s1), w_lo' = fp8((w - w_hi) 2^s2): the
     first C / 32 chunks meet a_hi in fp16 MFMAs, then C / 64 fp8 chunks meet a_lo' (w_hi') and C / 64 meet a_hi' (w_lo') in block-scaled
     fp8 MFMAs whose E8M0 scale operands undo s1 / s2 and the operand's 2^11."""
     if R != 3 or S != 3 or cin % 64 or act_dtype() != torch.float16:
         raise ValueError("the mixed-precision (MX) form serves 3x3 convolutions with Cin % 64 == 0 in the fp16 compute type")
-    w_hi = w.to(torch.float16)
-    hi8, e_w1 = _fp8_scaled(w_hi.float())
-    lo8, e_w2 = _fp8_scaled(w - w_hi.float())
-    rows = torch.cat([w_hi.contiguous().view(torch.uint8).reshape(cout, R, S, 2 * cin), hi8.reshape(cout, R, S, cin), lo8.reshape(cout, R, S, cin)], dim=-1)
+    ph = _phase_kernels(w) if upsample_phases else None       # [4, Cout, 2, 2, C]: one set of scales for the taps AND the phase sums
+    both = w if ph is None else torch.cat([w.reshape(-1), ph.reshape(-1)])
+    both_hi = both.to(torch.float16).float()
+    s1, s2 = _mx_shift(both_hi), _mx_shift(both - both_hi)
     kslots = 2 * cin                                           # 16-bit slots per tap
     cout_pad = _round_up(cout, 256 if cout >= 256 else 128)
     out = torch.zeros((cout_pad, R * S * kslots), device=dev, dtype=torch.float16)
-    out[:cout] = rows.reshape(cout, R * S * 4 * cin).contiguous().view(torch.float16)
+    out[:cout] = _mx_rows(w, s1, s2).reshape(cout, R * S * 4 * cin).contiguous().view(torch.float16)
     w_cm = out.view(cout_pad, 9, kslots // 32, 32).permute(2, 1, 0, 3).contiguous()
+    w_ph = None
+    if ph is not None:
+        full = torch.zeros((4, cout_pad, 4 * kslots), device=dev, dtype=torch.float16)
+        full[:, :cout] = _mx_rows(ph, s1, s2).reshape(4, cout, 4 * 4 * cin).contiguous().view(torch.float16)
+        w_ph = full.view(4, cout_pad, 4, kslots // 32, 32).permute(0, 3, 2, 1, 4).contiguous()         # [phase][chunk][tap][Cout_pad][32]
     b = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
-    return PackedWeight(out, b, cout, kslots, R, S, w_cm=w_cm, split=3, w_split=1, in_ld=kslots,
-                        mx=(cin // 32, e_w1, 127 - MX_LO_SHIFT, e_w2, 127))
+    return PackedWeight(out, b, cout, kslots, R, S, w_cm=w_cm, split=3, w_split=1, in_ld=kslots, w_ph=w_ph,
+                        mx=(cin // 32, 127 - s1, 127 - MX_LO_SHIFT, 127 - s2, 127))
 
 
 def _phase_kernels(w: torch.Tensor) -> torch.Tensor:
@@ -308,7 +317,7 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
     if split == 3:
         if cin8 != cin:
             raise ValueError("the mixed-precision (MX) form needs Cin % 64 == 0")
-        return _pack_mx(w, bias if bias is None else bias.detach().to(dev), cout, cin, R, S, dev)
+        return _pack_mx(w, bias if bias is None else bias.detach().to(dev), cout, cin, R, S, dev, upsample_phases)
     if split not in (1, 2) or w_split not in (1, 2):
         raise ValueError("split / w_split must be 1 or 2")
     in_ld = cin8 * split
@@ -384,7 +393,7 @@ def _out_tensor(shape, cout: int, out_dtype: int, out_split: int, device) -> tor
             raise ValueError("out_split applies to operand outputs (out_dtype=OUT_BF16)")
     if out_dtype == OUT_F32:
         return torch.empty((*shape, cout), device=device, dtype=torch.float32)
-    return torch.empty((*shape, cout * out_split), device=device, dtype=_ACT)
+    return torch.empty((*shape, cout * min(out_split, 2)), device=device, dtype=_ACT)       # split 3 (MX): 4 bytes per channel, like split 2
 
 
 def _fill_k(a: IgemmArgs, pw: PackedWeight) -> None:
@@ -402,6 +411,7 @@ def _fill_out(a: IgemmArgs, out: torch.Tensor, out_split: int, residual: Optiona
     a.out = out.data_ptr()
     a.out_dtype = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
     a.out_lo_off = cout if out_split == 2 else 0
+    a.out_mx = int(out_split == 3)
     if residual is not None:
         a.residual = residual.data_ptr()
         a.res_el = _el(residual, "residual")

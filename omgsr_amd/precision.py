@@ -79,8 +79,10 @@ FLUX_ACT, FLUX_W = FLUX_DEFAULT, FLUX_DEFAULT
 # the two correction terms a_lo w_hi, a_hi w_lo - which only need a few bits of their own - as block-scaled fp8 MFMAs at twice the
 # fp16 rate (v_mfma_scale_f32_32x32x64_f8f6f4): 2 instead of 3 segments of MFMA time and operand traffic. 3x3 stride-1 convs with
 # Cin % 64 == 0 whose operand a GroupNorm pass writes (ResnetBlock conv1 / conv2); they always take the halo-tile kernel.
-VAE_MX = [r"^encoder\..*resnets\.\d+\.conv[12]$", r"^decoder\.(mid_block|up_blocks\.0)\.resnets\.\d+\.conv[12]$"]
-UNET_MX = [_L64 + r"resnets\.\d+\.conv[12]$", _L32 + r"resnets\.\d+\.conv[12]$"]
+# ... and the nearest-2x upsampling convs (phase-decomposed form), whose operand the previous block's conv / linear epilogue writes.
+_DEC_UPS = r"^decoder\..*upsamplers\.0\.conv$"
+VAE_MX = [r"^encoder\..*resnets\.\d+\.conv[12]$", r"^decoder\.(mid_block|up_blocks\.0)\.resnets\.\d+\.conv[12]$", _DEC_UPS]
+UNET_MX = [_L64 + r"resnets\.\d+\.conv[12]$", _L32 + r"resnets\.\d+\.conv[12]$", r"upsamplers\.0\.conv$"]
 
 
 def set_operand_split(model: nn.Module, patterns: Iterable[str], split: int = 2) -> int:
@@ -126,7 +128,7 @@ def set_mx(model: nn.Module, patterns: Iterable[str]) -> int:
     for name, m in model.named_modules():
         if isinstance(m, Conv2d) and any(r.search(name) for r in regs):
             if m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.in_channels % 64 == 0 and m.out_channels >= 96 \
-                    and not m.phase_upsample and m.op_split == 2 and m.w_split == 2:
+                    and m.out_channels % 8 == 0 and m.op_split == 2 and m.w_split == 2:
                 m.op_split = 3
                 n += 1
     return n

@@ -206,6 +206,32 @@ def test_conv_mx(N, H, W, C, Cout):
     assert torch.allclose(mean.double().cpu(), r.mean(dim=(1, 3)), atol=1e-5, rtol=1e-5)
 
 
+def test_conv_mx_upsample_phase_form_and_epilogue_output():
+    """The producer / consumer pair of a decoder upsampler in the mixed-precision form: a GEMM epilogue writes the OMGSR_EL_MX operand
+    (out_split 3) and the phase-decomposed upsampling conv consumes it (fp16 + block-scaled fp8 chunks of the phase-summed kernels)."""
+    from omgsr_amd import ops
+    C = 256
+    x = torch.randn(2, 43, 86, C, generator=_g(31))
+    w = torch.randn(C, C, 3, 3, generator=_g(32)) * (9 * C) ** -0.5
+    b = 0.1 * torch.randn(C, generator=_g(33))
+    ref = F.conv2d(F.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    pw = ops.pack_conv_weight(w, b, device=DEV, split=3, upsample_phases=True)
+    assert pw.w_ph is not None and pw.mx is not None
+    y = ops.conv2d(x.to(DEV), pw, pad=1, upsample=True, gn_groups=32)
+    assert _rel(y, ref) < 2e-5
+    # an epilogue-written MX operand (identity GEMM of an fp16-representable x: the epilogue sees exactly x) equals the cast kernel's,
+    # byte for byte, on every GEMM-shaped kernel that can produce it (few rows: register staged; many rows: LDS-DMA)
+    eye = ops.pack_linear_weight(torch.eye(C), None, device=DEV)
+    for rows in (2 * 43 * 86, 40 * 43 * 86):
+        xr = (torch.randn(rows, C, generator=_g(34)) * 3).to(torch.float16).float().to(DEV)
+        via_epilogue = ops.linear(xr.reshape(1, rows, C), eye, out_dtype=ops.OUT_BF16, out_split=3).reshape(rows, 2 * C)
+        assert torch.equal(via_epilogue, ops.to_operand(xr, 3))
+    xm = ops.linear(x.to(torch.float16).float().to(DEV).reshape(1, -1, C), eye, out_dtype=ops.OUT_BF16, out_split=3).reshape(2, 43, 86, 2 * C)
+    y2 = ops.conv2d(xm, pw, pad=1, upsample=True)
+    ref2 = F.conv2d(F.interpolate(x.to(torch.float16).permute(0, 3, 1, 2).double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert _rel(y2, ref2) < 2e-5
+
+
 def test_conv_mx_multi_launch_and_saturation():
     """Several MX problems of one layer in one launch; operands far outside fp8's range degrade gracefully (the fp8 parts clamp at
     +-448: the correction is partly lost for those elements, nothing becomes NaN)."""
