@@ -23,7 +23,7 @@ DEV = "cuda"
 
 BOUNDS = {          # tier: (pipeline rel-L2, pipeline PSNR dB, DiT-alone rel-L2)
     "fp32": (1e-3, 60.0, 1e-3),
-    "bf16": (6e-2, 33.0, 6e-2),
+    "bf16": (3e-2, 40.0, 2.5e-2),       # measured 1.8e-2 / 44.8 dB / 1.3e-2 (weights rounded to bf16 by the tier, fp32 oracle)
 }
 
 
