@@ -73,7 +73,10 @@ VAE_W = [r"^(?!" + _VAE_SINGLE + r")"]
 _L32 = r"^(down_blocks\.1|up_blocks\.2)\."
 _L16 = r"^(down_blocks\.2|up_blocks\.1)\."
 UNET_ACT = UNET_DEFAULT + [_L32 + r"resnets\.\d+\.conv[12]$", _L32 + r"attentions\.\d+\.transformer_blocks\.", _L16 + r"attentions\.\d+\.transformer_blocks\."]
-UNET_W = [r"."]
+# weight side: everything but the 16 x 16 level's resnet convs (0.2 units) and the 8 x 8 level + mid block (0.0): long-K convs on tiny
+# maps that cost 5 ms of the S-1024 step when split (A/B on one box: 215.8 -> 210.6 ms; the six draws moved from 3.4e-4 ... 4.5e-4 to
+# 3.6e-4 ... 4.5e-4)
+UNET_W = [r"^(?!(down_blocks\.2|up_blocks\.1)\.resnets\.\d+\.conv[12]$|(down_blocks\.3|up_blocks\.0|mid_block)\.(resnets\.\d+\.conv[12]$|attentions\.\d+\.transformer_blocks\.))"]
 FLUX_ACT, FLUX_W = FLUX_DEFAULT, FLUX_DEFAULT
 # Layers whose both-sides split runs in the MIXED-PRECISION form (op_split 3, OMGSR_EL_MX): the product a_hi w_hi in fp16 MFMAs and
 # the two correction terms a_lo w_hi, a_hi w_lo - which only need a few bits of their own - as block-scaled fp8 MFMAs at twice the
@@ -198,8 +201,9 @@ def apply_default_policy(vae: Optional[nn.Module] = None, unet: Optional[nn.Modu
         set_mx(vae, VAE_MX)
         set_inner16(vae, VAE_INNER16)
     if unet is not None:
+        import os
         set_operand_split(unet, UNET_ACT)
-        set_weight_split(unet, UNET_W)
+        set_weight_split(unet, [r"."] if os.environ.get("OMGSR_UNET_W_ALL") == "1" else UNET_W)      # (A/B switch: every UNet weight split)
         set_mx(unet, UNET_MX)
     if flux is not None:
         set_operand_split(flux, FLUX_ACT)
