@@ -236,6 +236,10 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         const unsigned char* Bs = lds + B_OFF + (tap % NB) * B_BYTES;
         if constexpr (F8) {
             typedef int i32x4_t __attribute__((ext_vector_type(4)));
+            // the scale operands are VGPRs written by VALU moves: set them up in front of the fragment reads (the asm MFMAs that read them
+            // are invisible to the compiler's hazard padding; the LDS reads and their wait put >> the 2 required wait states in between)
+            int sw = cc < seg2_at ? p.mx_scale_w1 : p.mx_scale_w2, sa = cc < seg2_at ? p.mx_scale_a1 : p.mx_scale_a2;
+            asm volatile("" : "+v"(sw), "+v"(sa));
             i32x8_t a8[FM], b8[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -245,7 +249,6 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
             for (int j = 0; j < FN; ++j)
                 b8[j] = __builtin_shufflevector(*reinterpret_cast<const i32x4_t*>(Bs + j * 32 * 64 + boff0), *reinterpret_cast<const i32x4_t*>(Bs + j * 32 * 64 + boff1),
                                                 0, 1, 2, 3, 4, 5, 6, 7);
-            const int sw = cc < seg2_at ? p.mx_scale_w1 : p.mx_scale_w2, sa = cc < seg2_at ? p.mx_scale_a1 : p.mx_scale_a2;
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
 #pragma unroll

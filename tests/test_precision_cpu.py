@@ -1,0 +1,109 @@
+"""Host-side logic of the accurate tier on CPU (no kernels run): the shipped precision policy's layer assignment, its consistency
+checks and fingerprint, the weight packings of the split forms (two-term K-concatenation with the wrapped contraction, the
+mixed-precision fp16 + fp8 form, the phase-summed kernels of the upsampling convs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+@pytest.fixture()
+def accurate_tier():
+    from omgsr_amd import ops
+    ops.set_compute_dtype(torch.float32)          # host-side switch only (omgsr_set_compute_dtype touches no device)
+    yield ops
+    ops.set_compute_dtype(torch.bfloat16)
+
+
+def _forms(model):
+    from omgsr_amd import nn as N
+    out = {}
+    for _, m in model.named_modules():
+        if isinstance(m, (N.Conv2d, N.Linear)):
+            out[(m.op_split, m.w_split)] = out.get((m.op_split, m.w_split), 0) + 1
+    return out
+
+
+def test_shipped_policy_assignment_on_sd21_shapes():
+    from omgsr_amd import precision as P
+    from omgsr_amd.diffusers_api import AutoencoderKL, UNet2DConditionModel
+    with torch.device("meta"):
+        v, u = AutoencoderKL(), UNet2DConditionModel()
+    P.apply_default_policy(vae=v, unet=u)
+    fv, fu = _forms(v), _forms(u)
+    # VAE: 30 resnet convs + 3 upsampling convs in the mixed-precision form, the decoder's 18 resnet convs above 64 px single, the
+    # 8 attention linears weight-split only, everything else (shortcuts, samplers, conv_in / out, quant convs) split on both sides
+    assert fv == {(3, 2): 33, (1, 1): 18, (1, 2): 8, (2, 2): 13}
+    mx = [n for n, m in v.named_modules() if getattr(m, "op_split", 0) == 3]
+    assert all(("resnets" in n or "upsamplers" in n) for n in mx) and not any("decoder.up_blocks.1.resnets" in n for n in mx)
+    # UNet: the 64 x 64 and 32 x 32 resnet convs + the three upsampling convs in the mixed-precision form; 16 x 16 resnets and the
+    # 8 x 8 level + mid block single
+    assert fu[(3, 2)] == 23 and fu[(1, 1)] == 34 and sum(fu.values()) == 282
+    assert u.down_blocks[2].resnets[0].conv1.w_split == 1 and u.down_blocks[0].attentions[0].transformer_blocks[0].attn1.to_q.w_split == 2
+    a, b = P.policy_fingerprint(u), P.policy_fingerprint(v)
+    P.set_weight_split(u, [])
+    assert P.policy_fingerprint(u) != a and P.policy_fingerprint(v) == b
+    P.resolve("all", unet=u)
+    assert _forms(u) == {(2, 2): 282}
+
+
+def test_check_policy_rejects_layers_that_share_an_operand_but_disagree():
+    from omgsr_amd import precision as P
+    from omgsr_amd.diffusers_api import FluxTransformer2DModel, UNet2DConditionModel
+    with torch.device("meta"):
+        u = UNet2DConditionModel(block_out_channels=[64, 128, 256, 256], attention_head_dim=[1, 2, 4, 4], cross_attention_dim=128)
+        f = FluxTransformer2DModel(num_layers=1, num_single_layers=1, num_attention_heads=2, attention_head_dim=128, joint_attention_dim=64,
+                                   pooled_projection_dim=32, in_channels=64)
+    with pytest.raises(ValueError, match="to_q / to_k / to_v"):
+        P.set_operand_split(u, [r"attn1\.to_q$"])
+    with pytest.raises(ValueError, match="one fused weight"):
+        P.set_weight_split(u, [r"attn1\.to_q$"])
+    with pytest.raises(ValueError, match="add_q_proj / add_k_proj / add_v_proj"):
+        P.set_operand_split(f, [r"add_q_proj$"])
+    with pytest.raises(ValueError, match="to_out.0 / to_add_out"):
+        P.set_operand_split(f, [r"to_add_out$"])
+    P.set_operand_split(f, [r"to_add_out$", r"attn\.to_out\.0$"])       # together: fine
+
+
+def test_split_weight_packings(accurate_tier):
+    ops = accurate_tier
+    g = torch.Generator().manual_seed(0)
+    C, Cout = 64, 16
+    w = torch.randn(Cout, C, 3, 3, generator=g) * 0.05
+    w_hi = w.to(torch.float16).float()
+    # K-concatenation per tap: [w_hi] * split, then [w_lo]
+    pw = ops.pack_conv_weight(w, None, device="cpu", split=2, w_split=2)
+    assert pw.cin == 3 * C and pw.row_channels == 2 * C and pw.k_pad == 9 * 3 * C
+    rows = pw.w[:Cout].float().reshape(Cout, 9, 3 * C)
+    ref = w.permute(0, 2, 3, 1).reshape(Cout, 9, C)
+    assert torch.equal(rows[..., :C], w_hi.permute(0, 2, 3, 1).reshape(Cout, 9, C)) and torch.equal(rows[..., C:2 * C], rows[..., :C])
+    assert torch.equal(rows[..., 2 * C:], (ref - rows[..., :C]).to(torch.float16).float())
+    assert ((rows[..., :C] + rows[..., 2 * C:]) - ref).abs().max() < 2.0 ** -20 * ref.abs().max()
+    pw = ops.pack_conv_weight(w, None, device="cpu", split=1, w_split=2)
+    assert pw.cin == 2 * C and pw.row_channels == C           # the contraction wraps over the operand row (omgsr_igemm_args.in_ld)
+    # the mixed-precision form: per tap 4C bytes [w_hi fp16 | fp8(w_hi 2^s1) | fp8(w_lo 2^s2)], scales as E8M0 exponents
+    pw = ops.pack_conv_weight(w, None, device="cpu", split=3)
+    n16, e_w1, e_a1, e_w2, e_a2 = pw.mx
+    assert n16 == C // 32 and e_a1 == 127 - 11 and e_a2 == 127 and pw.cin == 2 * C and pw.row_channels == 2 * C
+    by = pw.w[:Cout].view(torch.uint8).reshape(Cout, 9, 4 * C)
+    hi = by[..., :2 * C].contiguous().view(torch.float16).float()
+    assert torch.equal(hi, rows[..., :C])
+    hi8 = by[..., 2 * C:3 * C].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** (e_w1 - 127)
+    lo8 = by[..., 3 * C:].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** (e_w2 - 127)
+    assert (hi8 - hi).abs().max() <= 2.0 ** -4 * hi.abs().max() and (lo8 - (ref - hi)).abs().max() <= 2.0 ** -4 * (ref - hi).abs().max()
+    assert ((hi + lo8) - ref).abs().max() < 2.0 ** -14 * ref.abs().max()           # w_hi + w_lo' carries w to ~2^-15
+    with pytest.raises(ValueError, match="Cin % 64"):
+        ops.pack_conv_weight(torch.randn(16, 32, 3, 3), None, device="cpu", split=3)
+
+
+def test_phase_summed_kernels_equal_the_upsampled_conv():
+    """conv3x3(nearest_up2(x)) at output pixel (2y + a, 2x + b) == the 2 x 2 convolution of x with the phase-(a, b) summed taps."""
+    from omgsr_amd.ops import _phase_kernels
+    g = torch.Generator().manual_seed(1)
+    x, w = torch.randn(2, 5, 7, 6, generator=g).double(), torch.randn(4, 5, 3, 3, generator=g).double()
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, padding=1)
+    ph = _phase_kernels(w.permute(0, 2, 3, 1).contiguous().float()).double()          # [4, Cout, 2, 2, C]
+    out = torch.zeros_like(ref)
+    for a in (0, 1):
+        for b in (0, 1):
+            out[:, :, a::2, b::2] = F.conv2d(F.pad(x, (1 - b, b, 1 - a, a)), ph[2 * a + b].permute(0, 3, 1, 2))
+    assert (out - ref).abs().max() < 1e-5
