@@ -353,251 +353,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     }
 }
 
-
-// ---- two-group form --------------------------------------------------------------------------------------
-// One workgroup = 8 waves = 256 queries; waves w and w + 4 share a SIMD and belong to groups A and B. A phase is either the
-// MFMA half of a key tile (PV of tile t - 1, then QK of tile t) or its VALU half (V^T fragment reads + online softmax of tile t);
-// group B runs one phase behind group A and ONE workgroup barrier per phase keeps it there, so every SIMD always holds one wave
-// issuing MFMAs and one issuing the exponentials - the schedule of igemm_p8_kernel. Both groups read the SAME K / V^T tiles (half
-// the L2 -> LDS bytes per query); tile t is read from phase 2t (A's QK) to phase 2t + 3 (B's PV), so the ring is three stages deep:
-// tiles t - 1 (V^T), t (K) and t + 1 (in flight, issued at phase 2t). Per-query arithmetic (contraction order, softmax, rescale
-// rule) is the four-wave kernel's, instruction for instruction: results are bit-identical (tests/test_kernels_gpu.py).
-template <typename T, int D, int GRPSEL = 0>
-__global__ __launch_bounds__(512, 2) void attn_pp_kernel(const omgsr_attn_args p, const int ntiles, const float defer) {
-    constexpr int KP = 2 * D, VP = 128;
-    constexpr int K_BYTES = 64 * KP, V_BYTES = D * VP, STAGE = K_BYTES + V_BYTES, NST = 3;
-    constexpr int NKS = D / 16, NDB = D / 32;
-    constexpr int CPRK = D / 8, RPPK = 64 / CPRK, RPBK = 16 / CPRK;
-    constexpr int NPW = D / 64;                  // 1-KiB DMA pieces per wave and operand (K tile = V^T tile = D / 8 pieces, 8 waves)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int grp = (p.o_lo_off == -12345) ? (wave >> 2) : __builtin_amdgcn_readfirstlane(GRPSEL == 0 ? (wave >> 2) : GRPSEL == 1 ? (wave & 1) : ((wave >> 1) & 1));
-    const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 256 + wave * 32;
-
-    const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_bstride + h * D;
-    const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_bstride + h * D;
-    const T* __restrict__ vp = (const T*)p.vt + (int64_t)b * p.vt_bstride + (int64_t)h * D * p.vt_ld;
-
-    x8_t<T> qf[NKS];
-    {
-        int qrow = q0 + l31; if (qrow > p.Lq - 1) qrow = p.Lq - 1;
-        const T* qr = qp + (int64_t)qrow * p.q_ld + 8 * half;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const x8_t<T>*>(qr + 16 * ks);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks]));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the counted waits below count LDS-DMA pieces only
-
-    // DMA staging: wave w moves pieces w and (d = 128) w + 8 of the K tile and of the V^T tile; the swizzle term of a lane repeats
-    // every 16 K rows / 16 V^T rows, so one source offset serves both pieces
-    const int krow = RPPK * wave + lane / CPRK, kc = (lane % CPRK) ^ ((krow / RPBK) & (CPRK - 1));
-    const unsigned kvoff = (unsigned)((krow * p.k_ld + kc * 8) * 2);
-    const int vrow = 8 * wave + (lane >> 3), vc = (lane & 7) ^ ((vrow >> 1) & 7);
-    const unsigned vvoff = (unsigned)((vrow * p.vt_ld + vc * 8) * 2);
-    typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
-    const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;
-    auto issue_tile = [&](const int kt, const int buf) {
-        const unsigned char* kb = reinterpret_cast<const unsigned char*>(kp + (int64_t)kt * 64 * p.k_ld);
-        const unsigned char* vb = reinterpret_cast<const unsigned char*>(vp + (int64_t)kt * 64);
-#pragma unroll
-        for (int j = 0; j < NPW; ++j) {
-            const unsigned dst = lds_base + buf * STAGE + wave * 1024 + j * 8192;
-            glds16_sv(kvoff, kb + (int64_t)j * (8 * RPPK) * p.k_ld * 2, __builtin_amdgcn_readfirstlane(dst));
-            glds16_sv(vvoff, vb + (int64_t)j * 64 * p.vt_ld * 2, __builtin_amdgcn_readfirstlane(dst + K_BYTES));
-        }
-    };
-
-    f32x16_t o[NDB];
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
-    const float sc = p.scale * 1.4426950408889634f;
-
-    unsigned koff[NKS], voff[4];
-    {
-        const int prow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-        const int fk = (prow / RPBK) & (CPRK - 1);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) koff[ks] = (unsigned)(prow * KP + (((2 * ks + half) ^ fk) << 4));
-        const int fv = (l31 >> 1) & 7;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) voff[c] = (unsigned)(l31 * VP + (((2 * c + half) ^ fv) << 4));
-    }
-
-    issue_tile(0, 0);
-
-    f32x16_t s[2];                    // scores of a tile between its MFMA and VALU phases
-    x8_t<T> pf[2][2];                 // its P^T operand between the VALU phase and the next MFMA phase
-    x8_t<T> vpre[4];                  // ... and the first 32 rows of its V^T, fetched under the softmax
-    int issue_buf = 1;                // stage of the next tile to issue (tile index % 3)
-    int kbuf = 0, vbuf = 0;           // stages of this wave's next QK tile / next PV tile
-
-    // phase 2i begins: tile i is first read in it (group A's QK) - it was issued two phases ago and is the only DMA in flight, so
-    // every wave retires its pieces and the barrier publishes them. Then tile i + 1 goes into the stage tile i - 2 left when group
-    // B ran PV(i - 2) in phase 2i - 1.
-    auto enter_even = [&](const int i) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (i + 1 < ntiles) issue_tile(i + 1, issue_buf);
-        issue_buf = issue_buf == NST - 1 ? 0 : issue_buf + 1;
-    };
-    auto enter_odd = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    // MFMA phase: O^T += V^T P^T of tile kt - 1, then S^T = K Q^T of tile kt. The first 32 rows of V^T were fetched under the softmax
-    // (vpre), the K fragments of the first 32-key block and the further V^T blocks are requested here and land under the PV MFMAs:
-    // no LDS latency is exposed after the phase barrier.
-    auto mfma_phase = [&](const int kt) {
-        const unsigned char* Ks = lds + kbuf * STAGE;
-        x8_t<T> kf[2][NKS];
-        if (kt < ntiles) {
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) kf[0][ks] = *reinterpret_cast<const x8_t<T>*>(Ks + koff[ks]);
-        }
-        if (kt > 0) {
-            const unsigned char* Vs = lds + vbuf * STAGE + K_BYTES;
-            x8_t<T> vf[2][4];
-#pragma unroll
-            for (int db = 0; db < NDB; ++db) {
-                if (db + 1 < NDB) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) vf[(db + 1) & 1][c] = *reinterpret_cast<const x8_t<T>*>(Vs + 32 * (db + 1) * VP + voff[c]);
-                }
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) o[db] = mfma32(db == 0 ? vpre[2 * sb + u] : vf[db & 1][2 * sb + u], pf[sb][u], o[db]);
-                __builtin_amdgcn_s_setprio(0);
-            }
-            vbuf = vbuf == NST - 1 ? 0 : vbuf + 1;
-        }
-        __builtin_amdgcn_sched_barrier(0);        // the score zero-fill below is issued under the PV MFMAs, not in front of them
-        if (kt < ntiles) {
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) kf[1][ks] = *reinterpret_cast<const x8_t<T>*>(Ks + 32 * KP + koff[ks]);
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[sb][r] = 0.0f;
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) s[sb] = mfma32(kf[sb][ks], qf[ks], s[sb]);
-            __builtin_amdgcn_s_setprio(0);
-            kbuf = kbuf == NST - 1 ? 0 : kbuf + 1;
-        }
-        // ... and the MFMAs stay in front of the barrier that ends their phase
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) asm volatile("" : "+v"(s[sb]));
-#pragma unroll
-        for (int i = 0; i < NDB; ++i) asm volatile("" : "+v"(o[i]));
-    };
-    // VALU phase of a tile: online softmax (base 2, one query per lane pair), P^T operand
-    auto valu_phase = [&]() {
-        {
-            const unsigned char* Vs = lds + vbuf * STAGE + K_BYTES;      // this tile's V^T (resident since its QK phase), rows 0..31 of d
-#pragma unroll
-            for (int c = 0; c < 4; ++c) vpre[c] = *reinterpret_cast<const x8_t<T>*>(Vs + voff[c]);
-        }
-        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};       // four independent chains: one wave per SIMD runs this phase alone
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx[2 * sb + (r >> 3)] = fmaxf(mx[2 * sb + (r >> 3)], s[sb][r]);
-        float mt = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);
-        if (__any((m_new - m_run) * sc > defer)) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < NDB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-            m_run = m_new;
-        }
-        const float neg_m = -m_run * sc;
-        float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[sb][r], sc, neg_m));
-                s[sb][r] = e;
-                rs[r & 3] += e;
-            }
-        l_run += (rs[0] + rs[1]) + (rs[2] + rs[3]);
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[sb][u][j] = (T)s[sb][8 * u + j];
-        // a barrier orders memory only: without these the compiler sinks the whole softmax (register arithmetic) past the phase barrier,
-        // next to the PV MFMAs that consume it - i.e. back into the other group's VALU phase
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(pf[sb][u]));
-#pragma unroll
-        for (int i = 0; i < NDB; ++i) asm volatile("" : "+v"(o[i]));
-        asm volatile("" : "+v"(l_run), "+v"(m_run));
-    };
-
-    // 2 * ntiles + 2 phases; group A: M(0) V(0) M(1) ... V(n - 1) M(n) -, group B the same one phase later: - M(0) V(0) ... M(n)
-    if (grp == 0) {
-        for (int i = 0; i <= ntiles; ++i) {
-            enter_even(i);
-            mfma_phase(i);
-            enter_odd();
-            if (i < ntiles) valu_phase();
-        }
-    } else {
-        for (int i = 0; i <= ntiles; ++i) {
-            enter_even(i);
-            if (i > 0) valu_phase();
-            enter_odd();
-            mfma_phase(i);
-        }
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    const int qrow = q0 + l31;
-    if (qrow < p.Lq) {
-        T* op = (T*)p.o + (int64_t)b * p.o_bstride + (int64_t)qrow * p.o_ld + h * D + 4 * half;
-        const int lo_off = p.o_lo_off;
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float v0 = o[db][4 * g] * inv, v1 = o[db][4 * g + 1] * inv, v2 = o[db][4 * g + 2] * inv, v3 = o[db][4 * g + 3] * inv;
-                u32x2_t w;
-                w[0] = pack2<T>(v0, v1);
-                w[1] = pack2<T>(v2, v3);
-                *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g) = w;
-                if (lo_off > 0) {
-                    const x8_t<T> hv = __builtin_bit_cast(x8_t<T>, (u32x4_t){w[0], w[1], 0u, 0u});
-                    u32x2_t l;
-                    l[0] = pack2<T>(v0 - (float)hv[0], v1 - (float)hv[1]);
-                    l[1] = pack2<T>(v2 - (float)hv[2], v3 - (float)hv[3]);
-                    *reinterpret_cast<u32x2_t*>(op + lo_off + 32 * db + 8 * g) = l;
-                }
-            }
-    }
-}
-
 float g_defer_max = 0.0f;
 
 template <int D, bool DMA>
@@ -618,22 +373,6 @@ int launch_attn(const omgsr_attn_args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-
-template <int D, int GRPSEL = 0>
-int launch_attn_pp(const omgsr_attn_args& a, hipStream_t st) {
-    constexpr int LDS = 3 * (64 * 2 * D + D * 128);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp_kernel<bf16_t, D, GRPSEL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pp_kernel<f16_t, D, GRPSEL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int ntiles = a.Lk / 64;
-    dim3 grid((a.Lq + 255) / 256, a.H, a.B);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL((attn_pp_kernel<T, D, GRPSEL>), grid, dim3(512), LDS, st, a, ntiles, g_defer_max));
-    return (int)hipGetLastError();
-}
 }  // namespace
 
 extern "C" int omgsr_set_attention_defer_max(float log2_threshold) {
@@ -655,13 +394,6 @@ extern "C" int omgsr_attention(const omgsr_attn_args* ap, void* stream) {
     // LDS-DMA staging needs whole 64-key tiles (a DMA piece cannot be masked) and 32-bit source offsets
     static const char* var = getenv("OMGSR_ATTN_VARIANT");      // A/B runs: "0" = register-staged K / V^T tiles everywhere
     const bool dma = (a.Lk & 63) == 0 && a.k_ld < (1 << 22) && a.vt_ld < (1 << 22) && !(var && var[0] == '0');
-    const char* ppv = getenv("OMGSR_ATTN_PP");                   // A/B runs and the bit-equality test: "1" = the two-group kernel wherever it applies (read per call)
-    if (dma && ppv && ppv[0] == '1' && a.Lk >= 128) {
-        const char* gs = getenv("OMGSR_ATTN_GRP");
-        const int g = gs ? atoi(gs) : 0;
-        if (a.D == 64) return g == 1 ? launch_attn_pp<64, 1>(a, st) : g == 2 ? launch_attn_pp<64, 2>(a, st) : launch_attn_pp<64>(a, st);
-        if (a.D == 128) return g == 1 ? launch_attn_pp<128, 1>(a, st) : g == 2 ? launch_attn_pp<128, 2>(a, st) : launch_attn_pp<128>(a, st);
-    }
     if (a.D == 64) return dma ? launch_attn<64, true>(a, st) : launch_attn<64, false>(a, st);
     if (a.D == 128) return dma ? launch_attn<128, true>(a, st) : launch_attn<128, false>(a, st);
     return OMGSR_E_SHAPE;
