@@ -530,8 +530,8 @@ def cpu_leg_f(device, tiers, side, tile, overlap):
 
 def f1024_record(args, device, _lib):
     """BASELINE configs[3] (OMGSR-F 256->1024, FLUX.1-dev-shaped DiT at full depth + FLUX VAE) inside the default run, so that the
-    89.8 TFLOP/image configuration is timed under the same driver clock as the headline: the accurate tier at batch 4 and the
-    reference's default bf16 at batch 8 (the per-GPU share of configs[4]), each with its own roofline / stages, plus parity and a
+    89.8 TFLOP/image configuration is timed under the same driver clock as the headline: the accurate tier and the reference's default bf16, both at
+    batch 8 (the per-GPU share of configs[4]), each with its own roofline / stages, plus parity and a
     CPU baseline on the bounded (reduced-depth) sample of cpu_leg_f."""
     import torch
     from omgsr_amd import ops
@@ -543,7 +543,7 @@ def f1024_record(args, device, _lib):
     pipe, _ = build_f(device, 0, 1, torch.float32)
     rec["setup_s"] = round(time.time() - t0, 1)
     nsteps = 3
-    for tier, B in (("fp32", 4), ("bf16", 8)):
+    for tier, B in (("fp32", 8), ("bf16", 8)):
         wd = getattr(torch, DTYPES[tier])
         if tier != "fp32":      # the same modules, cast in place to the reference's default dtype
             pipe = OMGSR_F_Infer(None, None, device, wd, 244, 1.0, vae=pipe.vae, flux_transformer=pipe.flux_transformer)

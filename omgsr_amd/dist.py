@@ -99,9 +99,9 @@ def module_checksum(module: torch.nn.Module) -> torch.Tensor:
 
 def replicas_identical(module: torch.nn.Module) -> bool:
     """all_reduce(MAX) and all_reduce(MIN) of the checksum agree <=> every rank holds the same bits."""
-    cs = module_checksum(module)
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return True
+        return True              # no peers: nothing to compare (and no 12 G-element reduction in front of a profiled run)
+    cs = module_checksum(module)
     hi, lo = cs.clone(), cs.clone()
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)

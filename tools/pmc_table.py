@@ -3,8 +3,9 @@ MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's 1024 SIMDs) / (10
 GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs), when both are present; LDS active % = SQ_LDS_IDX_ACTIVE / (256 CUs * cycles). Usage: pmc_table.py <counter_collection.csv>"""
 import collections, csv, re, sys
 
-FAM = [("igemm_halo_kernel", re.compile(r"igemm_halo_kernel")), ("igemm_dma_kernel", re.compile(r"igemm_dma_kernel")),
-       ("igemm_kernel", re.compile(r"igemm_kernel")), ("attn_kernel", re.compile(r"attn_kernel")),
+FAM = [("igemm_halo_multi_kernel", re.compile(r"igemm_halo_multi_kernel")), ("igemm_halo_kernel", re.compile(r"igemm_halo_kernel")),
+       ("igemm_p8_kernel", re.compile(r"igemm_p8_kernel")), ("igemm_dma_kernel", re.compile(r"igemm_dma_kernel")),
+       ("igemm_kernel", re.compile(r"igemm_kernel")), ("splitk_reduce", re.compile(r"splitk_reduce")), ("attn_kernel", re.compile(r"attn_kernel")),
        ("gn_apply", re.compile(r"gn_apply")), ("layernorm", re.compile(r"layernorm"))]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for r in csv.DictReader(open(sys.argv[1])):

@@ -1,9 +1,10 @@
 """Assemble profiles/<tag>_*.md + <tag>_traffic.json from what tools/profile_round.sh left under gpurun_out/prof_<dir>.
-Usage: python tools/profile_summary.py gpurun_out/prof_r02b r02_s1024_accurate "title of the workload" [r02_traffic] """
+Usage: python tools/profile_summary.py gpurun_out/prof_r02b r02_s1024_accurate "title of the workload" [r02_traffic ["extra bench flags"]] """
 import json, os, shutil, sys
 
 src, tag, title = sys.argv[1], sys.argv[2], sys.argv[3]
 ttag = sys.argv[4] if len(sys.argv) > 4 else tag + "_traffic"
+extra = (" " + sys.argv[5]) if len(sys.argv) > 5 else ""
 bench = json.loads(open(os.path.join(src, "bench_under_trace.json")).read().strip().splitlines()[-1])
 traffic = json.load(open(os.path.join(src, "traffic.json")))
 roof = bench["roofline"]
@@ -11,7 +12,7 @@ fam = traffic["families"]
 lines = []
 lines.append(f"# rocprofv3 --kernel-trace --stats of the default bench: {title}\n")
 lines.append(f"Command (GPU box, `tools/profile_round.sh`): `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 "
-             f"--no-cpu-baseline --no-fast-tiers --no-f1024`; config {json.dumps(bench['config'])}, dtype {bench['dtype']}. "
+             f"--no-cpu-baseline --no-fast-tiers --no-f1024{extra}`; config {json.dumps(bench['config'])}, dtype {bench['dtype']}. "
              f"5 pipeline passes in the trace (1 warm-up + 3 timed + 1 roofline pass).")
 lines.append(f"bench line under the profiler: {bench['ms_per_step']} ms/step ({bench['value']} {bench['unit']}). bench.py's HIP-event leg in the "
              f"same run: igemm family {roof['kernel_ms']} ms / {roof['launches']} launches; per kernel (total ms per pass, algorithmic TFLOP/s): "
