@@ -320,6 +320,10 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
         return _pack_mx(w, bias if bias is None else bias.detach().to(dev), cout, cin, R, S, dev, upsample_phases)
     if split not in (1, 2) or w_split not in (1, 2):
         raise ValueError("split / w_split must be 1 or 2")
+    if w_split == 2 and bool(torch.equal(w.to(act_dtype()).float(), w)):
+        # every value is exact in the compute type (an fp16 / bf16 checkpoint's layers that no LoRA merge touched): w_lo == 0, and a
+        # segment of zeros adds exactly 0 to the accumulator - drop it (same bits, one K segment less)
+        w_split = 1
     in_ld = cin8 * split
     w_raw = w
     w = _segments(w, split, w_split)

@@ -80,6 +80,10 @@ def test_split_weight_packings(accurate_tier):
     assert ((rows[..., :C] + rows[..., 2 * C:]) - ref).abs().max() < 2.0 ** -20 * ref.abs().max()
     pw = ops.pack_conv_weight(w, None, device="cpu", split=1, w_split=2)
     assert pw.cin == 2 * C and pw.row_channels == C           # the contraction wraps over the operand row (omgsr_igemm_args.in_ld)
+    # weights that are exact in the compute type have w_lo == 0: the low segment is dropped at pack time (same bits, less work)
+    pw = ops.pack_conv_weight(w_hi, None, device="cpu", split=2, w_split=2)
+    assert pw.w_split == 1 and pw.cin == 2 * C and pw.row_channels == 2 * C and torch.equal(pw.w[:Cout].float().reshape(Cout, 9, 2 * C), rows[..., :2 * C])
+    assert ops.pack_linear_weight(w_hi[:, :, 0, 0], None, device="cpu", split=1, w_split=2).cin == C
     # the mixed-precision form: per tap 4C bytes [w_hi fp16 | fp8(w_hi 2^s1) | fp8(w_lo 2^s2)], scales as E8M0 exponents
     pw = ops.pack_conv_weight(w, None, device="cpu", split=3)
     n16, e_w1, e_a1, e_w2, e_a2 = pw.mx
