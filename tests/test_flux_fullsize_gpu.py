@@ -13,6 +13,7 @@ Tiers: fp32 = accurate tier at the north-star bar (rel-L2 <= 1e-3, PSNR >= 60 dB
 module is cast to bf16 (weights rounded to 8-bit mantissas, like `--weight_dtype bf16` does) and compared with the SAME fp32
 oracle, so its bound includes the weight rounding of the tier (stated below, measured 2026-10 on MI355X).
 """
+import os
 import time
 
 import pytest
@@ -40,11 +41,12 @@ def f_case():
     with torch.device("meta"):
         pf = FluxTransformer2DModel()
     pf = pf.to_empty(device=DEV)
-    seeded_init_device_(pf, 404)                       # full-mantissa fp32 weights, generated on the GPU
-    ov = seeded_init_(R.AutoencoderKL(**FLUX_VAE_CONFIG), 303, rounded=False).eval()
-    g = torch.Generator().manual_seed(4321)
-    x = synthetic_lq(1, 1024, 1024, seed=1234)
-    eps = torch.randn(1, 16, 128, 128, generator=torch.Generator().manual_seed(99))
+    draw = int(os.environ.get("OMGSR_FLUX_DRAW", "0"))      # other weight / input / noise draws (DESIGN.md §4 records draws 0-2)
+    seeded_init_device_(pf, 404 + 31 * draw)           # full-mantissa fp32 weights, generated on the GPU
+    ov = seeded_init_(R.AutoencoderKL(**FLUX_VAE_CONFIG), 303 + 31 * draw, rounded=False).eval()
+    g = torch.Generator().manual_seed(4321 + draw)
+    x = synthetic_lq(1, 1024, 1024, seed=1234 + draw)
+    eps = torch.randn(1, 16, 128, 128, generator=torch.Generator().manual_seed(99 + draw))
     pe, pooled = torch.randn(1, 512, 4096, generator=g), torch.randn(1, 768, generator=g)
     tids, iids = torch.zeros(512, 3), prepare_latent_image_ids(64, 64)
     ov.posterior_noise = eps

@@ -8,6 +8,8 @@ and posterior noise, at the real SD2.1-base / FLUX.1-dev layer shapes:
     and reduced DEPTH (2 double + 2 single blocks: the fp32 oracle of all 57 blocks needs 48 GB and ~90 TFLOP on the CPU)
 The fast tiers (bf16 = the reference's default dtype, fp16) run the same comparison against THEIR bound, which is what
 16-bit activation storage allows (tests/emulate_numerics.py reproduces both numbers on the CPU), not the north-star's."""
+import os
+
 import pytest
 import torch
 
@@ -113,7 +115,8 @@ def test_flux_full_width_vs_oracle():
 ROBUST_REL_L2 = 8e-4          # 25 % head-room under the north-star's 1e-3
 
 
-@pytest.mark.parametrize("wseed", [0, 1, 2])
+# OMGSR_ROBUST_DRAWS=<n> widens the sweep beyond the three weight draws the suite runs by default (DESIGN.md §4 records a 12-draw run)
+@pytest.mark.parametrize("wseed", list(range(int(os.environ.get("OMGSR_ROBUST_DRAWS", "3")))))
 def test_accurate_tier_full_mantissa_weights_over_seeds(wseed):
     """OMGSR-S 128->512 at SD2.1 shapes with weights that carry FULL fp32 mantissas (nothing pre-rounded to a 16-bit-representable
     value: what a checkpoint looks like after the reference's fp32 LoRA merge, infer/omgsr_s_infer_model.py:16-23), three weight
