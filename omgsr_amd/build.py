@@ -41,7 +41,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     out = lib_path()
     stamp = out + ".sha256"
-    digest = _source_digest()
+    # OMGSR_BUILD_ABLATIONS=1 adds the experiment-only kernel instantiations (parts of a kernel compiled out for timing runs, the
+    # schedules kept for A/B: profiles/r02_dma_ablation.md); the shipped library leaves them out
+    defs = ["-DOMGSR_BUILD_ABLATIONS"] if os.environ.get("OMGSR_BUILD_ABLATIONS", "0") == "1" else []
+    digest = _source_digest() + "".join(defs)
     if not force and os.path.isfile(out) and os.path.isfile(stamp) and open(stamp).read().strip() == digest:
         return out
     if not os.path.exists(hipcc):
@@ -57,10 +60,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     def compile_one(src: str) -> str:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         with open(os.path.join(CSRC, src), "rb") as f:
-            want = hashlib.sha256(hdr.digest() + f.read()).hexdigest()
+            want = hashlib.sha256(hdr.digest() + f.read() + "".join(defs).encode()).hexdigest()
         if not force and os.path.isfile(obj) and os.path.isfile(obj + ".sha256") and open(obj + ".sha256").read().strip() == want:
             return obj
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *defs,
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -301,6 +301,8 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     }
     g.splits = 1;
     g.nk = g.nk_total;
+#ifdef OMGSR_BUILD_ABLATIONS      // python -m omgsr_amd.build with OMGSR_BUILD_ABLATIONS=1: the experiment-only instantiations (profiles/r02_dma_ablation.md);
+                                  // the shipped library leaves them out (20 kernels, 2/3 of this file's compile time)
     static const char* shape = getenv("OMGSR_DMA_WAVES");      // A/B runs: "256" = allow the lockstep 8-wave 256 x 256 tile again
     static const char* abl = ablation_env("OMGSR_DMA_ABLATE");      // timing experiments only: results are garbage (needs OMGSR_ABLATION_OK=1)
     static const char* var = getenv("OMGSR_DMA_VARIANT");     // A/B runs: "0" = LDS-DMA issued in front of the MFMAs
@@ -324,6 +326,9 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     if ((shape && shape[0] == '2') && (a.Cout_pad % 256) == 0 && logical_cols >= 256 && t256 >= 200 &&
         cols256 * 16 <= cols128 * 17)
         return early ? launch_dma<2, 4, 5>(a, g, st) : launch_dma<2, 4>(a, g, st);
+#else
+    const bool early = false;
+#endif
     // tile-count quantisation on the 512 slots (2 workgroups per CU): when the 256-row grid leaves the last round under
     // ~3/4 full and the 192-row grid fills it better, take 192 x 128
     {
@@ -335,6 +340,10 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
         if (!force256 && (g.M % 192) == 0 && (force192 || (eff(t256b) < 0.78 && eff(t192) > eff(t256b) + 0.1)))
             return launch_dma<2, 2, 0, 192>(a, g, st);
     }
-    return early ? launch_dma<2, 2, 5>(a, g, st) : launch_dma<2, 2>(a, g, st);
+#ifdef OMGSR_BUILD_ABLATIONS
+    if (early) return launch_dma<2, 2, 5>(a, g, st);
+#endif
+    (void)early;
+    return launch_dma<2, 2>(a, g, st);
 }
 }  // namespace omgsr
