@@ -44,6 +44,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     # OMGSR_BUILD_ABLATIONS=1 adds the experiment-only kernel instantiations (parts of a kernel compiled out for timing runs, the
     # schedules kept for A/B: profiles/r02_dma_ablation.md); the shipped library leaves them out
     defs = ["-DOMGSR_BUILD_ABLATIONS"] if os.environ.get("OMGSR_BUILD_ABLATIONS", "0") == "1" else []
+    defs += os.environ.get("OMGSR_EXTRA_DEFS", "").split()          # A/B builds of compile-time variants (e.g. -DOMGSR_NT_STORE)
     digest = _source_digest() + "".join(defs)
     if not force and os.path.isfile(out) and os.path.isfile(stamp) and open(stamp).read().strip() == digest:
         return out
