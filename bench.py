@@ -353,7 +353,8 @@ DENOISER_TFLOP = {"s512": 0.804, "s1024": 9 * 0.804, "f1024": 74.4}      # per i
 def find_traffic(args, workload, weight_dtype, B):
     """`roofline.traffic` comes from rocprofv3 PMC passes, which cannot run inside this process: tools/profile_round.sh collects them
     for one (workload, tier, batch) and tools/profile_summary.py writes profiles/r<round>_traffic.json. Take --traffic-file, else
-    the newest such file whose recorded args equal this run's; a stale / absent file gives traffic = null, never a wrong number."""
+    the newest such file whose recorded args equal this run's; a stale / absent file gives traffic = null, never a wrong number.
+    Returns (family bytes per launch, per-kernel rows {bench kernel name: row}, path, kernel-source digest)."""
     import glob
     cands = [args.traffic_file] if args.traffic_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True)
     for tpath in cands:
@@ -364,8 +365,46 @@ def find_traffic(args, workload, weight_dtype, B):
         if tj.get("workload") == workload and tj.get("weight_dtype") == weight_dtype and tj.get("batch") == B:
             fam = (tj.get("families") or {}).get("igemm")
             if fam:
-                return round(fam["hbm_bytes_per_launch"]), os.path.relpath(tpath, ROOT), tj.get("source_digest")
-    return None, None, None
+                return fam, tj.get("kernels") or {}, os.path.relpath(tpath, ROOT), tj.get("source_digest")
+    return None, None, None, None
+
+
+def attach_traffic(roofline, per_kernel, fam, krows):
+    """Per-kernel measured HBM bytes next to the algorithmic `bytes_per_launch` - only where the PMC run saw EXACTLY the launches this
+    process timed for that kernel (a mean over a subset of the launches is not a traffic figure). rocprofv3 sees
+    kernel names, bench.py dispatch variants: the split-K variant is an igemm_dma_kernel launch plus a splitk_reduce_kernel launch."""
+    mine = {k: v["launches"] for k, v in per_kernel.items()}
+    sk = mine.get("igemm_dma_kernel(split-K)+splitk_reduce_kernel", 0)
+    expect = {k: v for k, v in mine.items() if "(split-K)" not in k}
+    if sk:
+        expect["igemm_dma_kernel"] = expect.get("igemm_dma_kernel", 0) + sk
+        expect["splitk_reduce_kernel"] = sk
+    ok_all, total_meas, total_n = True, 0.0, 0
+    for name, n in expect.items():
+        row = krows.get(name)
+        seen = row.get("launches_per_pipeline_pass") if row else None
+        ok = row is not None and seen is not None and abs(seen - n) < 0.5
+        ok_all = ok_all and (ok or name == "attn_kernel")
+        if name.startswith(("igemm", "splitk")) and ok:
+            total_meas += row["hbm_bytes_per_launch"] * n
+            total_n += n
+        tgt = per_kernel.get(name)
+        if tgt is None and name == "splitk_reduce_kernel":
+            continue
+        if tgt is not None:
+            tgt["traffic_bytes_per_launch"] = round(row["hbm_bytes_per_launch"]) if ok else None
+            tgt["traffic_launches_seen"] = seen
+            if ok and tgt["bytes_per_launch"] > 0 and "(split-K)" not in name and not (name == "igemm_dma_kernel" and sk):
+                tgt["traffic_over_algorithmic"] = round(row["hbm_bytes_per_launch"] / tgt["bytes_per_launch"], 3)
+    n_igemm = sum(n for k, n in expect.items() if k.startswith(("igemm", "splitk")))
+    if ok_all and total_n == n_igemm and roofline["launches"] > 0:
+        # family figure: measured bytes of EVERY igemm launch of the step / the step's igemm launches as bench.py counts them
+        roofline["traffic"] = round(total_meas / roofline["launches"])
+        roofline["traffic_over_algorithmic"] = round(total_meas / roofline["launches"] / max(roofline["algorithmic_bytes_per_launch"], 1), 3)
+    else:
+        roofline["traffic"] = None
+        roofline["traffic_note"] = "PMC launch counts do not match this step's launches per kernel: no family figure quoted"
+    roofline["traffic_launch_counts_match"] = ok_all
 
 
 def roofline_leg(_lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, wdtype, workload=None, weight_dtype=None, steps=None):
@@ -410,10 +449,13 @@ def roofline_leg(_lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, 
                     "achieved_all_mfma_kernels": round(tflop_per_img * B / (mfma_ms * 1e-3), 2),
                     "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"]),
                     "kernels": per_kernel}
-        traffic, tsrc, tdigest = find_traffic(args, workload, weight_dtype, B)
-        if traffic is not None:
+        fam, krows, tsrc, tdigest = find_traffic(args, workload, weight_dtype, B)
+        if fam is not None:
             from omgsr_amd.build import _source_digest
-            roofline["traffic"] = traffic
+            if krows:
+                attach_traffic(roofline, per_kernel, fam, krows)
+            else:            # a pre-round-4 file (family mean over whatever its regex matched): not trusted
+                roofline["traffic_note"] = f"{tsrc} has no per-kernel rows (pre-round-4 summary): regenerate with tools/profile_round.sh"
             roofline["traffic_source"] = f"{tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)"
             roofline["traffic_kernels_current"] = (tdigest == _source_digest()) if tdigest else None     # False: kernels changed since the PMC run
     names = {1: "igemm", 2: "attention", 3: "groupnorm", 4: "layernorm", 5: "elementwise", 6: "softmax"}

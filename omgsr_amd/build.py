@@ -64,11 +64,31 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             want = hashlib.sha256(hdr.digest() + f.read() + "".join(defs).encode()).hexdigest()
         if not force and os.path.isfile(obj) and os.path.isfile(obj + ".sha256") and open(obj + ".sha256").read().strip() == want:
             return obj
+        # -Rpass-analysis=kernel-resource-usage: the register / spill / scratch / LDS figures of every kernel, kept next to the object
+        # (<src>.resources.txt) - tests/test_kernel_resources_cpu.py pins the hand-scheduled kernels' figures against a committed table
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *defs,
-               "-c", os.path.join(CSRC, src), "-o", obj]
+               "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        import re
+        remarks = [ln for ln in r.stderr.splitlines() if "remark:" in ln]
+        # (each remark is followed by a source excerpt and a caret line; "In file included from" lines precede remarks in headers)
+        rest, lines = [], r.stderr.splitlines()
+        for i, ln in enumerate(lines):
+            if "remark:" in ln or not ln.strip() or re.match(r"^\s*\d*\s*\|", ln):
+                continue
+            if ln.startswith("In file included from") and i + 1 < len(lines) and ("remark:" in lines[i + 1] or lines[i + 1].startswith("In file included")):
+                continue
+            if re.match(r"^\d+ (warning|remark)s? generated", ln):
+                continue
+            rest.append(ln)
+        if rest:
+            print("\n".join(rest), file=sys.stderr)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        with open(os.path.join(LIBDIR, src + ".resources.txt"), "w") as f:
+            f.write("\n".join(remarks) + "\n")
         with open(obj + ".sha256", "w") as f:
             f.write(want)
         return obj
@@ -81,6 +101,66 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     subprocess.run(cmd, check=True)
     with open(stamp, "w") as f:
         f.write(digest)
+    return out
+
+
+def _short_name(mangled: str) -> str:
+    """`_ZN12_GLOBAL__N_117igemm_halo_kernelIDF16_Li0ELb0ELb0ELi9ELb1EEEv...` -> `igemm_halo_kernel<fp16,0,0,0,9,1>` (the image's c++filt
+    predates the _Float16 / __bf16 manglings DF16_ / DF16b, so the few forms this library uses are decoded here)."""
+    import re
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", mangled)
+    if m:
+        n = int(m.group(1))
+        rest = mangled[m.end():]
+        name, rest = rest[:n], rest[n:]
+    else:
+        m = re.match(r"_Z(\d+)", mangled)
+        if not m:
+            return mangled
+        n = int(m.group(1))
+        name, rest = mangled[m.end():m.end() + n], mangled[m.end() + n:]
+    args = []
+    if rest.startswith("I"):
+        body = rest[1:]
+        while body and not body.startswith("E"):
+            for rx, fn in ((r"DF16_", lambda g: "fp16"), (r"DF16b", lambda g: "bf16"), (r"Lin(\d+)E", lambda g: "-" + g.group(1)),
+                           (r"Li(\d+)E", lambda g: g.group(1)), (r"Lb([01])E", lambda g: g.group(1)), (r"f", lambda g: "float")):
+                g = re.match(rx, body)
+                if g:
+                    args.append(fn(g))
+                    body = body[g.end():]
+                    break
+            else:
+                args.append("?")
+                break
+    return name + ("<" + ",".join(args) + ">" if args else "")
+
+
+def kernel_resources() -> dict:
+    """{demangled kernel name: {vgpr, agpr, sgpr, spill_vgpr, spill_sgpr, scratch, occupancy, lds}} of the library as built
+    (parsed from the compiler's kernel-resource-usage remarks the build keeps next to each object)."""
+    import re
+    build_library()
+    keys = {"VGPRs": "vgpr", "AGPRs": "agpr", "SGPRs": "sgpr", "VGPRs Spill": "spill_vgpr", "SGPRs Spill": "spill_sgpr",
+            "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy", "LDS Size [bytes/block]": "lds"}
+    out, mangled = {}, []
+    for src in SOURCES:
+        path = os.path.join(LIBDIR, src + ".resources.txt")
+        if not os.path.isfile(path):        # object predates this build step: recompile it
+            build_library(force=True)
+        cur = None
+        for line in open(path):
+            m = re.search(r"remark: (?:[^:]+:\d+:\d+: +)?([A-Za-z \[\]/]+): +(\S+)", line)
+            if not m:
+                continue
+            k, v = m.group(1).strip(), m.group(2)
+            if k == "Function Name":
+                cur = {"source": src}
+                mangled.append((v, cur))
+            elif cur is not None and k in keys:
+                cur[keys[k]] = int(v)
+    for m, rec in mangled:
+        out[_short_name(m)] = rec
     return out
 
 

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
         }
     }
     const int64_t ldo = p.out_ld > 0 ? p.out_ld : p.Cout;
+    float amax = 0.0f;          // fp16 range guard, as in the fused epilogues: largest magnitude written as a 16-bit value
     for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
         float x = v[e];
         if (p.gate) x *= p.gate[n + e];
@@ -251,11 +252,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
                                                        : (float)((const T*)p.residual)[(int64_t)m * p.Cout + n + e];
         if (p.out_dtype == OMGSR_OUT_BF16) {
             // same overflow behaviour as the fused epilogues (pack2 / split8): fp16 saturates at +-65504 instead of hi = inf, lo = -inf
+            amax = fmaxf(amax, fabsf(x));
             if constexpr (std::is_same<T, f16_t>::value) x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
             const T hi = (T)x;
             ((T*)p.out)[(int64_t)m * ldo + n + e] = hi;
             if (p.out_lo_off > 0) ((T*)p.out)[(int64_t)m * ldo + p.out_lo_off + n + e] = (T)(x - (float)hi);
         } else ((float*)p.out)[(int64_t)m * ldo + n + e] = x;
+    }
+    if constexpr (std::is_same<T, f16_t>::value) {
+        if (p.overflow_flag && p.out_dtype == OMGSR_OUT_BF16 && amax > 65504.0f) atomicOr(p.overflow_flag, 1u);
     }
 }
 

@@ -347,7 +347,7 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= gate8[e];
             }
-            if (!resb) note8(v);            // (with a residual the stored value is v + r: a 16-bit residual output is a fast-tier form)
+            if (p.out_layout != OMGSR_LAYOUT_NHWC) note8(v);     // (the transposed form carries no residual)
             if (p.out_layout == OMGSR_LAYOUT_NHWC) {
                 const int64_t o = (int64_t)m * ldo + n;
                 const int64_t ro = (int64_t)m * p.Cout + n;
@@ -359,6 +359,7 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
                         for (int e = 0; e < 8; ++e) v[e] += rf[e];
                     }
                     if (p.out_dtype == OMGSR_OUT_BF16) {
+                        note8(v);               // after the residual add, like the fast path: the value that is actually stored
                         *reinterpret_cast<u32x4_t*>(outb + o) = pack8<T>(v);
                     } else {
                         *reinterpret_cast<f32x4_t*>(outf + o) = (f32x4_t){v[0], v[1], v[2], v[3]};
@@ -368,6 +369,7 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
                     for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
                         float x = v[e];
                         if (resb) x += (float)resb[ro + e];
+                        if constexpr (OVF_CHK) amax = fmaxf(amax, fabsf(x));
                         if (p.out_dtype == OMGSR_OUT_BF16) outb[o + e] = (T)x; else outf[o + e] = x;
                     }
                 }

@@ -262,15 +262,20 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
         return v
 
     def _mod_deps(self):
-        deps = self.__dict__.get("_mod_dep_list")
-        if deps is None:            # the parameter OBJECTS never change (load_state_dict / .to() / LoRA merges write in place or bump _version)
-            deps = [p for m in (self.time_text_embed, self.norm_out) for p in m.parameters()]
-            for b in list(self.transformer_blocks) + list(self.single_transformer_blocks):
-                for nm in ("norm1", "norm1_context", "norm"):
-                    if hasattr(b, nm):
-                        deps += list(getattr(b, nm).parameters())
-            self.__dict__["_mod_dep_list"] = deps
-        return deps
+        """The parameters the modulation tables depend on, as a flat cached list. load_state_dict / .to() / in-place LoRA merges keep
+        the parameter OBJECTS (and bump _version), but load_state_dict(assign=True) / swap_tensors-style conversion REPLACE them: the
+        cache holds (owner module, name, parameter) and is rebuilt when any owner no longer holds that object (360 `is` tests per
+        forward instead of a recursive .parameters() walk)."""
+        owners = self.__dict__.get("_mod_dep_owners")
+        if owners is not None and all(m._parameters.get(n) is p for m, n, p in owners):
+            return self.__dict__["_mod_dep_list"]
+        mods = [self.time_text_embed, self.norm_out]
+        for b in list(self.transformer_blocks) + list(self.single_transformer_blocks):
+            mods += [getattr(b, nm) for nm in ("norm1", "norm1_context", "norm") if hasattr(b, nm)]
+        owners = [(sub, n, p) for m in mods for sub in m.modules() for n, p in sub._parameters.items() if p is not None]
+        self.__dict__["_mod_dep_owners"] = owners
+        self.__dict__["_mod_dep_list"] = [p for _, _, p in owners]
+        return self.__dict__["_mod_dep_list"]
 
     def _mod_key(self, timestep, guidance) -> tuple:
         """(scaled timestep, scaled guidance, identity of every parameter the modulation tables depend on)."""

@@ -67,9 +67,11 @@ class OMGSR_F_Infer(torch.nn.Module):
         self.flux_transformer = flux_transformer.eval()
         self.device = device
         self.verbose = verbose
+        from ..precision import RangeFallback
         if weight_dtype == torch.float32:
             from ..precision import resolve
             resolve(precision_policy, vae=self.vae, flux=self.flux_transformer)
+        self.range_fallback = RangeFallback(self.vae, self.flux_transformer)
 
     def _init_tiled_vae(self, encoder_tile_size=256, decoder_tile_size=256, fast_decoder=False, fast_encoder=False,
                         color_fix=False, vae_to_gpu=True):
@@ -85,7 +87,7 @@ class OMGSR_F_Infer(torch.nn.Module):
         tok = ops.flux_pack(z_nhwc, C)
         B = tok.shape[0]
         # the same two tensors on every call (the DiT reads their value once per tensor: no per-image host synchronisation)
-        key = (str(tok.device), B)
+        key = (str(tok.device), B, float(self.t_curr), float(self.guidance_scale))
         if self.__dict__.get("_tg_key") != key:
             self.__dict__["_tg"] = (torch.tensor([self.t_curr], device=tok.device),
                                     torch.full((B,), self.guidance_scale, device=tok.device, dtype=torch.float32))
@@ -129,16 +131,9 @@ class OMGSR_F_Infer(torch.nn.Module):
             x = ops.nchw_to_nhwc(lq_img.contiguous(), 8)
             img = self.sr_nhwc(x, prompt_embeds, pooled_prompt_embeds, text_ids, latent_image_ids, tile_size, tile_overlap)
             return ops.nhwc_to_nchw(img, channels=3, dtype=ops.io_dtype(lq_img))
-        pred_img = run()
-        torch.cuda.synchronize()
-        if ops.precise() and ops.overflow_seen():
-            # FLUX activations are why the reference defaults to bf16: an fp16 operand left the fp16 range in this call - redo it range-safe
-            import warnings
-            from ..precision import bf16_operand_fallback
-            warnings.warn("OMGSR-F accurate tier: an fp16 MFMA operand exceeded 65504; this call is recomputed with bf16 operands")
-            with bf16_operand_fallback(self.vae, self.flux_transformer):
-                pred_img = run()
-                torch.cuda.synchronize()
+        # FLUX activations are why the reference defaults to bf16: when an fp16 operand leaves the fp16 range the call runs again with
+        # bf16 operands and the pipeline STAYS range-safe (precision.RangeFallback), instead of paying two passes and two re-packs per image
+        pred_img = self.range_fallback.run(run, "OMGSR-F")
         t = time.time() - start_time
         if self.verbose:
             print(f"Inference time per image: {t}s")

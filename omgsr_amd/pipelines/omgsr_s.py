@@ -49,9 +49,11 @@ class OMGSR_S_Infer(torch.nn.Module):
         self.vae = vae.to(device=device, dtype=weight_dtype).eval()
         self.unet = unet.to(device=device, dtype=weight_dtype).eval()
         self.device = device
+        from ..precision import RangeFallback
         if weight_dtype == torch.float32:       # which layers carry two-term split operands / weights (omgsr_amd/precision.py)
             from ..precision import resolve
             resolve(precision_policy, vae=self.vae, unet=self.unet)
+        self.range_fallback = RangeFallback(self.vae, self.unet)
 
     def _init_tiled_vae(self, encoder_tile_size=256, decoder_tile_size=256, fast_decoder=False, fast_encoder=False,
                         color_fix=False, vae_to_gpu=True):
@@ -103,16 +105,9 @@ class OMGSR_S_Infer(torch.nn.Module):
             x = ops.nchw_to_nhwc(lq_img.contiguous(), 8)
             img = self.sr_nhwc(x, prompt_embeds, tile_size, tile_overlap)
             return ops.nhwc_to_nchw(img, channels=3, dtype=ops.io_dtype(lq_img), clamp=(-1.0, 1.0))
-        pred_img = run()
-        torch.cuda.synchronize()
-        if ops.precise() and ops.overflow_seen():
-            # an fp16 operand left the fp16 range somewhere in this call (the stores saturate at +-65504): redo it range-safe
-            import warnings
-            from ..precision import bf16_operand_fallback
-            warnings.warn("OMGSR-S accurate tier: an fp16 MFMA operand exceeded 65504; this call is recomputed with bf16 operands")
-            with bf16_operand_fallback(self.vae, self.unet):
-                pred_img = run()
-                torch.cuda.synchronize()
+        # an fp16 operand that leaves the fp16 range somewhere in this call (the stores saturate at +-65504) makes the call run again
+        # range-safe, and the pipeline stays that way (precision.RangeFallback: `self.range_fallback.count / .sticky`)
+        pred_img = self.range_fallback.run(run, "OMGSR-S")
         t = time.time() - start_time
         if self.verbose:
             print(f"Inference time per image: {t}s")

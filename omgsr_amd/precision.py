@@ -255,6 +255,63 @@ def bf16_operand_fallback(*models):
         ops.set_compute_dtype(torch.float32)
 
 
+class RangeFallback:
+    """Per-pipeline state of the fp16 range guard. The first call whose fp16 operands clip is recomputed with bf16 operands (every
+    operand and weight as a two-term split) - and the pipeline then STAYS in that mode (`sticky`): with a checkpoint whose
+    activations leave the fp16 range (FLUX: the reason the reference defaults to bf16) every image would otherwise pay an fp16 pass,
+    a re-pack of every weight, a bf16 pass and a re-pack back. `count` = calls that overflowed; `sticky` = running range-safe;
+    `reset()` returns to fp16 operands and the policy that was active when the pipeline was built."""
+
+    def __init__(self, *models):
+        self.models = [m for m in models if m is not None]
+        self.count = 0
+        self.sticky = False
+        self._saved = None
+
+    def enter(self) -> None:
+        from . import ops
+        if self._saved is None:
+            self._saved = [[(m, m.op_split, m.w_split, m.out_inner16) for m in model.modules() if isinstance(m, (Conv2d, Linear))]
+                           for model in self.models]
+            for model in self.models:
+                apply_policy(model, [r"."], [r"."])
+        ops.set_compute_dtype(torch.float32, operand_dtype=torch.bfloat16)
+        self.sticky = True
+
+    def reassert(self) -> None:
+        """Called at the top of every forward(): another pipeline may have switched the process-wide tier in between."""
+        from . import ops
+        if self.sticky and (not ops.precise() or ops.act_dtype() != torch.bfloat16):
+            ops.set_compute_dtype(torch.float32, operand_dtype=torch.bfloat16)
+
+    def reset(self) -> None:
+        from . import ops
+        if self._saved is not None:
+            for rows in self._saved:
+                for m, a, w, i16 in rows:
+                    m.op_split, m.w_split, m.out_inner16 = a, w, i16
+            self._saved = None
+        if self.sticky:
+            ops.set_compute_dtype(torch.float32)
+        self.sticky = False
+
+    def run(self, run, what: str):
+        """run() -> result (synchronised by the caller's contract: this method synchronises before reading the guard word)."""
+        import warnings
+        from . import ops
+        self.reassert()
+        out = run()
+        torch.cuda.synchronize()
+        if not self.sticky and ops.precise() and ops.overflow_seen():
+            self.count += 1
+            warnings.warn(f"{what} accurate tier: an fp16 MFMA operand exceeded 65504; this call is recomputed with bf16 operands and "
+                          f"the pipeline stays range-safe (pipe.range_fallback.reset() returns to fp16 operands)")
+            self.enter()
+            out = run()
+            torch.cuda.synchronize()
+        return out
+
+
 def apply_policy(model: nn.Module, act: Iterable[str], weight: Iterable[str] = (), inner16: Iterable[str] = ()) -> None:
     """An explicit policy for one model (pipelines: `precision_policy=` / the CLI's --precision_policy all): lists of regular
     expressions over module names; [r"."] splits every layer (activation and weight to 2^-22: 3x the MFMA work)."""

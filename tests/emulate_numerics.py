@@ -292,13 +292,24 @@ def main():
     ap.add_argument("--fp32-weights", action="store_true", help="seeded weights with full fp32 mantissas (not pre-rounded to bf16 values)")
     ap.add_argument("--wseed", type=int, default=0)
     ap.add_argument("--xseed", type=int, default=1234)
+    ap.add_argument("--test-draw", default="", help="W,X: the weights / input / prompt / noise of weight draw W, input draw X of "
+                                                    "tests/test_fullsize_parity_gpu.py::test_accurate_tier_full_mantissa_weights_over_seeds")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
-    vae = seeded_init_(R.AutoencoderKL(), 101 + a.wseed, rounded=not a.fp32_weights).eval()
-    u = seeded_init_(R.UNet2DConditionModel(), 202 + a.wseed, rounded=not a.fp32_weights).eval()
-    x = synthetic_lq(1, a.side, a.side, seed=a.xseed)
-    eps = torch.randn(1, 4, a.side // 8, a.side // 8, generator=torch.Generator().manual_seed(99))
-    ehs = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(4321)).to(torch.bfloat16).float()
+    if a.test_draw:
+        w_, x_ = (int(v) for v in a.test_draw.split(","))
+        vae = seeded_init_(R.AutoencoderKL(), 1101 + 17 * w_, rounded=False).eval()
+        u = seeded_init_(R.UNet2DConditionModel(), 2202 + 17 * w_, rounded=False).eval()
+        g_ = torch.Generator().manual_seed(5000 + 10 * w_ + x_)
+        x = synthetic_lq(1, 512, 512, seed=777 + 10 * w_ + x_)
+        ehs = torch.randn(1, 77, 1024, generator=g_)
+        eps = torch.randn(1, 4, 64, 64, generator=g_)
+    else:
+        vae = seeded_init_(R.AutoencoderKL(), 101 + a.wseed, rounded=not a.fp32_weights).eval()
+        u = seeded_init_(R.UNet2DConditionModel(), 202 + a.wseed, rounded=not a.fp32_weights).eval()
+        x = synthetic_lq(1, a.side, a.side, seed=a.xseed)
+        eps = torch.randn(1, 4, a.side // 8, a.side // 8, generator=torch.Generator().manual_seed(99))
+        ehs = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(4321)).to(torch.bfloat16).float()
     alpha_t = R.DDPMScheduler().alphas_cumprod[273]
     with torch.no_grad():
         t0 = time.time()

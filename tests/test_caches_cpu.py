@@ -1,0 +1,55 @@
+"""Host-side caches that must not go stale: the Flux modulation-table dependency list and the pipeline's cached
+timestep / guidance tensors. CPU only: no kernel is called."""
+import torch
+
+
+def _tiny_flux():
+    from omgsr_amd.diffusers_api.transformer_flux import FluxTransformer2DModel
+    return FluxTransformer2DModel(num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=1, joint_attention_dim=64,
+                                  pooled_projection_dim=32, in_channels=16)
+
+
+def test_flux_modulation_deps_follow_replaced_parameters():
+    m = _tiny_flux()
+    d1 = m._mod_deps()
+    assert m._mod_deps() is d1                                   # steady state: the cached list, no module walk
+    want = [p for mm in (m.time_text_embed, m.norm_out) for p in mm.parameters()]
+    for b in list(m.transformer_blocks) + list(m.single_transformer_blocks):
+        for nm in ("norm1", "norm1_context", "norm"):
+            if hasattr(b, nm):
+                want += list(getattr(b, nm).parameters())
+    assert len(want) == len(d1) and all(a is b for a, b in zip(want, d1))
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})          # in place: same objects, versions bump
+    assert m._mod_deps() is d1
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, assign=True)      # objects REPLACED
+    d2 = m._mod_deps()
+    assert d2 is not d1 and len(d2) == len(d1) and all(a is not b for a, b in zip(d1, d2))
+    assert all(p is q for p, q in zip(d2, [p for mm in (m.time_text_embed, m.norm_out) for p in mm.parameters()]))
+
+
+def test_range_fallback_state_machine_without_gpu(monkeypatch):
+    """RangeFallback bookkeeping (sticky after the first overflow, reset restores the saved policy) with the device calls stubbed."""
+    from omgsr_amd import ops, precision
+    from omgsr_amd.nn import Conv2d, Linear
+    net = torch.nn.Sequential(Conv2d(32, 32, 3, padding=1), Linear(32, 32))
+    net[0].op_split, net[0].w_split, net[1].op_split = 3, 2, 2
+    state = dict(act=torch.float16, precise=True, ovf=[True, False])
+    monkeypatch.setattr(ops, "set_compute_dtype", lambda dt, operand_dtype=None: state.update(act=operand_dtype or torch.float16, precise=dt == torch.float32))
+    monkeypatch.setattr(ops, "precise", lambda: state["precise"])
+    monkeypatch.setattr(ops, "act_dtype", lambda: state["act"])
+    monkeypatch.setattr(ops, "overflow_seen", lambda reset=True: state["ovf"].pop(0))
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    rf = precision.RangeFallback(net)
+    calls = []
+    import warnings
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        rf.run(lambda: calls.append(state["act"]), "test")
+    assert calls == [torch.float16, torch.bfloat16] and rf.count == 1 and rf.sticky and len(wl) == 1
+    assert (net[0].op_split, net[0].w_split, net[1].op_split, net[1].w_split) == (2, 2, 2, 2)
+    state.update(act=torch.bfloat16, precise=False)              # someone else switched the process-wide tier
+    rf.run(lambda: calls.append((state["act"], state["precise"])), "test")
+    assert calls[-1] == (torch.bfloat16, True) and rf.count == 1 and len(calls) == 3      # one pass, re-asserted, guard word not read
+    rf.reset()
+    assert not rf.sticky and state["act"] == torch.float16
+    assert (net[0].op_split, net[0].w_split, net[1].op_split, net[1].w_split) == (3, 2, 2, 1)

@@ -61,34 +61,69 @@ def f_case():
     ops.set_compute_dtype(torch.bfloat16)
 
 
-@pytest.mark.parametrize("tier", ["fp32", "bf16"])       # order matters: the bf16 leg casts the shared module in place
-def test_omgsr_f_1024_full_depth_vs_oracle(f_case, tier):
-    from omgsr_amd import ops
+def _pipe(c, tier):
     from omgsr_amd.diffusers_api import AutoencoderKL, FLUX_VAE_CONFIG
-    from omgsr_amd.pipelines.omgsr_f import OMGSR_F_Infer, get_flux_setting_timesteps
-    from omgsr_amd.testing import psnr, rel_l2
-    c = f_case
+    from omgsr_amd.pipelines.omgsr_f import OMGSR_F_Infer
     wd = torch.float32 if tier == "fp32" else torch.bfloat16
+    pv = AutoencoderKL(**FLUX_VAE_CONFIG)
+    pv.load_state_dict(c["vae_sd"])
+    pf = c["flux"]
+    pf.round_timestep_to_weight_dtype = False      # condition on the exact sigma(t*), like the fp32 oracle does
+    return OMGSR_F_Infer(None, None, DEV, wd, 244, 1.0, vae=pv, flux_transformer=pf), wd
+
+
+# order matters: the bf16 legs cast the shared module in place, so both fp32 cases run first
+@pytest.mark.parametrize("tier,batch", [("fp32", 1), ("fp32", 8), ("bf16", 1), ("bf16", 8)])
+def test_omgsr_f_1024_full_depth_vs_oracle(f_case, tier, batch):
+    """batch 1: the pipeline's image and the DiT's velocity alone against the oracle.
+    batch 8 = the per-GPU share of BASELINE configs[4] (OMGSR-F 256->1024, batch 64 over 8 GPUs; VERDICT r3 'untested config'): the
+    Flux executor flattens the batch to B x 4608-row GEMMs, so igemm_p8_kernel / split-K / attention grids differ from batch 1.
+    Images 0 and 7 of the batch ARE the oracle's image (same input, same posterior noise; images 1-6 are other draws), so the ONE
+    streamed oracle run checks both ends of the flattened row range; and each must agree with the batch-1 result of the same tier
+    up to summation order."""
+    from omgsr_amd import ops
+    from omgsr_amd.pipelines.omgsr_f import get_flux_setting_timesteps
+    from omgsr_amd.testing import psnr, rel_l2, synthetic_lq
+    c = f_case
     tol, min_psnr, tol_dit = BOUNDS[tier]
     try:
-        pv = AutoencoderKL(**FLUX_VAE_CONFIG)
-        pv.load_state_dict(c["vae_sd"])
-        pf = c["flux"]
-        pf.round_timestep_to_weight_dtype = False      # condition on the exact sigma(t*), like the fp32 oracle does
-        pipe = OMGSR_F_Infer(None, None, DEV, wd, 244, 1.0, vae=pv, flux_transformer=pf)
-        pipe.vae.posterior_noise = c["eps"].to(DEV)
+        pipe, wd = _pipe(c, tier)
         to = lambda t: t.to(device=DEV, dtype=wd)      # noqa: E731
-        with torch.no_grad():
-            got, _ = pipe(to(c["x"]), to(c["pe"]), to(c["pooled"]), to(c["tids"]), to(c["iids"]), 128, 64)
-            t_curr = get_flux_setting_timesteps()[-(244 + 1)]
-            vel = pipe.flux_transformer(hidden_states=to(c["tok"]), timestep=torch.tensor([t_curr], device=DEV),
-                                        guidance=torch.full((1,), 1.0, device=DEV), pooled_projections=to(c["pooled"]),
-                                        encoder_hidden_states=to(c["pe"]), txt_ids=to(c["tids"]), img_ids=to(c["iids"]), return_dict=False)[0]
+        if batch == 1:
+            pipe.vae.posterior_noise = c["eps"].to(DEV)
+            with torch.no_grad():
+                got, _ = pipe(to(c["x"]), to(c["pe"]), to(c["pooled"]), to(c["tids"]), to(c["iids"]), 128, 64)
+                t_curr = get_flux_setting_timesteps()[-(244 + 1)]
+                vel = pipe.flux_transformer(hidden_states=to(c["tok"]), timestep=torch.tensor([t_curr], device=DEV),
+                                            guidance=torch.full((1,), 1.0, device=DEV), pooled_projections=to(c["pooled"]),
+                                            encoder_hidden_states=to(c["pe"]), txt_ids=to(c["tids"]), img_ids=to(c["iids"]), return_dict=False)[0]
+        else:
+            others = synthetic_lq(6, 1024, 1024, seed=77)
+            x8 = torch.cat([c["x"], others, c["x"]], dim=0)
+            e8 = torch.cat([c["eps"], torch.randn(6, 16, 128, 128, generator=torch.Generator().manual_seed(5)), c["eps"]], dim=0)
+            pipe.vae.posterior_noise = e8.to(DEV)
+            with torch.no_grad():
+                got8, _ = pipe(to(x8), to(c["pe"]), to(c["pooled"]), to(c["tids"]), to(c["iids"]), 128, 64)
     finally:
         ops.set_compute_dtype(torch.bfloat16)
-    got, vel = got.float().cpu(), vel.float().cpu()
-    e, p, ed = rel_l2(got, c["ref"]), psnr(got, c["ref"]), rel_l2(vel, c["vel"])
-    print(f"OMGSR-F 256->1024, 19+38 blocks, {tier}: pipeline rel-L2 {e:.3e} PSNR {p:.1f} dB; DiT alone rel-L2 {ed:.3e} "
-          f"(bounds {tol:g} / {min_psnr} dB / {tol_dit:g})")
-    assert got.shape == c["ref"].shape and torch.isfinite(got).all() and torch.isfinite(vel).all()
-    assert ed <= tol_dit and e <= tol and p >= min_psnr
+    if batch == 1:
+        got, vel = got.float().cpu(), vel.float().cpu()
+        c.setdefault("got_b1", {})[tier] = got
+        e, p, ed = rel_l2(got, c["ref"]), psnr(got, c["ref"]), rel_l2(vel, c["vel"])
+        print(f"OMGSR-F 256->1024, 19+38 blocks, {tier}: pipeline rel-L2 {e:.3e} PSNR {p:.1f} dB; DiT alone rel-L2 {ed:.3e} "
+              f"(bounds {tol:g} / {min_psnr} dB / {tol_dit:g})")
+        assert got.shape == c["ref"].shape and torch.isfinite(got).all() and torch.isfinite(vel).all()
+        assert ed <= tol_dit and e <= tol and p >= min_psnr
+        return
+    got8 = got8.float().cpu()
+    assert tuple(got8.shape) == (8, 3, 1024, 1024) and torch.isfinite(got8).all()
+    b1 = c.get("got_b1", {}).get(tier)
+    for i in (0, 7):
+        g = got8[i:i + 1]
+        e, p = rel_l2(g, c["ref"]), psnr(g, c["ref"])
+        d = rel_l2(g, b1) if b1 is not None else float("nan")
+        print(f"OMGSR-F 256->1024, 19+38 blocks, {tier}, batch 8, image {i}: rel-L2 {e:.3e} PSNR {p:.1f} dB vs the oracle; vs the batch-1 result {d:.3e}")
+        assert e <= tol and p >= min_psnr
+        if b1 is not None:           # same arithmetic up to summation order (tile shapes / split-K follow the row count)
+            assert d <= (5e-4 if tier == "fp32" else 3e-2)
+    assert rel_l2(got8[1:2], c["ref"]) > 10 * tol           # (the other images really are other images)

@@ -1,0 +1,61 @@
+"""ISA pin of the hand-scheduled kernels: the register allocation, spill counts, scratch size and occupancy of
+every MFMA kernel in the shipped library, as the compiler reports them at build time (-Rpass-analysis=kernel-resource-usage, kept by
+omgsr_amd/build.py), against the committed table tests/golden/kernel_resources.json. The MX halo kernel lives at 256 registers with
+13-14 spilled VGPRs and inline-asm MFMAs between hand-placed s_nops; a compiler or source change that re-spills it, or that drops a
+kernel from two workgroups per CU to one, must fail HERE (build container) and not as a silent slowdown on the GPU box.
+After a deliberate kernel change: `python tools/kernel_resources.py --write`, and read the diff."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tables():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import GOLDEN, pinned
+    from omgsr_amd.build import kernel_resources
+    return pinned(kernel_resources()), json.load(open(GOLDEN))
+
+
+def test_every_pinned_kernel_is_still_built(tables):
+    built, golden = tables
+    missing = sorted(set(golden) - set(built))
+    assert not missing, f"kernels in the committed table that the library no longer contains: {missing}"
+    new = sorted(set(built) - set(golden))
+    assert not new, f"MFMA kernels without a row in tests/golden/kernel_resources.json (run tools/kernel_resources.py --write): {new}"
+
+
+def test_spills_scratch_and_occupancy_did_not_regress(tables):
+    built, golden = tables
+    bad = []
+    for k, g in golden.items():
+        b = built.get(k)
+        if b is None:
+            continue
+        if b["occupancy"] < g["occupancy"]:
+            bad.append(f"{k}: occupancy {g['occupancy']} -> {b['occupancy']} waves/SIMD")
+        if b["spill_vgpr"] > g["spill_vgpr"]:
+            bad.append(f"{k}: spilled VGPRs {g['spill_vgpr']} -> {b['spill_vgpr']}")
+        if b["scratch"] > g["scratch"]:
+            bad.append(f"{k}: scratch {g['scratch']} -> {b['scratch']} bytes/lane")
+        if b["vgpr"] + b.get("agpr", 0) > 256 and b["occupancy"] >= 2:
+            bad.append(f"{k}: {b['vgpr']} + {b.get('agpr', 0)} registers cannot give 2 waves/SIMD")
+    assert not bad, "kernel resources regressed against tests/golden/kernel_resources.json:\n  " + "\n  ".join(bad)
+
+
+def test_the_tight_kernels_are_where_design_says(tables):
+    """the accumulator-heavy kernels run two workgroups per CU (<= 256 registers), the MX halo kernel's spills stay in the
+    low teens, nothing else that ships in the hot path spills more than a handful."""
+    built, _ = tables
+    for k, b in built.items():
+        if k.startswith(("igemm_halo", "igemm_dma", "igemm_p8", "igemm_a8", "attn_kernel")):
+            assert b["occupancy"] >= 2, (k, b)
+    mx = [b for k, b in built.items() if k.startswith("igemm_halo") and k.endswith(",9,1>")]
+    assert mx and all(b["spill_vgpr"] <= 16 and b["scratch"] <= 64 for b in mx), mx
+    for k, b in built.items():
+        if k.startswith("igemm_halo") and not k.endswith(",9,1>") and ",0,1,0,9,0>" not in k:      # (the s_setprio A/B instantiation spills 8)
+            assert b["spill_vgpr"] == 0, (k, b)

@@ -459,6 +459,47 @@ def test_range_guard_flags_clipped_operands():
         ops.set_range_guard(True)
 
 
+def test_range_guard_covers_split_k_and_residual_paths(monkeypatch):
+    """the split-K reduce pass clamps 16-bit outputs like the fused epilogues, so it must raise the overflow word like
+    them (few rows, long K: the shape class of the UNet's 16 x 16 / 8 x 8 projections), GEGLU reduce branch included; and the
+    generic (non-16-byte-row) epilogue path notes the value it STORES, i.e. after the residual add."""
+    import ctypes as C
+    from omgsr_amd import _lib, ops
+    ws_bytes = []
+    orig = ops._igemm
+    def spy(a, device, what):
+        ws_bytes.append(int(_lib.load().omgsr_igemm_workspace_bytes(C.byref(a))))
+        return orig(a, device, what)
+    monkeypatch.setattr(ops, "_igemm", spy)
+    ops.overflow_seen()
+    g = _g(50)
+    x = torch.randn(1, 256, 2560, generator=g).to(DEV)
+    w = torch.randn(1280, 2560, generator=g) * 2560 ** -0.5
+    pw, big = ops.pack_linear_weight(w, None, device=DEV), ops.pack_linear_weight(w * 4e4, None, device=DEV)
+    ops.linear(x, pw, out_dtype=ops.OUT_BF16)
+    assert ws_bytes[-1] > 0, "shape no longer takes split-K: pick another"
+    assert not ops.overflow_seen()
+    y = ops.linear(x, big, out_dtype=ops.OUT_BF16)
+    assert ws_bytes[-1] > 0 and ops.overflow_seen() and y.float().abs().max().item() == 65504.0
+    ops.linear(x, big, out_dtype=ops.OUT_F32)
+    assert ws_bytes[-1] > 0 and not ops.overflow_seen()
+    ops.linear(x, big, out_dtype=ops.OUT_BF16, out_split=2)
+    assert ws_bytes[-1] > 0 and ops.overflow_seen()
+    wg = torch.randn(2 * 1280, 2560, generator=g) * 2560 ** -0.5
+    pg = ops.pack_geglu_weight(wg * 300.0, None, device=DEV)                       # a * gelu(gate) ~ 9e4 x N(0,1) x ...
+    ops.linear(x, pg, out_dtype=ops.OUT_BF16, act=ops.ACT_GEGLU)
+    assert ws_bytes[-1] > 0 and ops.overflow_seen()
+    # generic epilogue path (Cout % 8 != 0) with a residual: only the SUM leaves the range
+    xs = torch.randn(1, 300, 320, generator=g).to(DEV)
+    w2 = torch.randn(324, 320, generator=g) * 320 ** -0.5
+    p2 = ops.pack_linear_weight(w2, None, device=DEV)
+    res = torch.full((1, 300, 324), 6.0e4, device=DEV, dtype=ops.stream_dtype())
+    ops.linear(xs * 2000.0, p2, out_dtype=ops.OUT_BF16, residual=res)             # |x W| ~ 2e3 x N(0,1): + 6e4 crosses 65504 in places
+    assert ops.overflow_seen()
+    ops.linear(xs, p2, out_dtype=ops.OUT_BF16, residual=res * 0.5)
+    assert not ops.overflow_seen()
+
+
 def test_pipeline_falls_back_to_bf16_operands_on_fp16_overflow():
     """Activations past 65504 inside the model: every attention V projection of the UNet is scaled by 2e5 and its output projection
     by 1 / 2e5 - the same function (attention is linear in V) whose V operand no longer fits fp16. The accurate tier notices (one
@@ -499,8 +540,21 @@ def test_pipeline_falls_back_to_bf16_operands_on_fp16_overflow():
         with warnings.catch_warnings(record=True) as wlist:
             warnings.simplefilter("always")
             got, _ = pipe(x.to(DEV), ehs.to(DEV), 16, 8)
-    assert any("65504" in str(w.message) for w in wlist)
-    assert ops.precise() and ops.act_dtype() == torch.float16                     # tier and policy are back
+        assert any("65504" in str(w.message) for w in wlist)
+        # the fallback is STICKY: the pipeline stays range-safe, so the next call is ONE bf16-operand pass with no
+        # warning, no fp16 pass in front of it and no re-pack (same bits as the recomputed call)
+        assert pipe.range_fallback.count == 1 and pipe.range_fallback.sticky
+        assert ops.precise() and ops.act_dtype() == torch.bfloat16
+        with warnings.catch_warnings(record=True) as wlist2:
+            warnings.simplefilter("always")
+            again, _ = pipe(x.to(DEV), ehs.to(DEV), 16, 8)
+        assert not any("65504" in str(w.message) for w in wlist2) and pipe.range_fallback.count == 1
+        assert torch.equal(again, got)
+        ops.set_compute_dtype(torch.bfloat16)                                        # (another pipeline switches the process-wide tier ...)
+        third, _ = pipe(x.to(DEV), ehs.to(DEV), 16, 8)                               # ... and the sticky one re-asserts its own)
+        assert torch.equal(third, got)
+        pipe.range_fallback.reset()
+    assert ops.precise() and ops.act_dtype() == torch.float16                     # reset(): tier and policy are back
     assert snap == [(m.op_split, m.w_split) for m in pipe.unet.modules() if hasattr(m, "op_split")]
     e_clip, e = rel_l2(clipped, ref), rel_l2(got, ref)
     print(f"fp16 operands clipped: rel-L2 {e_clip:.3e}; bf16-operand fallback: rel-L2 {e:.3e}")
