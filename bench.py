@@ -46,7 +46,7 @@ WORKLOADS = {
     "f1024": ("F", 1024, 8, 128, 64, 89.8),        # configs[3] (and the per-GPU share of configs[4]: 64 images over 8 GPUs)
 }
 DTYPES = {"fp32": "float32", "fp16": "float16", "bf16": "bfloat16"}
-IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel", 6: "igemm_halo_kernel<TAPS=4>", 7: "igemm_halo_multi_kernel", 8: "igemm_halo_multi_kernel<TAPS=4>"}
+IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel", 6: "igemm_halo_kernel<TAPS=4>", 7: "igemm_halo_multi_kernel", 8: "igemm_halo_multi_kernel<TAPS=4>", 9: "igemm_gmx_kernel"}
 
 
 def parse(argv=None):
@@ -64,6 +64,7 @@ def parse(argv=None):
     ap.add_argument("--no-fast-tiers", action="store_true", help="skip the short bf16 / fp16 legs")
     ap.add_argument("--no-tiled-vae", action="store_true", help="s1024 only: run the VAE untiled (the reference's shipped default)")
     ap.add_argument("--no-f1024", action="store_true", help="default (s1024, 1 GPU) run only: skip the OMGSR-F 256->1024 record (`workloads.f1024`)")
+    ap.add_argument("--no-latency", action="store_true", help="default (s1024, 1 GPU) run only: skip the batch-1 latency record (`workloads.latency_ms_b1`: eager vs hipGraph replay)")
     ap.add_argument("--traffic-file", default="", help="rocprofv3 PMC summary (tools/profile_summary.py) to take `roofline.traffic` from; "
                                                        "default: the newest profiles/r*_traffic.json whose args match this run")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU oracle (median reported) after one warm-up")
@@ -296,6 +297,13 @@ def main():
         del pipe, step, out
         torch.cuda.empty_cache()
         workloads = {"f1024": f1024_record(args, device, _lib)}
+        ops.set_compute_dtype(wdtype)
+    if rank == 0 and world == 1 and args.workload == "s1024" and not args.no_latency:
+        if workloads is None:
+            del pipe, step, out
+            torch.cuda.empty_cache()
+            workloads = {}
+        workloads["latency_ms_b1"] = latency_b1_record(args, device, _lib)
         ops.set_compute_dtype(wdtype)
 
     if rank == 0:
@@ -611,6 +619,54 @@ def f1024_record(args, device, _lib):
         rec["cpu_baseline"], par = cpu_leg_f(device, ["fp32", "bf16"], side, tile, overlap)
         for tier, pr in par.items():
             rec[tier]["parity"] = pr
+    return rec
+
+
+def latency_b1_record(args, device, _lib):
+    """The reference's OWN operating point: batch 1, one 128 -> 512 image per call (infer/infer_omgsr_s.py:92-93),
+    as wall-clock latency of pipe.forward - eager (every launch issued from Python) and as a hipGraph replay (pipe.enable_graphs():
+    one host call per image) - next to the GPU time of the same step (sum of the kernels' HIP-event times): `gpu_busy_frac` says how
+    launch-bound the eager path is. Replay and eager outputs are compared bit for bit."""
+    import torch
+    from omgsr_amd import ops
+    family, side, _, tile, overlap, tflop = WORKLOADS["s512"]
+    rec = {"config": "OMGSR-S 128->512, batch 1, untiled VAE, latent 64 x 64 (one UNet tile)", "algorithmic_tflop_per_image": tflop}
+    lib = _lib.load()
+    for tier in ("fp32", "bf16"):
+        wd = getattr(torch, DTYPES[tier])
+        pipe, _ = build_s(device, 0, 1, wd)
+        inp = make_inputs(family, side, 1, tile, 0, device, wd)
+        pipe.vae.posterior_noise = inp["eps"].to(device)
+        step = make_step(pipe, family, inp, tile, overlap)
+
+        def timed(n):
+            with torch.no_grad():
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(n):
+                    t0 = time.perf_counter()
+                    out = step()                      # forward() synchronises on both sides, like the reference's
+                    ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2] * 1e3, out
+        timed(3)
+        eager_ms, out_eager = timed(20)
+        lib.omgsr_timing_reset(); lib.omgsr_timing_enable(1)
+        with torch.no_grad():
+            step()
+        kinds, kernels, _ = collect_timing(_lib)
+        lib.omgsr_timing_enable(0); lib.omgsr_timing_reset()
+        gpu_ms = sum(k["ms"] for k in kinds.values())
+        launches = sum(k["launches"] for k in kinds.values())
+        pipe.enable_graphs(True)
+        timed(3)                                      # first call eager, second captures, third replays
+        graph_ms, out_graph = timed(20)
+        rec[tier] = {"eager_ms": round(eager_ms, 3), "graph_ms": round(graph_ms, 3), "gpu_kernel_ms": round(gpu_ms, 3), "timed_launches": launches,
+                     "gpu_busy_frac_eager": round(gpu_ms / eager_ms, 3), "gpu_busy_frac_graph": round(gpu_ms / graph_ms, 3),
+                     "images_per_s_graph": round(1e3 / graph_ms, 2), "graph_replays": pipe.graphs.replays, "graph_captures": pipe.graphs.captures,
+                     "graph_equals_eager_bitwise": bool(torch.equal(out_eager, out_graph)),
+                     "frac_of_mfma_peak_graph": round(tflop / (graph_ms * 1e-3) / PEAK_DENSE_TFLOPS, 4)}
+        del pipe, step, inp
+        torch.cuda.empty_cache()
     return rec
 
 

@@ -51,10 +51,10 @@ extern "C" {
 #define OMGSR_EL_16 0
 #define OMGSR_EL_F32 1
 #define OMGSR_EL_SPLIT 2
-/* OMGSR_EL_MX (outputs of the GroupNorm apply / cast kernels only; fp16 compute type): the three-part operand of the mixed-precision
+/* OMGSR_EL_MX (outputs of the GroupNorm apply / LayerNorm / cast kernels, omgsr_igemm's out_mx, omgsr_attention's o_mx; fp16 compute type): the three-part operand of the mixed-precision
  * split. A row of C logical channels (C % 64 == 0) is 4C bytes = 2C 16-bit slots: [a_hi fp16 | a_lo' fp8 e4m3 | a_hi' fp8 e4m3] with
- * a_lo' = (a - a_hi) * 2^11 and a_hi' = a_hi, both clamped to +-448. Its consumer (omgsr_igemm_args.mx_chunks16 > 0, halo-tile
- * kernel) multiplies the first half by fp16 weights in fp16 MFMAs and the fp8 parts by fp8 copies of w_hi / w_lo in block-scaled MFMAs
+ * a_lo' = (a - a_hi) * 2^11 and a_hi' = a_hi, both clamped to +-448. Its consumer (omgsr_igemm_args.mx_chunks16 > 0: the halo-tile
+ * kernel for 3x3 convs, igemm_gmx_kernel for GEMM-shaped problems) multiplies the first half by fp16 weights in fp16 MFMAs and the fp8 parts by fp8 copies of w_hi / w_lo in block-scaled MFMAs
  * (v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 rate), all into one fp32 accumulator. */
 #define OMGSR_EL_MX 3
 
@@ -135,8 +135,9 @@ typedef struct omgsr_igemm_args {
     int32_t mx_chunks16;   /* > 0: `in` is an OMGSR_EL_MX operand and `weight_cm` (/ `weight_ph`) its mixed-precision weight: per tap the first
                               mx_chunks16 32-channel chunks are fp16 x fp16, the remaining (Cin / 32 - mx_chunks16) 64-byte chunks hold 64 fp8
                               channels each - first the a_lo' x w_hi' segment, then a_hi' x w_lo' - and run as block-scaled fp8 MFMAs with
-                              the E8M0 scales below (weight / operand, per segment). 3x3 stride 1 pad 1 (or the phase form) only: these
-                              problems always take the halo-tile kernel. Cin = 2 x logical channels (16-bit slots), in_ld = 0. */
+                              the E8M0 scales below (weight / operand, per segment). Two shapes: 3x3 stride 1 pad 1 (or the phase form), which
+                              always takes the halo-tile kernel; and 1x1 stride 1 (every Linear: `weight` rows are [w_hi fp16 | w_hi' fp8 | w_lo' fp8],
+                              K_pad = Cin), which takes igemm_gmx_kernel (ABI v14). Cin = 2 x logical channels (16-bit slots), in_ld = 0. */
     int32_t mx_scale_w1, mx_scale_a1, mx_scale_w2, mx_scale_a2;   /* E8M0 exponents (127 = 2^0): the instruction multiplies each product by 2^(w - 127) 2^(a - 127) */
     int32_t out_mx;        /* 1: the 16-bit output is written in the OMGSR_EL_MX form (4 Cout bytes per pixel; out_dtype OMGSR_OUT_BF16, NHWC,
                               Cout % 64 == 0, fp16 compute type, no GroupNorm statistics): the operand of a following mixed-precision conv */
@@ -245,6 +246,10 @@ typedef struct omgsr_attn_args {
     float scale;
     int32_t o_lo_off;      /* > 0: o is written as the two-term split: lo lands o_lo_off columns after hi
                               (o_lo_off >= H*D, o_ld >= o_lo_off + H*D, o_lo_off % 4 == 0) */
+    int32_t o_mx;          /* 1: o is written in the mixed-precision operand form OMGSR_EL_MX (the output projection is an MX GEMM,
+                              omgsr_igemm with mx_chunks16 > 0): a row of C = H*D channels is 4C bytes [hi fp16 | lo' fp8 | hi' fp8];
+                              o_ld = 2C (16-bit slots), o_lo_off = 0, C % 64 == 0, fp16 compute type (ABI v14) */
+    int32_t reserved0;
 } omgsr_attn_args;
 /* Process-wide (default 0): the online softmax moves its running maximum only when a row's maximum grows by more than 2^t in
  * the scaled base-2 domain (probabilities then reach 2^t instead of 1; the result is the same quotient). 0 = exact running

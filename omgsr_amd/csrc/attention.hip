@@ -27,6 +27,7 @@
 //    read through the permutation that swaps bits 2 and 3 of the row index: C row (r&3) + 8(r>>2) + 4h of S^T then holds
 //    key 16(r>>3) + 8h + (r&7), i.e. the P^T operand's contraction slots are 8 CONSECUTIVE keys.
 #include "common.hip.h"
+#include <type_traits>
 #include "../../include/omgsr_hip.h"
 #include "timing.hip.h"
 #include <stdlib.h>
@@ -342,7 +343,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
                 w[0] = pack2<T>(v0, v1);
                 w[1] = pack2<T>(v2, v3);
                 *reinterpret_cast<u32x2_t*>(op + 32 * db + 8 * g) = w;
-                if (lo_off > 0) {
+                if (p.o_mx) {
+                    // OMGSR_EL_MX row (the consumer is an MX GEMM): [hi fp16 (2C B) | (v - hi) 2^11 fp8 (C B) | hi fp8 (C B)], C = H * D
+                    // channels; o_ld counts 16-bit slots of the row (2C). Channel c = h * D + 4 half + 32 db + 8 g.
+                    if constexpr (std::is_same<T, f16_t>::value) {
+                        const x8_t<T> hv = __builtin_bit_cast(x8_t<T>, (u32x4_t){w[0], w[1], 0u, 0u});
+                        const float h0 = (float)hv[0], h1 = (float)hv[1], h2 = (float)hv[2], h3 = (float)hv[3];
+                        const float sc = (float)(1 << OMGSR_MX_LO_SHIFT);
+                        unsigned char* row = reinterpret_cast<unsigned char*>((T*)p.o + (int64_t)b * p.o_bstride + (int64_t)qrow * p.o_ld);
+                        const int Cc = p.H * D, c = h * D + 4 * half + 32 * db + 8 * g;
+                        *reinterpret_cast<unsigned int*>(row + 2 * Cc + c) = pack4_fp8((v0 - h0) * sc, (v1 - h1) * sc, (v2 - h2) * sc, (v3 - h3) * sc);
+                        *reinterpret_cast<unsigned int*>(row + 3 * Cc + c) = pack4_fp8(h0, h1, h2, h3);
+                    }
+                } else if (lo_off > 0) {
                     const x8_t<T> hv = __builtin_bit_cast(x8_t<T>, (u32x4_t){w[0], w[1], 0u, 0u});
                     u32x2_t l;
                     l[0] = pack2<T>(v0 - (float)hv[0], v1 - (float)hv[1]);
@@ -387,6 +400,8 @@ extern "C" int omgsr_attention(const omgsr_attn_args* ap, void* stream) {
     if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return OMGSR_E_BADARG;
     if ((a.q_ld & 7) || (a.k_ld & 7) || (a.vt_ld & 7) || (a.o_ld & 3) || a.vt_ld < a.Lk) return OMGSR_E_SHAPE;
     if (a.o_lo_off < 0 || (a.o_lo_off && ((a.o_lo_off & 3) || a.o_lo_off < a.H * a.D || a.o_ld < (int64_t)a.o_lo_off + a.H * a.D))) return OMGSR_E_SHAPE;
+    // MX output: the whole row belongs to this call (heads at column 0, o_ld = 2 H D slots), fp16 compute type
+    if (a.o_mx && (a.o_lo_off || a.o_ld != 2ll * a.H * a.D || ((a.H * a.D) & 63) || omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const double flops = 4.0 * (double)a.B * a.H * (double)a.Lq * a.Lk * a.D;
     const double bytes = 2.0 * (double)a.B * a.H * a.D * (2.0 * a.Lq + 2.0 * a.Lk);

@@ -30,6 +30,8 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, boo
 int igemm_halo_launch_multi(const omgsr_igemm_args* a, const IgemmGeo* g0, int count, hipStream_t st, bool phase);
 bool igemm_p8_wanted(const omgsr_igemm_args& a, const IgemmGeo& g);
 int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
+bool igemm_gmx_ok(const omgsr_igemm_args& a);
+int igemm_gmx_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 int igemm_halo_tiles(const omgsr_igemm_args& a, bool phase = false);
 int igemm_halo_gn_slots(const omgsr_igemm_args& a, bool phase = false);
 }
@@ -412,9 +414,10 @@ int validate_args(omgsr_igemm_args& a) {
     if (a.in_ld == a.Cin) a.in_ld = 0;
     const int ksegs = 1 + (a.in_split ? 1 : 0) + (a.w_split ? 1 : 0);      // K-concat segments of one logical channel set
     if (a.Cin % (8 * ksegs)) return OMGSR_E_SHAPE;
-    if (a.mx_chunks16 < 0 || (a.mx_chunks16 > 0 && !mx_geometry_ok(a))) return OMGSR_E_SHAPE;
+    // an MX operand is understood by the halo-tile kernel (3x3 convs, mx_geometry_ok) and by the MX GEMM kernel (1x1: igemm_gmx.hip)
+    if (a.mx_chunks16 < 0 || (a.mx_chunks16 > 0 && !mx_geometry_ok(a) && !omgsr::igemm_gmx_ok(a))) return OMGSR_E_SHAPE;
     if (a.out_mx && (a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cout & 63) || a.out_lo_off || a.out_ld || a.gn_partial ||
-                     a.act == OMGSR_ACT_GEGLU || omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
+                     omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
     if (a.gn_partial) {                            // must be exactly what omgsr_igemm_gn_slots / _gn_entries promised
         int nslot, entries;
         gn_plan(a, &nslot, &entries);
@@ -556,6 +559,8 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
             return (int)hipGetLastError();
         }
     }
+    // GEMM-shaped problem over a mixed-precision operand (the UNet's transformer-block linears in the accurate tier)
+    if (a.mx_chunks16 > 0 && omgsr::igemm_gmx_ok(a)) { ts.rec.variant = 9; return omgsr::igemm_gmx_launch(a, g, st); }
     // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
     if (use_halo_phase(a)) { ts.rec.variant = 6; return omgsr::igemm_halo_launch(a, g, st, true); }
     if (use_halo(a)) { ts.rec.variant = 3; return omgsr::igemm_halo_launch(a, g, st); }

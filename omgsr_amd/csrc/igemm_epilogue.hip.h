@@ -417,4 +417,6 @@ struct IgemmGeo {
     int nk_total;   // K steps of the whole contraction
     int splits;     // split-K factor (1 = none)
     int ntm, ntn;   // tile counts
+    int interleave; // halo-tile kernel, phase form: 1 = the four output phases of a tile are consecutive logical blocks of ONE x-only grid
+                    // (they share an XCD's L2: the low-res patch is fetched from HBM once, not four times); 0 = blockIdx.y = phase
 };

@@ -70,7 +70,7 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 // fragment instead of 2 x 2 waves over 128 columns. The im2col kernels gather every input pixel nine times out of L2
 // (3.2 GB for a 1.4 MPixel x 128-channel map: 350 us, L2-bound at 70 TFLOP/s); here the patch is read once.
 template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false>
-OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const int bid, const int bidy) {
+OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const int tile, const int bidy) {      // tile: logical (XCD-remapped) tile index
     constexpr int WTN = NARROW ? 32 : 64, FM = NARROW ? 2 : 4, FN = NARROW ? 1 : 2, BNK = NARROW ? 32 : 128;
     using HG = HaloGeo<TAPS>;
     constexpr int KS = HG::KS, PW = HG::PW, PROWS = HG::PROWS, APIECES = HG::APIECES, APW = HG::APW, A_BYTES = HG::A_BYTES;
@@ -85,7 +85,6 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = NARROW ? wave : (wave >> 1), wn = NARROW ? 0 : (wave & 1);
 
-    const int tile = xcd_remap(bid, g.ntm * g.ntn);
     const int tn = tile % g.ntn, tm = tile / g.ntn;
     const int per_img = g.tiles_x * g.tiles_y;
     const int img = tm / per_img;
@@ -348,7 +347,19 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
 
 template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
-    halo_body<T, ABL, PRIO, NARROW, TAPS, MX>(p, g, (int)blockIdx.x, (int)blockIdx.y);
+    int tile, phase;
+    // Phase form (TAPS = 4). The four phases of a tile read the SAME low-res patch. With blockIdx.y = phase the grid ran phase 0 over every
+    // tile, then phase 1 ...: the input (1.5 GB at the decoder's last upsampler, far beyond L2 + MALL) came from HBM four times (8.7 GB
+    // measured against 4.0 GB algorithmic per launch, profiles/r04_*traffic*.json). Interleaved: logical block L = 4 tile + phase of an
+    // x-only grid; the XCD remap hands each XCD a contiguous L range, so a tile's phases are dispatched together (blocks b, b + 8, b + 16,
+    // b + 24) onto one XCD and three of the four patch reads hit its L2.
+    if (TAPS == 4 && g.interleave) {
+        const int L = xcd_remap((int)blockIdx.x, 4 * g.ntm * g.ntn);
+        tile = L >> 2; phase = L & 3;
+    } else {
+        tile = xcd_remap((int)blockIdx.x, g.ntm * g.ntn); phase = (int)blockIdx.y;
+    }
+    halo_body<T, ABL, PRIO, NARROW, TAPS, MX>(p, g, tile, phase);
 }
 
 // Several problems that share weights and epilogue options in ONE launch (the tiled VAE runs every layer once per tile-shape group:
@@ -364,11 +375,21 @@ struct HaloMulti {
 };
 template <typename T, bool NARROW, int TAPS, bool MX = false>
 __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMulti m) {
-    int s = 0;
-    while (s + 1 < m.count && (int)blockIdx.x >= m.start[s + 1]) ++s;          // wave-uniform
-    const int bid = (int)blockIdx.x - m.start[s];
-    if (bid >= m.g[s].ntm * m.g[s].ntn) return;                                 // filler block of the 8-aligned range
-    halo_body<T, 0, false, NARROW, TAPS, MX>(m.p[s], m.g[s], bid, (int)blockIdx.y);
+    int s = 0, tile, phase;
+    if (TAPS == 4 && m.g[0].interleave) {      // x-only grid of 4 x the 8-aligned ranges: logical block L = 4 tile + phase inside each problem's range (see igemm_halo_kernel)
+        while (s + 1 < m.count && (int)blockIdx.x >= 4 * m.start[s + 1]) ++s;      // wave-uniform
+        const int b = (int)blockIdx.x - 4 * m.start[s];
+        const int q = (m.start[s + 1] - m.start[s]) >> 1;                       // blocks per XCD of this range (4 x n8 / 8), a multiple of 4
+        const int L = (b & 7) * q + (b >> 3);
+        tile = L >> 2; phase = L & 3;
+        if (tile >= m.g[s].ntm * m.g[s].ntn) return;                            // filler tile of the 8-aligned range
+    } else {
+        while (s + 1 < m.count && (int)blockIdx.x >= m.start[s + 1]) ++s;          // wave-uniform
+        const int bid = (int)blockIdx.x - m.start[s];
+        if (bid >= m.g[s].ntm * m.g[s].ntn) return;                                 // filler block of the 8-aligned range
+        tile = xcd_remap(bid, m.g[s].ntm * m.g[s].ntn); phase = (int)blockIdx.y;
+    }
+    halo_body<T, 0, false, NARROW, TAPS, MX>(m.p[s], m.g[s], tile, phase);
 }
 
 
@@ -376,6 +397,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMult
 // several problems / the mixed-precision form)
 static inline bool halo_geo(const omgsr_igemm_args& a, IgemmGeo& g, const bool phase) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    static const char* il = getenv("OMGSR_PHASE_INTERLEAVE");      // A/B runs: "0" = blockIdx.y = phase (every phase sweeps the whole map)
+    g.interleave = (phase && !(il && il[0] == '0')) ? 1 : 0;
     g.nk = a.Cin / 32;
     g.tiles_x = ((phase ? a.W : a.Wo) + TW - 1) / TW;          // phase form: tiles of the LOW-res map, four phases each
     g.tiles_y = ((phase ? a.H : a.Ho) + TH - 1) / TH;

@@ -41,7 +41,7 @@ int igemm_halo_launch_multi(const omgsr_igemm_args* a, const IgemmGeo* g0, const
     m.start[count] = at;
     const int rc = multi_attrs();
     if (rc != 0) return rc;
-    dim3 grid(at, phase ? 4 : 1, 1);
+    const dim3 grid = (phase && m.g[0].interleave) ? dim3(4 * at) : dim3(at, phase ? 4 : 1, 1);
     if (a[0].mx_chunks16 > 0) return igemm_halo_launch_multi_mx(&m, (unsigned)at, st);
     if (phase) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_multi_kernel<T, false, 4>), grid, dim3(256), LDS_BYTES, st, m));
     else if (narrow) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_multi_kernel<T, true, 9>), grid, dim3(256), LDS_BYTES, st, m));

@@ -20,7 +20,7 @@ int igemm_halo_launch_multi_mx(const void* halo_multi, unsigned blocks, hipStrea
     const HaloMulti& m = *reinterpret_cast<const HaloMulti*>(halo_multi);         // igemm_halo_multi.hip's struct of the same header
     const int rc = mx_attrs();
     if (rc != 0) return rc;
-    if (m.p[0].upsample) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 4, true>), dim3(blocks, 4), dim3(256), LDS_BYTES, st, m);
+    if (m.p[0].upsample) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 4, true>), m.g[0].interleave ? dim3(4 * blocks) : dim3(blocks, 4), dim3(256), LDS_BYTES, st, m);
     else hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, true>), dim3(blocks), dim3(256), LDS_BYTES, st, m);
     return (int)hipGetLastError();
 }
@@ -28,7 +28,7 @@ int igemm_halo_launch_mx(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) 
     halo_geo(a, g, a.upsample != 0);
     const int rc = mx_attrs();
     if (rc != 0) return rc;
-    if (a.upsample) hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 4, true>), dim3(g.ntm * g.ntn, 4), dim3(256), LDS_BYTES, st, a, g);
+    if (a.upsample) hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 4, true>), g.interleave ? dim3(4 * g.ntm * g.ntn) : dim3(g.ntm * g.ntn, 4), dim3(256), LDS_BYTES, st, a, g);
     else hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 9, true>), dim3(g.ntm * g.ntn), dim3(256), LDS_BYTES, st, a, g);
     return (int)hipGetLastError();
 }

@@ -342,7 +342,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     o8[e] = (f[r][i][e] - mu[r]) * rs * (PRE ? av[PRE ? i : 0][e] : ga[e]) + (PRE ? bv[PRE ? i : 0][e] : be[e]);
-                store8<T, YEL>(y, (row0 + r) * (YEL == 2 ? 2 * C : C) + c8 * 8, C, o8);
+                if constexpr (YEL == 3) {
+                    if constexpr (std::is_same<T, f16_t>::value) store8_mx<T>(y, (row0 + r) * 4 * (int64_t)C, C, c8 * 8, o8);   // OMGSR_EL_MX row: 4C bytes
+                } else store8<T, YEL>(y, (row0 + r) * (YEL == 2 ? 2 * C : C) + c8 * 8, C, o8);
             }
         }
     }
@@ -393,7 +395,9 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const void* __rest
             load_affine8(a, c8 * 8, 1.0f, ga); load_affine8(b, c8 * 8, 0.0f, be);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o8[e] = (f[i][e] - mu) * rs * ga[e] + be[e];
-            store8<T, YEL>(y, row * (YEL == 2 ? 2 * C : C) + c8 * 8, C, o8);
+            if constexpr (YEL == 3) {
+                if constexpr (std::is_same<T, f16_t>::value) store8_mx<T>(y, row * 4 * (int64_t)C, C, c8 * 8, o8);
+            } else store8<T, YEL>(y, row * (YEL == 2 ? 2 * C : C) + c8 * 8, C, o8);
         }
     }
 }
@@ -668,10 +672,13 @@ int layernorm_launch(const void* x, void* y, const float* a, const float* b, int
 extern "C" int omgsr_layernorm(const void* x, void* y, const float* a, const float* b, int64_t rows, int32_t C,
                                float eps, int32_t x_el, int32_t y_el, void* stream) {
     if (!x || !y || rows <= 0 || C <= 0) return OMGSR_E_BADARG;
-    if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT)) return OMGSR_E_BADARG;
+    if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT && y_el != OMGSR_EL_MX)) return OMGSR_E_BADARG;
     if ((C & 7) || C > 64 * 8 * 8) return OMGSR_E_SHAPE;
+    // the mixed-precision operand form (the consumer is an MX GEMM, igemm_gmx.hip): fp32 stream in, fp16 compute type, C % 64 == 0
+    if (y_el == OMGSR_EL_MX && (x_el != OMGSR_EL_F32 || omgsr::compute_dtype() != 1 || (C & 63))) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    omgsr::TimingScope ts(OMGSR_TK_LN, 0.0, ((x_el == OMGSR_EL_F32 ? 4.0 : 2.0) + (y_el == OMGSR_EL_SPLIT ? 4.0 : 2.0)) * (double)rows * C, st);
+    omgsr::TimingScope ts(OMGSR_TK_LN, 0.0, ((x_el == OMGSR_EL_F32 ? 4.0 : 2.0) + (y_el != OMGSR_EL_16 ? 4.0 : 2.0)) * (double)rows * C, st);
+    if (y_el == OMGSR_EL_MX) return layernorm_launch<true, 3>(x, y, a, b, rows, C, eps, st);
     if (x_el == OMGSR_EL_F32 && y_el == OMGSR_EL_SPLIT) return layernorm_launch<true, 2>(x, y, a, b, rows, C, eps, st);
     if (x_el == OMGSR_EL_F32) return layernorm_launch<true, 0>(x, y, a, b, rows, C, eps, st);
     if (y_el == OMGSR_EL_SPLIT) return layernorm_launch<false, 2>(x, y, a, b, rows, C, eps, st);

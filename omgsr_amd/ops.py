@@ -252,8 +252,8 @@ def _pack_mx(w: torch.Tensor, bias, cout: int, cin: int, R: int, S: int, dev, up
     [w_hi fp16 (2C B) | w_hi' fp8 (C B) | w_lo' fp8 (C B)] with w_hi = fp16(w), w_hi' = fp8(w_hi 2^s1), w_lo' = fp8((w - w_hi) 2^s2): the
     first C / 32 chunks meet a_hi in fp16 MFMAs, then C / 64 fp8 chunks meet a_lo' (w_hi') and C / 64 meet a_hi' (w_lo') in block-scaled
     fp8 MFMAs whose E8M0 scale operands undo s1 / s2 and the operand's 2^11."""
-    if R != 3 or S != 3 or cin % 64 or act_dtype() != torch.float16:
-        raise ValueError("the mixed-precision (MX) form serves 3x3 convolutions with Cin % 64 == 0 in the fp16 compute type")
+    if (R, S) not in ((3, 3), (1, 1)) or cin % 64 or act_dtype() != torch.float16:
+        raise ValueError("the mixed-precision (MX) form serves 3x3 and 1x1 convolutions (linears) with Cin % 64 == 0 in the fp16 compute type")
     ph = _phase_kernels(w) if upsample_phases else None       # [4, Cout, 2, 2, C]: one set of scales for the taps AND the phase sums
     both = w if ph is None else torch.cat([w.reshape(-1), ph.reshape(-1)])
     both_hi = both.to(torch.float16).float()
@@ -262,7 +262,8 @@ def _pack_mx(w: torch.Tensor, bias, cout: int, cin: int, R: int, S: int, dev, up
     cout_pad = _round_up(cout, 256 if cout >= 256 else 128)
     out = torch.zeros((cout_pad, R * S * kslots), device=dev, dtype=torch.float16)
     out[:cout] = _mx_rows(w, s1, s2).reshape(cout, R * S * 4 * cin).contiguous().view(torch.float16)
-    w_cm = out.view(cout_pad, 9, kslots // 32, 32).permute(2, 1, 0, 3).contiguous()
+    # 3x3: slice-major copy for the halo-tile kernel; 1x1 (a Linear): `out` itself is what igemm_gmx_kernel streams, row by row
+    w_cm = out.view(cout_pad, 9, kslots // 32, 32).permute(2, 1, 0, 3).contiguous() if R == 3 else None
     w_ph = None
     if ph is not None:
         full = torch.zeros((4, cout_pad, 4 * kslots), device=dev, dtype=torch.float16)
@@ -856,8 +857,8 @@ def layer_norm(x: torch.Tensor, a: Optional[torch.Tensor], b: Optional[torch.Ten
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     y = _operand_like(x, split)
-    check(_lib.load().omgsr_layernorm(x.data_ptr(), y.data_ptr(), _ptr(a), _ptr(b), rows, Cc, eps, xel,
-                                      EL_SPLIT if split == 2 else EL_16, _stream()), "omgsr_layernorm")
+    check(_lib.load().omgsr_layernorm(x.data_ptr(), y.data_ptr(), _ptr(a), _ptr(b), rows, Cc, eps, xel, _el_of_split(split), _stream()),
+          "omgsr_layernorm")
     return y
 
 
@@ -868,7 +869,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, he
               *, q_col: int = 0, k_col: int = 0, Lk: Optional[int] = None, out: Optional[torch.Tensor] = None,
               o_col: int = 0, out_split: int = 1, o_lo_col: Optional[int] = None) -> torch.Tensor:
     """q [B, Lq, *] (heads at columns q_col + h*D), k [Bk, Lk, *], vt [Bk, heads*D, ld] -> o [B, Lq, heads*D]
-    (an operand for the output projection; out_split 2: [B, Lq, 2*heads*D] as the two-term split).
+    (an operand for the output projection; out_split 2: [B, Lq, 2*heads*D] as the two-term split; 3: the same bytes per row in the
+    mixed-precision form OMGSR_EL_MX, for an output projection that runs as an MX GEMM).
     Bk == 1 broadcasts one K/V over the batch (constant cross-attention context)."""
     _req(q, act_dtype(), "q"); _req(k, act_dtype(), "k"); _req(vt, act_dtype(), "vt")
     B, Lq = q.shape[0], q.shape[1]
@@ -876,7 +878,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, he
     Lk = Lk if Lk is not None else k.shape[1]
     inner = heads * head_dim
     if out is None:
-        out = torch.empty((B, Lq, inner * out_split), device=q.device, dtype=act_dtype())
+        out = torch.empty((B, Lq, inner * min(out_split, 2)), device=q.device, dtype=act_dtype())      # split 3 (MX): 4 bytes per channel
     a = AttnArgs()
     esz = 2
     a.q = q.data_ptr() + q_col * esz
@@ -891,6 +893,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, he
     a.o_bstride = Lq * out.shape[-1]
     a.scale = scale
     a.o_lo_off = 0 if out_split != 2 else ((o_lo_col - o_col) if o_lo_col is not None else inner)
+    a.o_mx = int(out_split == 3)
+    if out_split == 3 and o_col != 0:
+        raise ValueError("attention: an MX output owns its whole row (o_col must be 0)")
     check(_lib.load().omgsr_attention(C.byref(a), _stream()), "omgsr_attention")
     return out
 

@@ -1,0 +1,74 @@
+"""HIP-graph replay of a pipeline's forward pass (the brief's "HIP streams and graphs instead of a tracing compiler").
+
+The reference driver is strictly batch 1 (infer/infer_omgsr_s.py:92-93): one 128 -> 512 image is ~1 000 kernel launches of a few
+microseconds each, and issuing them from Python costs more host time than the GPU needs to run them (a ctypes call, argument
+structs, output allocation per launch). Every launch of the hot path has fixed arguments once the input shape, the tier and the
+prompt are fixed (weights, folded constants and cached K / V^T live at fixed addresses; the caching allocator replays its
+allocations inside a captured region), so the whole `run()` body of `forward()` is captured ONCE per (shape, dtype, tile geometry,
+prompt tensor, tier, policy) into a hipGraph and replayed afterwards: one host call per image.
+
+What stays outside the graph, exactly where the reference has it: the synchronisation on both sides of the timed region, and the
+accurate tier's fp16 range-guard read (one 4-byte read at that synchronisation; a call that overflowed is recomputed eagerly by
+precision.RangeFallback and the graphs of the fp16-operand mode are dropped).
+
+Use: `pipe.enable_graphs()` (or OMGSR_GRAPH=1); `forward()` keeps its signature and return value. The first call with a new key runs
+eagerly (it also warms the weight packing, constant folding and kernel attributes, none of which may happen under capture), the second
+captures, later ones replay. Inputs are copied into the graph's static input buffer (12 MB per 1024^2 image: ~3 us of HBM time);
+the returned image is a fresh tensor, like the reference's.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+
+class GraphCache:
+    def __init__(self, max_graphs: int = 8):
+        self.enabled = False
+        self.max_graphs = max_graphs
+        self._seen: Dict[tuple, int] = {}
+        self._graphs: Dict[tuple, Tuple[torch.cuda.CUDAGraph, list, torch.Tensor, tuple]] = {}
+        self.replays = 0
+        self.captures = 0
+
+    def clear(self) -> None:
+        self._graphs.clear()
+        self._seen.clear()
+
+    @staticmethod
+    def _ident(t: Optional[torch.Tensor]):
+        return None if t is None else (id(t), t._version, t.data_ptr(), tuple(t.shape), t.dtype)
+
+    def call(self, key: tuple, dynamic: list, fixed: list, fn: Callable[..., torch.Tensor]) -> torch.Tensor:
+        """fn(*dynamic_inputs) -> output tensor. `dynamic`: tensors whose VALUES change per call (the LQ image): copied into static
+        buffers. `fixed`: tensors read by address (prompt embeddings, ids, posterior noise override): part of the key by identity and
+        version - a new tensor object, or an in-place edit, is a new graph."""
+        from .. import ops
+        if not self.enabled:
+            return fn(*dynamic)
+        full = (key, ops.mode_key(), tuple((tuple(d.shape), d.dtype, str(d.device)) for d in dynamic), tuple(self._ident(t) for t in fixed))
+        hit = self._graphs.get(full)
+        if hit is not None:
+            g, static_in, static_out, keep = hit
+            for s, d in zip(static_in, dynamic):
+                s.copy_(d)
+            g.replay()
+            self.replays += 1
+            return static_out.clone()
+        n = self._seen.get(full, 0)
+        self._seen[full] = n + 1
+        if n == 0:                       # first sight: eager (warms packed weights, folded constants, kernel attributes, the allocator)
+            return fn(*dynamic)
+        if len(self._graphs) >= self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))
+        static_in = [d.clone() for d in dynamic]
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_out = fn(*static_in)
+        self._graphs[full] = (g, static_in, static_out, tuple(fixed))      # `fixed` kept alive: their addresses are baked into the graph
+        self.captures += 1
+        g.replay()
+        self.replays += 1
+        return static_out.clone()

@@ -72,6 +72,23 @@ class OMGSR_F_Infer(torch.nn.Module):
             from ..precision import resolve
             resolve(precision_policy, vae=self.vae, flux=self.flux_transformer)
         self.range_fallback = RangeFallback(self.vae, self.flux_transformer)
+        from .graphed import GraphCache          # hipGraph replay of forward()'s body: off by default, enable_graphs() / OMGSR_GRAPH=1
+        import os
+        self.graphs = GraphCache()
+        self.graphs.enabled = os.environ.get("OMGSR_GRAPH", "0") == "1"
+        self.range_fallback.on_mode_change = self.graphs.clear
+        self._graph_params = None
+
+    def enable_graphs(self, on: bool = True) -> None:
+        """See OMGSR_S_Infer.enable_graphs."""
+        self.graphs.enabled = bool(on)
+        if not on:
+            self.graphs.clear()
+
+    def _weights_stamp(self) -> int:
+        if self._graph_params is None:
+            self._graph_params = list(self.vae.parameters()) + list(self.flux_transformer.parameters())
+        return sum(p._version for p in self._graph_params)
 
     def _init_tiled_vae(self, encoder_tile_size=256, decoder_tile_size=256, fast_decoder=False, fast_encoder=False,
                         color_fix=False, vae_to_gpu=True):
@@ -127,10 +144,17 @@ class OMGSR_F_Infer(torch.nn.Module):
     def forward(self, lq_img, prompt_embeds, pooled_prompt_embeds, text_ids, latent_image_ids, tile_size, tile_overlap):
         torch.cuda.synchronize()
         start_time = time.time()
-        def run():
-            x = ops.nchw_to_nhwc(lq_img.contiguous(), 8)
+        def body(lq):
+            x = ops.nchw_to_nhwc(lq.contiguous(), 8)
             img = self.sr_nhwc(x, prompt_embeds, pooled_prompt_embeds, text_ids, latent_image_ids, tile_size, tile_overlap)
-            return ops.nhwc_to_nchw(img, channels=3, dtype=ops.io_dtype(lq_img))
+            return ops.nhwc_to_nchw(img, channels=3, dtype=ops.io_dtype(lq))
+
+        def run():
+            if not self.graphs.enabled:
+                return body(lq_img)
+            hooks = (id(getattr(self.vae.encoder, "_tile_hook", None)), id(getattr(self.vae.decoder, "_tile_hook", None)))
+            key = ("F", tile_size, tile_overlap, float(self.t_curr), float(self.guidance_scale), hooks, self._weights_stamp())
+            return self.graphs.call(key, [lq_img], [prompt_embeds, pooled_prompt_embeds, text_ids, latent_image_ids, self.vae.posterior_noise], body)
         # FLUX activations are why the reference defaults to bf16: when an fp16 operand leaves the fp16 range the call runs again with
         # bf16 operands and the pipeline STAYS range-safe (precision.RangeFallback), instead of paying two passes and two re-packs per image
         pred_img = self.range_fallback.run(run, "OMGSR-F")

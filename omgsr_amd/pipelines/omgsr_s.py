@@ -54,6 +54,25 @@ class OMGSR_S_Infer(torch.nn.Module):
             from ..precision import resolve
             resolve(precision_policy, vae=self.vae, unet=self.unet)
         self.range_fallback = RangeFallback(self.vae, self.unet)
+        # hipGraph replay of forward()'s body (pipelines/graphed.py): off by default, enable_graphs() / OMGSR_GRAPH=1
+        from .graphed import GraphCache
+        self.graphs = GraphCache()
+        self.graphs.enabled = os.environ.get("OMGSR_GRAPH", "0") == "1"
+        self.range_fallback.on_mode_change = self.graphs.clear
+        self._graph_params = None
+
+    def enable_graphs(self, on: bool = True) -> None:
+        """Capture forward()'s launches into a hipGraph per (input shape, tile geometry, prompt tensor, tier) and replay it: one host
+        call per image instead of ~1 000 - 2 200 kernel launches issued from Python (the reference's batch-1 operating point is
+        launch-bound otherwise). Call `self.graphs.clear()` after changing weights in place."""
+        self.graphs.enabled = bool(on)
+        if not on:
+            self.graphs.clear()
+
+    def _weights_stamp(self) -> int:
+        if self._graph_params is None:
+            self._graph_params = list(self.vae.parameters()) + list(self.unet.parameters())
+        return sum(p._version for p in self._graph_params)
 
     def _init_tiled_vae(self, encoder_tile_size=256, decoder_tile_size=256, fast_decoder=False, fast_encoder=False,
                         color_fix=False, vae_to_gpu=True):
@@ -101,10 +120,17 @@ class OMGSR_S_Infer(torch.nn.Module):
     def forward(self, lq_img: torch.Tensor, prompt_embeds: torch.Tensor, tile_size: int, tile_overlap: int):
         torch.cuda.synchronize()
         start_time = time.time()
-        def run():
-            x = ops.nchw_to_nhwc(lq_img.contiguous(), 8)
+        def body(lq):
+            x = ops.nchw_to_nhwc(lq.contiguous(), 8)
             img = self.sr_nhwc(x, prompt_embeds, tile_size, tile_overlap)
-            return ops.nhwc_to_nchw(img, channels=3, dtype=ops.io_dtype(lq_img), clamp=(-1.0, 1.0))
+            return ops.nhwc_to_nchw(img, channels=3, dtype=ops.io_dtype(lq), clamp=(-1.0, 1.0))
+
+        def run():
+            if not self.graphs.enabled:
+                return body(lq_img)
+            hooks = (id(getattr(self.vae.encoder, "_tile_hook", None)), id(getattr(self.vae.decoder, "_tile_hook", None)))
+            key = ("S", tile_size, tile_overlap, self.mid_timestep, hooks, self._weights_stamp())
+            return self.graphs.call(key, [lq_img], [prompt_embeds, self.vae.posterior_noise], body)
         # an fp16 operand that leaves the fp16 range somewhere in this call (the stores saturate at +-65504) makes the call run again
         # range-safe, and the pipeline stays that way (precision.RangeFallback: `self.range_fallback.count / .sticky`)
         pred_img = self.range_fallback.run(run, "OMGSR-S")

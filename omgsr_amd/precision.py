@@ -67,16 +67,36 @@ VAE_INNER16 = [r"^decoder\.up_blocks\.[23]\.resnets\.\d+\.conv1$"]
 # those six draws and 9.2e-4 on the sixth - so they stay split. precision_policy="all" is the 2^-22 floor.
 # A weight split costs MFMA time only (no producer changes, no extra activation bytes); an operand split also doubles the bytes of
 # the operand it splits.
-_VAE_SINGLE = r"decoder\.up_blocks\.[123]\.resnets\.\d+\.conv[12]$"
+# Round 4: the 9.2e-4 outlier of round 3's trimmed policy was attributed with the emulator on THAT draw (tests/emulate_numerics.py
+# --test-draw 1,0 reproduces the GPU test's weights / input / noise; shipped policy 4.39e-4 emulated, 4.51e-4 measured), squared rel-L2
+# in 1e-8 units:
+#   shipped 19.3 | + decoder mid / 64 px resnets unsplit 25.5 (+6.2) | + encoder 128 px level unsplit 56.0 (+36.7) | both 64.9 (8.1e-4)
+# The encoder's 128 px level costs 5 units on the reference draw and 37 on this one (same weights, other input: 5.9e-4 measured): it
+# stays split. The decoder's mid block / first level was then tried alone, and the UNet's 16 x 16 transformer blocks, on four draws
+# (weight, input) = (0,0) (1,0) (11,0) (4,1):
+#   shipped                                   21.0   19.3   27.5   13.6
+#   decoder mid + up_blocks.0 unsplit         24.3   25.5   42.9   11.2     (+3 ... +15: draw-dependent, 6.5e-4 on the worst; -4 ms)
+#   UNet 16 x 16 transformer blocks unsplit   22.6   23.4   30.8   11.1     (+1.6 ... +4.1; -6 ms)
+#   both                                      25.9   28.0   46.6   13.6     (6.8e-4 on the worst of four draws)
+# Taken: the UNet's 16 x 16 transformer blocks on BOTH sides (thirty-odd long-K GEMMs at three K segments, 8.7 ms of the S-1024 step,
+# for <= 4 units on every draw tried). NOT taken: the decoder trim - its cost moves by a factor 5 between draws, and two draw-sensitive
+# groups together would eat most of the head-room under 8e-4 for 4 ms. OMGSR_POLICY_TRIM=0 restores round 3's lists (A/B runs),
+# OMGSR_POLICY_TRIM=2 adds the decoder trim (A/B runs).
+import os as _os
+_TRIM = int(_os.environ.get("OMGSR_POLICY_TRIM", "1"))
+_VAE_SINGLE = (r"decoder\.(mid_block|up_blocks\.[0123])\.resnets\.\d+\.conv[12]$" if _TRIM >= 2 else
+               r"decoder\.up_blocks\.[123]\.resnets\.\d+\.conv[12]$")
 VAE_ACT = [r"^(?!" + _VAE_SINGLE + r"|.*attentions\.)"]
 VAE_W = [r"^(?!" + _VAE_SINGLE + r")"]
 _L32 = r"^(down_blocks\.1|up_blocks\.2)\."
 _L16 = r"^(down_blocks\.2|up_blocks\.1)\."
-UNET_ACT = UNET_DEFAULT + [_L32 + r"resnets\.\d+\.conv[12]$", _L32 + r"attentions\.\d+\.transformer_blocks\.", _L16 + r"attentions\.\d+\.transformer_blocks\."]
-# weight side: everything but the 16 x 16 level's resnet convs (0.2 units) and the 8 x 8 level + mid block (0.0): long-K convs on tiny
-# maps that cost 5 ms of the S-1024 step when split (A/B on one box: 215.8 -> 210.6 ms; the six draws moved from 3.4e-4 ... 4.5e-4 to
-# 3.6e-4 ... 4.5e-4)
-UNET_W = [r"^(?!(down_blocks\.2|up_blocks\.1)\.resnets\.\d+\.conv[12]$|(down_blocks\.3|up_blocks\.0|mid_block)\.(resnets\.\d+\.conv[12]$|attentions\.\d+\.transformer_blocks\.))"]
+UNET_ACT = UNET_DEFAULT + [_L32 + r"resnets\.\d+\.conv[12]$", _L32 + r"attentions\.\d+\.transformer_blocks\."] + \
+    ([] if _TRIM >= 1 else [_L16 + r"attentions\.\d+\.transformer_blocks\."])
+# weight side: everything but the 16 x 16 level's resnet convs (0.2 units) and transformer blocks (round 4) and the 8 x 8 level + mid
+# block (0.0): long-K convs / GEMMs on tiny maps (round 3, resnet convs only: 215.8 -> 210.6 ms on one box, six draws 3.4e-4 ... 4.5e-4
+# -> 3.6e-4 ... 4.5e-4)
+UNET_W = [r"^(?!(down_blocks\.2|up_blocks\.1)\.(resnets\.\d+\.conv[12]$" + (r"|attentions\.\d+\.transformer_blocks\." if _TRIM >= 1 else "") +
+          r")|(down_blocks\.3|up_blocks\.0|mid_block)\.(resnets\.\d+\.conv[12]$|attentions\.\d+\.transformer_blocks\.))"]
 FLUX_ACT, FLUX_W = FLUX_DEFAULT, FLUX_DEFAULT
 # Layers whose both-sides split runs in the MIXED-PRECISION form (op_split 3, OMGSR_EL_MX): the product a_hi w_hi in fp16 MFMAs and
 # the two correction terms a_lo w_hi, a_hi w_lo - which only need a few bits of their own - as block-scaled fp8 MFMAs at twice the
@@ -115,6 +135,43 @@ def set_weight_split(model: nn.Module, patterns: Iterable[str], split: int = 2) 
             hit = any(r.search(name) for r in regs)
             m.w_split = split if hit else 1
             n += int(hit)
+    check_policy(model)
+    return n
+
+
+# Linears whose both-sides split runs in the mixed-precision form (round 4, igemm_gmx_kernel): every Linear of the UNet's 64 x 64 and
+# 32 x 32 transformer blocks that the lists above split on BOTH sides - q / k / v of the 32 x 32 level (one LayerNorm'd operand), the
+# attention output projections, the cross-attention query, the GEGLU projection and the feed-forward output, proj_in / proj_out. The
+# producers write the three-part operand (LayerNorm / GroupNorm apply / attention epilogue / GEGLU and plain GEMM epilogues); the
+# cross-attention K / V projections read the PROMPT (1024 channels, computed once per prompt tensor) and keep the two-term split.
+UNET_MX_LIN = [r"\.attentions\.\d+\.(proj_in|proj_out)$", r"\.transformer_blocks\.\d+\.(attn1\.to_(q|k|v|out\.0)|attn2\.to_(q|out\.0)|ff\.net\.(0\.proj|2))$"]
+
+
+def set_mx_linear(model: nn.Module, patterns: Iterable[str]) -> int:
+    """Move the both-sides split of the matching Linear layers (in_features % 64 == 0) to the mixed-precision form (op_split 3): the
+    layer then runs on igemm_gmx_kernel with 2 instead of 3 K segments of MFMA time and operand traffic. Layers that read ONE operand
+    (q / k / v of a self-attention) move together or not at all. OMGSR_MX_LINEAR=0 switches it off (A/B runs). Returns how many moved."""
+    import os
+    if os.environ.get("OMGSR_MX", "1") == "0" or os.environ.get("OMGSR_MX_LINEAR", "1") == "0":
+        return 0
+    regs = [re.compile(p) for p in patterns]
+    ok = lambda m: isinstance(m, Linear) and m.in_features % 64 == 0 and m.op_split == 2 and m.w_split == 2      # noqa: E731
+    n = 0
+    grouped = set()
+    for name, m in model.named_modules():
+        qkv = [getattr(m, a, None) for a in ("to_q", "to_k", "to_v")]
+        if all(isinstance(g, Linear) for g in qkv) and not getattr(m, "is_cross", False):
+            grouped.update(id(g) for g in qkv)
+            hit = all(any(r.search(f"{name}.{a}") for r in regs) for a in ("to_q", "to_k", "to_v"))
+            if hit and all(ok(g) for g in qkv) and getattr(m, "_shares_input_with", None) is None:
+                for g in qkv:
+                    g.op_split = 3
+                n += 3
+    for name, m in model.named_modules():
+        if id(m) in grouped or not ok(m) or not any(r.search(name) for r in regs):
+            continue
+        m.op_split = 3
+        n += 1
     check_policy(model)
     return n
 
@@ -205,6 +262,7 @@ def apply_default_policy(vae: Optional[nn.Module] = None, unet: Optional[nn.Modu
         set_operand_split(unet, UNET_ACT)
         set_weight_split(unet, [r"."] if os.environ.get("OMGSR_UNET_W_ALL") == "1" else UNET_W)      # (A/B switch: every UNet weight split)
         set_mx(unet, UNET_MX)
+        set_mx_linear(unet, UNET_MX_LIN)
     if flux is not None:
         set_operand_split(flux, FLUX_ACT)
         set_weight_split(flux, FLUX_W)
@@ -267,6 +325,7 @@ class RangeFallback:
         self.count = 0
         self.sticky = False
         self._saved = None
+        self.on_mode_change = None       # optional callback (the pipelines drop their captured hipGraphs: other kernels, other packed weights)
 
     def enter(self) -> None:
         from . import ops
@@ -277,6 +336,8 @@ class RangeFallback:
                 apply_policy(model, [r"."], [r"."])
         ops.set_compute_dtype(torch.float32, operand_dtype=torch.bfloat16)
         self.sticky = True
+        if self.on_mode_change:
+            self.on_mode_change()
 
     def reassert(self) -> None:
         """Called at the top of every forward(): another pipeline may have switched the process-wide tier in between."""
@@ -294,6 +355,8 @@ class RangeFallback:
         if self.sticky:
             ops.set_compute_dtype(torch.float32)
         self.sticky = False
+        if self.on_mode_change:
+            self.on_mode_change()
 
     def run(self, run, what: str):
         """run() -> result (synchronised by the caller's contract: this method synchronises before reading the guard word)."""

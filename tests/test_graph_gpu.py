@@ -1,0 +1,84 @@
+"""hipGraph replay of the pipelines' forward() (omgsr_amd/pipelines/graphed.py): a replayed call returns the same
+bits as the eager call on the same input, for new input VALUES (copied into the graph's static buffer), in both tiers and both
+families; a new prompt tensor, another input shape or an in-place weight edit is a new graph, never a stale one."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _s_pipe(wd):
+    from omgsr_amd.diffusers_api import AutoencoderKL, UNet2DConditionModel
+    from omgsr_amd.pipelines.omgsr_s import OMGSR_S_Infer
+    from omgsr_amd.testing import seeded_init_
+    vcfg = dict(block_out_channels=[32, 64, 128, 128], layers_per_block=1)
+    ucfg = dict(block_out_channels=[64, 128, 256, 256], attention_head_dim=[1, 2, 4, 4], cross_attention_dim=128)
+    v, u = seeded_init_(AutoencoderKL(**vcfg), 1, rounded=False), seeded_init_(UNet2DConditionModel(**ucfg), 2, rounded=False)
+    return OMGSR_S_Infer(None, None, 273, DEV, wd, vae=v, unet=u)
+
+
+@pytest.mark.parametrize("wd", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tiled_vae", [False, True])
+def test_omgsr_s_graph_replay_equals_eager(wd, tiled_vae):
+    from omgsr_amd import ops
+    from omgsr_amd.testing import synthetic_lq
+    try:
+        pipe = _s_pipe(wd)
+        if tiled_vae:
+            pipe._init_tiled_vae(encoder_tile_size=128, decoder_tile_size=16)
+        g = torch.Generator().manual_seed(5)
+        prompt = torch.randn(1, 77, 128, generator=g).to(device=DEV, dtype=wd)
+        pipe.vae.posterior_noise = torch.randn(2, 4, 24, 24, generator=g).to(DEV)
+        xs = [synthetic_lq(2, 192, 192, seed=s).to(device=DEV, dtype=wd) for s in (1, 2, 3, 4)]
+        with torch.no_grad():
+            eager = [pipe(x, prompt, 16, 8)[0] for x in xs]              # latent 24 x 24 > 16 x 16: the tiled-latent path
+            pipe.enable_graphs(True)
+            got = [pipe(x, prompt, 16, 8)[0] for x in xs]                # eager, capture + replay, replay, replay
+            assert pipe.graphs.captures == 1 and pipe.graphs.replays == 3
+            for a, b in zip(eager, got):
+                assert torch.equal(a, b)
+            assert got[1].data_ptr() != got[2].data_ptr()                # fresh result tensors, like the reference's
+            # another prompt TENSOR (new values): its K / V^T cache is rebuilt eagerly, then captured - never a stale replay
+            prompt2 = (prompt * 0.5).contiguous()
+            ref2 = None
+            pipe.enable_graphs(False)
+            ref2 = pipe(xs[0], prompt2, 16, 8)[0]
+            pipe.enable_graphs(True)
+            outs = [pipe(xs[0], prompt2, 16, 8)[0] for _ in range(3)]
+            assert all(torch.equal(o, ref2) for o in outs) and not torch.equal(ref2, eager[0])
+            # an in-place weight edit bumps the parameter version: new key, packed weights rebuilt, result follows the new weights
+            pipe.unet.conv_out.weight.mul_(0.5)
+            outs = [pipe(xs[0], prompt2, 16, 8)[0] for _ in range(3)]
+            pipe.enable_graphs(False)
+            ref3 = pipe(xs[0], prompt2, 16, 8)[0]
+            assert all(torch.equal(o, ref3) for o in outs) and not torch.equal(ref3, ref2)
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
+
+
+def test_omgsr_f_graph_replay_equals_eager():
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api import AutoencoderKL, FluxTransformer2DModel
+    from omgsr_amd.pipelines.omgsr_f import OMGSR_F_Infer, prepare_latent_image_ids
+    from omgsr_amd.testing import seeded_init_, synthetic_lq
+    wd = torch.float32
+    try:
+        vae = seeded_init_(AutoencoderKL(block_out_channels=[32, 64, 128, 128], layers_per_block=1, latent_channels=16, scaling_factor=0.3611, shift_factor=0.1159), 3, rounded=False)
+        flux = seeded_init_(FluxTransformer2DModel(num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=64,
+                                                   pooled_projection_dim=32, in_channels=64), 4, rounded=False)
+        pipe = OMGSR_F_Infer(None, None, DEV, wd, 244, 1.0, vae=vae, flux_transformer=flux)
+        g = torch.Generator().manual_seed(6)
+        pe, pooled = torch.randn(1, 32, 64, generator=g).to(DEV), torch.randn(1, 32, generator=g).to(DEV)
+        tids, iids = torch.zeros(32, 3, device=DEV), prepare_latent_image_ids(8, 8, DEV, wd)
+        pipe.vae.posterior_noise = torch.randn(1, 16, 16, 16, generator=g).to(DEV)
+        xs = [synthetic_lq(1, 128, 128, seed=s).to(DEV) for s in (1, 2, 3)]
+        with torch.no_grad():
+            eager = [pipe(x, pe, pooled, tids, iids, 16, 8)[0] for x in xs]
+            pipe.enable_graphs(True)
+            got = [pipe(x, pe, pooled, tids, iids, 16, 8)[0] for x in xs]
+        assert pipe.graphs.captures == 1 and pipe.graphs.replays == 2
+        for a, b in zip(eager, got):
+            assert torch.equal(a, b)
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)

@@ -52,7 +52,7 @@ def test_the_tight_kernels_are_where_design_says(tables):
     low teens, nothing else that ships in the hot path spills more than a handful."""
     built, _ = tables
     for k, b in built.items():
-        if k.startswith(("igemm_halo", "igemm_dma", "igemm_p8", "igemm_a8", "attn_kernel")):
+        if k.startswith(("igemm_halo", "igemm_dma", "igemm_p8", "igemm_gmx", "attn_kernel")):
             assert b["occupancy"] >= 2, (k, b)
     mx = [b for k, b in built.items() if k.startswith("igemm_halo") and k.endswith(",9,1>")]
     assert mx and all(b["spill_vgpr"] <= 16 and b["scratch"] <= 64 for b in mx), mx

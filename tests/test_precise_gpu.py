@@ -266,6 +266,96 @@ def test_linear_weight_split(M, K, Nn, split, w_split):
     assert _rel(y, ref) < 3e-6
 
 
+def _mx_decode(y, C):
+    """[..., 2C] fp16 view of an OMGSR_EL_MX tensor -> (hi fp32, lo fp32 = lo' 2^-11, hi' fp32) each [..., C]."""
+    raw = y.contiguous().view(torch.uint8).reshape(*y.shape[:-1], 4 * C)
+    hi = raw[..., :2 * C].contiguous().view(torch.float16).float()
+    lo = raw[..., 2 * C:3 * C].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -11
+    hi8 = raw[..., 3 * C:].contiguous().view(torch.float8_e4m3fn).float()
+    return hi, lo, hi8
+
+
+@pytest.mark.parametrize("M,C,Nn", [(300, 320, 320), (147456, 320, 320), (36864, 640, 1280), (9216, 1280, 1280), (4100, 64, 192), (20000, 1280, 320)])
+def test_linear_mx(M, C, Nn):
+    """a Linear in the mixed-precision form on igemm_gmx_kernel - a_hi w_hi in fp16 MFMAs, a_lo w_hi + a_hi w_lo as
+    block-scaled fp8 MFMAs, one fp32 accumulator - from a full-mantissa fp32 operand and weight: ~1e-5 of the fp64 product where one
+    fp16 rounding of each side leaves ~3e-4; fp32 output with fp32 residual, ragged M, every K-step count mod 3 (C / 32 = 10, 20, 40, 2)."""
+    from omgsr_amd import ops
+    x = torch.randn(1, M, C, generator=_g(60))
+    w = torch.randn(Nn, C, generator=_g(61)) * C ** -0.5
+    b = 0.1 * torch.randn(Nn, generator=_g(62))
+    res = torch.randn(1, M, Nn, generator=_g(63))
+    pw = ops.pack_linear_weight(w, b, device=DEV, split=3)
+    assert pw.mx is not None and pw.row_channels == 2 * C and pw.w_cm is None
+    xd = x.to(DEV)
+    y = ops.linear(xd, pw, residual=res.to(DEV))
+    ref = (torch.addmm(b.to(DEV).double(), xd[0].double(), w.to(DEV).double().t()) + res[0].to(DEV).double())[None]
+    e = _rel(y, ref)
+    e1 = _rel(ops.linear(xd, ops.pack_linear_weight(w, b, device=DEV), residual=res.to(DEV)), ref)
+    print(f"linear MX {M, C, Nn}: rel {e:.2e} (single fp16 rounding of both sides {e1:.2e})")
+    assert y.dtype == torch.float32 and e < 2e-5 and e1 > 8 * e
+    # the operand the producers write (here: the cast kernel) and a 16-bit output
+    xm = ops.to_operand(xd, 3)
+    y16 = ops.linear(xm, pw, out_dtype=ops.OUT_BF16)
+    assert y16.dtype == torch.float16 and _rel(y16, ref - res.to(DEV).double()) < 6e-4
+
+
+def test_linear_mx_geglu_transposed_and_chained_outputs():
+    """The producer / consumer chain of a transformer block's feed-forward and V projection in the mixed-precision form:
+    LayerNorm writes the MX operand -> GEGLU projection (MX GEMM, epilogue a * gelu(gate)) writes the hidden tensor AS an MX operand
+    -> output projection (MX GEMM) with the fp32 residual; and the V projection (LAYOUT_T output) over the same LayerNorm'd operand."""
+    from omgsr_amd import ops
+    B, L, C = 2, 1100, 320
+    x = torch.randn(B, L, C, generator=_g(70)) * 2 + 0.3
+    g, bb = 1.0 + 0.1 * torch.randn(C, generator=_g(71)), 0.05 * torch.randn(C, generator=_g(72))
+    w1 = torch.randn(2 * 4 * C, C, generator=_g(73)) * C ** -0.5
+    b1 = 0.1 * torch.randn(2 * 4 * C, generator=_g(74))
+    w2 = torch.randn(C, 4 * C, generator=_g(75)) * (4 * C) ** -0.5
+    b2 = 0.1 * torch.randn(C, generator=_g(76))
+    wv = torch.randn(C, C, generator=_g(77)) * C ** -0.5
+    xd = x.to(DEV)
+    xn = ops.layer_norm(xd, g.to(DEV), bb.to(DEV), 1e-5, split=3)
+    assert xn.dtype == torch.float16 and tuple(xn.shape) == (B, L, 2 * C)
+    ln = F.layer_norm(x.double(), (C,), g.double(), bb.double(), 1e-5)
+    hi, lo, hi8 = _mx_decode(xn.cpu(), C)
+    assert _rel(hi + lo, ln) < 2e-5 and _rel(hi, ln) > 1e-4          # hi + lo' 2^-11 carries the operand to ~2^-15; hi alone is one fp16 rounding
+    assert torch.equal(hi8, hi.clamp(-448, 448).to(torch.float8_e4m3fn).float())
+    h = ops.linear(xn, ops.pack_geglu_weight(w1, b1, device=DEV, split=3), out_dtype=ops.OUT_BF16, out_split=3)
+    assert tuple(h.shape) == (B, L, 2 * 4 * C)
+    a, gate = (ln @ w1.double().t() + b1.double()).chunk(2, dim=-1)
+    href = a * F.gelu(gate)
+    hh, hl, _ = _mx_decode(h.cpu(), 4 * C)
+    assert _rel(hh + hl, href) < 4e-5
+    y = ops.linear(h, ops.pack_linear_weight(w2, b2, device=DEV, split=3), residual=xd)
+    ref = href @ w2.double().t() + b2.double() + x.double()
+    e = _rel(y, ref)
+    print(f"LayerNorm -> GEGLU (MX) -> FF out (MX) + residual: rel {e:.2e}")
+    assert y.dtype == torch.float32 and e < 3e-5
+    vt = ops.linear_t(xn, ops.pack_linear_weight(wv, None, device=DEV, split=3), L)          # [B, C, L8] fp16
+    vref = (ln @ wv.double().t()).transpose(1, 2)
+    # one fp16 rounding of the exact product; against the ROUNDED exact product only the values that sit on a rounding boundary differ
+    assert _rel(vt[..., :L], vref) < 6e-4 and _rel(vt[..., :L].float(), vref.to(torch.float16).float()) < 1.5e-4
+
+
+def test_attention_writes_mx_operand():
+    """omgsr_attention with o_mx: the output projection's operand leaves the attention epilogue in the mixed-precision form; hi is
+    bit-identical to the plain output, hi + lo' 2^-11 equals the two-term split's hi + lo to fp8 accuracy of the low part."""
+    from omgsr_amd import ops
+    B, L, H, D = 2, 1024, 5, 64
+    q = torch.randn(B, L, H * D, generator=_g(80)).to(torch.float16).to(DEV)
+    k = torch.randn(B, L, H * D, generator=_g(81)).to(torch.float16).to(DEV)
+    vt = torch.randn(B, H * D, L, generator=_g(82)).to(torch.float16).to(DEV)
+    o1 = ops.attention(q, k, vt, H, D, D ** -0.5)
+    o2 = ops.attention(q, k, vt, H, D, D ** -0.5, out_split=2)
+    o3 = ops.attention(q, k, vt, H, D, D ** -0.5, out_split=3)
+    assert tuple(o3.shape) == (B, L, 2 * H * D)
+    hi, lo, hi8 = _mx_decode(o3.cpu(), H * D)
+    assert torch.equal(hi, o1.float().cpu()) and torch.equal(hi, o2[..., :H * D].float().cpu())
+    lo2 = o2[..., H * D:].float().cpu()
+    assert (lo - lo2).abs().max() <= 2.0 ** -4 * lo2.abs().max() and _rel(lo, lo2) < 0.05
+    assert torch.equal(hi8, hi.to(torch.float8_e4m3fn).float())
+
+
 def test_linear_epilogue_writes_split_operand():
     """A GEMM whose output is the next GEMM's operand (FF hidden, attention output): out_split 2 writes [hi | lo]."""
     from omgsr_amd import ops

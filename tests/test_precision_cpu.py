@@ -14,11 +14,11 @@ def accurate_tier():
     ops.set_compute_dtype(torch.bfloat16)
 
 
-def _forms(model):
+def _forms(model, kinds=None):
     from omgsr_amd import nn as N
     out = {}
     for _, m in model.named_modules():
-        if isinstance(m, (N.Conv2d, N.Linear)):
+        if isinstance(m, kinds or (N.Conv2d, N.Linear)):
             out[(m.op_split, m.w_split)] = out.get((m.op_split, m.w_split), 0) + 1
     return out
 
@@ -35,10 +35,19 @@ def test_shipped_policy_assignment_on_sd21_shapes():
     assert fv == {(3, 2): 33, (1, 1): 18, (1, 2): 8, (2, 2): 13}
     mx = [n for n, m in v.named_modules() if getattr(m, "op_split", 0) == 3]
     assert all(("resnets" in n or "upsamplers" in n) for n in mx) and not any("decoder.up_blocks.1.resnets" in n for n in mx)
-    # UNet: the 64 x 64 and 32 x 32 resnet convs + the three upsampling convs in the mixed-precision form; 16 x 16 resnets and the
-    # 8 x 8 level + mid block single
-    assert fu[(3, 2)] == 23 and fu[(1, 1)] == 34 and sum(fu.values()) == 282
+    # UNet convs: the 64 x 64 and 32 x 32 resnet convs + the three upsampling convs in the mixed-precision form; 16 x 16 resnets and
+    # the 8 x 8 level + mid block single. UNet linears (round 4): the 64 x 64 / 32 x 32 transformer blocks' both-sides splits and every
+    # proj_in / proj_out run as mixed-precision GEMMs (igemm_gmx_kernel); the 16 x 16 transformer blocks are single (round-4 trim);
+    # 64 x 64 q / k / v weight-split only; the 32 x 32 cross-attention K / V (the prompt's projections) keep the two-term split
+    from omgsr_amd import nn as N
+    assert _forms(u, N.Conv2d) == {(2, 2): 19, (3, 2): 23, (1, 1): 24}
+    assert _forms(u, N.Linear) == {(1, 2): 49, (2, 2): 15, (3, 2): 92, (1, 1): 60} and sum(fu.values()) == 282
     assert u.down_blocks[2].resnets[0].conv1.w_split == 1 and u.down_blocks[0].attentions[0].transformer_blocks[0].attn1.to_q.w_split == 2
+    b32, b16 = u.down_blocks[1].attentions[0].transformer_blocks[0], u.down_blocks[2].attentions[0].transformer_blocks[0]
+    assert [m.op_split for m in (b32.attn1.to_q, b32.attn1.to_k, b32.attn1.to_v, b32.attn1.to_out[0], b32.attn2.to_q, b32.ff.net[0].proj, b32.ff.net[2])] == [3] * 7
+    assert (b32.attn2.to_k.op_split, b32.attn2.to_v.op_split) == (2, 2)
+    assert {(m.op_split, m.w_split) for m in b16.modules() if isinstance(m, N.Linear)} == {(1, 1)}
+    assert u.down_blocks[2].attentions[0].proj_in.op_split == 3 and u.down_blocks[0].attentions[0].transformer_blocks[0].attn1.to_q.op_split == 1
     a, b = P.policy_fingerprint(u), P.policy_fingerprint(v)
     P.set_weight_split(u, [])
     assert P.policy_fingerprint(u) != a and P.policy_fingerprint(v) == b
@@ -97,6 +106,17 @@ def test_split_weight_packings(accurate_tier):
     assert ((hi + lo8) - ref).abs().max() < 2.0 ** -14 * ref.abs().max()           # w_hi + w_lo' carries w to ~2^-15
     with pytest.raises(ValueError, match="Cin % 64"):
         ops.pack_conv_weight(torch.randn(16, 32, 3, 3), None, device="cpu", split=3)
+    # ... and of a Linear (round 4: igemm_gmx_kernel streams the plain row-major packing, there is no slice-major copy)
+    wl = torch.randn(200, 320, generator=g) * 320 ** -0.5
+    pl = ops.pack_linear_weight(wl, torch.zeros(200), device="cpu", split=3)
+    assert pl.mx is not None and pl.w_cm is None and (pl.R, pl.S) == (1, 1) and pl.cin == 640 and pl.k_pad == 640 and pl.cout_pad == 256 and pl.mx[0] == 10
+    byl = pl.w[:200].view(torch.uint8).reshape(200, 4 * 320)
+    hl = byl[:, :640].contiguous().view(torch.float16).float()
+    assert torch.equal(hl, wl.to(torch.float16).float()) and not pl.w[200:].any()
+    l8 = byl[:, 960:].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** (pl.mx[3] - 127)
+    assert ((hl + l8) - wl).abs().max() < 2.0 ** -14 * wl.abs().max()
+    pgl = ops.pack_geglu_weight(torch.randn(2 * 128, 64, generator=g), torch.randn(2 * 128, generator=g), device="cpu", split=3)
+    assert pgl.geglu and pgl.cout == 128 and pgl.mx is not None and pgl.cin == 128
 
 
 def test_phase_summed_kernels_equal_the_upsampled_conv():

@@ -4,7 +4,7 @@ GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs), when both are prese
 import collections, csv, re, sys
 
 FAM = [("igemm_halo_multi_kernel", re.compile(r"igemm_halo_multi_kernel")), ("igemm_halo_kernel", re.compile(r"igemm_halo_kernel")),
-       ("igemm_p8_kernel", re.compile(r"igemm_p8_kernel")), ("igemm_dma_kernel", re.compile(r"igemm_dma_kernel")),
+       ("igemm_p8_kernel", re.compile(r"igemm_p8_kernel")), ("igemm_gmx_kernel", re.compile(r"igemm_gmx_kernel")), ("igemm_dma_kernel", re.compile(r"igemm_dma_kernel")),
        ("igemm_kernel", re.compile(r"igemm_kernel")), ("splitk_reduce", re.compile(r"splitk_reduce")), ("attn_kernel", re.compile(r"attn_kernel")),
        ("gn_apply", re.compile(r"gn_apply")), ("layernorm", re.compile(r"layernorm"))]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))

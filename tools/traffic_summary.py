@@ -21,7 +21,7 @@ KERNELS = [
     ("igemm_halo_kernel<TAPS=4>", re.compile(r"igemm_halo_kernelI\w+?_?Li\dELb[01]ELb[01]ELi4E|igemm_halo_kernel<[^>]*, 4,")),
     ("igemm_halo_kernel", re.compile(r"igemm_halo_kernel")),
     ("igemm_p8_kernel", re.compile(r"igemm_p8_kernel")),
-    ("igemm_a8_kernel", re.compile(r"igemm_a8_kernel")),
+    ("igemm_gmx_kernel", re.compile(r"igemm_gmx_kernel")),
     ("igemm_dma_kernel", re.compile(r"igemm_dma_kernel")),
     ("igemm_kernel", re.compile(r"igemm_kernel")),
     ("splitk_reduce_kernel", re.compile(r"splitk_reduce")),
