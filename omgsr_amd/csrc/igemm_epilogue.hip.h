@@ -417,6 +417,8 @@ struct IgemmGeo {
     int nk_total;   // K steps of the whole contraction
     int splits;     // split-K factor (1 = none)
     int ntm, ntn;   // tile counts
+    int main_prio;  // halo-tile kernel (A/B switch OMGSR_HALO_MAINPRIO): s_setprio level of a wave while it is in its K loop (0 = off); its
+                    // prologue / epilogue run at priority 0, so the co-resident workgroup's MFMA stream is not delayed by epilogue VALU / LDS traffic
     int interleave; // halo-tile kernel, phase form: 1 = the four output phases of a tile are consecutive logical blocks of ONE x-only grid
                     // (they share an XCD's L2: the low-res patch is fetched from HBM once, not four times); 0 = blockIdx.y = phase
 };

@@ -309,6 +309,8 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
             step(std::integral_constant<int, 8>{}, par_c, f8_c, cc, s0 + 8);
         }
     };
+    if (g.main_prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (g.main_prio == 2) __builtin_amdgcn_s_setprio(2);
     int cc = 0;
     for (; cc < n16; cc += 2) {
         chunk(std::integral_constant<int, 0>{}, std::false_type{}, cc);
@@ -325,6 +327,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     }
 
+    if (g.main_prio) __builtin_amdgcn_s_setprio(0);
     int mb[FM], nv[FM];
     int colsv = (PHASE ? p.W : p.Wo) - x0; colsv = colsv > TW ? TW : colsv;
 #pragma unroll
@@ -397,6 +400,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMult
 // several problems / the mixed-precision form)
 static inline bool halo_geo(const omgsr_igemm_args& a, IgemmGeo& g, const bool phase) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    static const char* mp = getenv("OMGSR_HALO_MAINPRIO");         // A/B runs: "1" | "2" = waves raise their priority for the K loop
+    g.main_prio = mp ? atoi(mp) : 0;
     static const char* il = getenv("OMGSR_PHASE_INTERLEAVE");      // A/B runs: "0" = blockIdx.y = phase (every phase sweeps the whole map)
     g.interleave = (phase && !(il && il[0] == '0')) ? 1 : 0;
     g.nk = a.Cin / 32;

@@ -104,9 +104,28 @@ def _ovf(device) -> Optional[int]:
     return t.data_ptr()
 
 
+_weight_overflow = False        # a WEIGHT beyond the fp16 range was packed for fp16 operands (pack_conv_weight saturates it at +-65504)
+
+
+def _note_weight_range(w: torch.Tensor) -> torch.Tensor:
+    """Accurate tier, fp16 operands: a weight beyond +-65504 cannot be carried by an fp16 operand (the reason the reference defaults
+    FLUX to bf16). Saturate it like the kernels saturate activations and raise the same guard the activations raise, so the pipelines
+    fall back to bf16 operands instead of multiplying by inf."""
+    global _weight_overflow
+    if _PRECISE and _ACT == torch.float16 and w.numel() and float(w.abs().max()) > 65504.0:
+        if _GUARD:
+            _weight_overflow = True
+        return w.clamp(-65504.0, 65504.0)
+    return w
+
+
 def overflow_seen(reset: bool = True) -> bool:
-    """True when a kernel clipped an fp16 operand since the last reset (synchronises: one 4-byte read per device in use)."""
-    seen = False
+    """True when a kernel clipped an fp16 operand (or a weight beyond the fp16 range was packed) since the last reset (synchronises:
+    one 4-byte read per device in use)."""
+    global _weight_overflow
+    seen = _weight_overflow
+    if reset:
+        _weight_overflow = False
     for t in _ovf_words.values():
         if bool(t.item()):
             seen = True
@@ -312,7 +331,7 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
             bias = torch.cat([bias.detach().to(dev), torch.zeros(extra, device=dev, dtype=bias.dtype)], dim=0)
         cout += extra
     cin8 = _round_up(cin, 8)
-    w = weight.detach().to(device=dev, dtype=torch.float32).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
+    w = _note_weight_range(weight.detach().to(device=dev, dtype=torch.float32)).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
     if cin8 != cin:
         w = torch.nn.functional.pad(w, (0, cin8 - cin))
     if split == 3:

@@ -50,6 +50,19 @@ def tile_grid(h: int, w: int, tile_size: int, tile_overlap: int) -> Tuple[int, L
     return tile_size, out
 
 
+_WTS: dict = {}
+
+
+def _weights_on(ts: int, device) -> torch.Tensor:
+    """The Gaussian tile weights as a device tensor, uploaded once per (tile size, device): a host -> device copy per call would also be
+    illegal inside a hipGraph capture (pipelines/graphed.py)."""
+    key = (ts, str(device))
+    t = _WTS.get(key)
+    if t is None:
+        t = _WTS[key] = torch.tensor(gaussian_weights(ts, ts), dtype=torch.float32, device=device)
+    return t
+
+
 def tiled_denoise(latent_nhwc: torch.Tensor, channels: int, tile_size: int, tile_overlap: int,
                   denoise: Callable[[torch.Tensor], torch.Tensor], tiles_per_call: int = 16) -> torch.Tensor:
     """latent_nhwc [B,h,w,C8] stream tensor; `denoise(tiles [n*B,t,t,C8]) -> [n*B,t,t,>=channels]`. Returns the
@@ -61,7 +74,7 @@ def tiled_denoise(latent_nhwc: torch.Tensor, channels: int, tile_size: int, tile
     while the low-resolution UNet layers see 9x more rows and fill the 256 CUs. Stitch order is unchanged."""
     B, h, w, ld = latent_nhwc.shape
     ts, offsets = tile_grid(h, w, tile_size, tile_overlap)
-    wts = torch.tensor(gaussian_weights(ts, ts), dtype=torch.float32, device=latent_nhwc.device)
+    wts = _weights_on(ts, latent_nhwc.device)
     acc = torch.zeros((B, h, w, channels), device=latent_nhwc.device, dtype=torch.float32)
     wsum = torch.zeros((1, h, w, 1), device=latent_nhwc.device, dtype=torch.float32)
     for i0 in range(0, len(offsets), max(1, tiles_per_call)):

@@ -659,6 +659,28 @@ def test_ping_pong_gemm_kernel():
     assert_close(s, torch.einsum("bmk,bnk->bmn", a_, b_) * Kb ** -0.5, "p8 bmm_nt", rel_l2=1e-5, max_ulps=0.05)
 
 
+@pytest.mark.parametrize("M,K,Nout", [(36900, 1536, 1024), (20000, 3072, 2304), (66000, 1536, 256)])
+def test_ping_pong_gemm_kernel_many_tiles(M, K, Nout):
+    """igemm_p8_kernel with more tiles than CUs (several rounds of workgroups per CU, tile counts that do not divide by the XCD count,
+    ragged M): bias + residual, f32 output, the same launch repeated. (Round 4 built a PERSISTENT form of this kernel - one workgroup
+    per CU walking its XCD's tile range with the next tile's first K-tile fetched behind the current epilogue - and removed it: 2 %
+    slower on F-1024 than letting the hardware dispatch one workgroup per tile, profiles/r04_experiments.md.)"""
+    ops = _ops()
+    x = rnd(1, M, K, seed=401)
+    w = rnd(Nout, K, seed=402, scale=K ** -0.5)
+    b = rnd(Nout, seed=403)
+    res = rnd(1, M, Nout, seed=404)
+    pw = ops.pack_linear_weight(w, b, device=DEV)
+    xd, rd = bf(x).to(DEV), bf(res).to(DEV)
+    assert ((M + 255) // 256) * ((Nout + 255) // 256) > 256
+    y = ops.linear(xd, pw, residual=rd)
+    assert_close(y, F.linear(x, w, b) + res, f"p8 linear + residual {M, K, Nout}")
+    for _ in range(20):
+        assert torch.equal(ops.linear(xd, pw, residual=rd), y), "p8: repeat differs"
+    y32 = ops.linear(xd, pw, out_dtype=ops.OUT_F32)
+    assert_close(y32, F.linear(x, w, b), "p8 f32 out", rel_l2=1e-5, max_ulps=0.05)
+
+
 @pytest.mark.parametrize("kind,N,C,Cout,H,W,G", [
     ("halo-channel", 4, 320, 320, 64, 64, 32),        # UNet level 0: group size 10 -> one entry per channel, slot per wave tile
     ("halo-channel", 4, 320, 640, 32, 96, 32),        # group size 20

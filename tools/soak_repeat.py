@@ -1,5 +1,5 @@
 """Soak: the same launch repeated many times must give the same bits (a mis-placed LDS-DMA wait shows up as rare wrong tiles).
-Kernels with hand-placed waits: igemm_p8_kernel, attn_kernel (LDS-DMA path), igemm_halo_kernel, igemm_dma_kernel. Usage: soak_repeat.py [reps]"""
+Kernels with hand-placed waits: igemm_p8_kernel (one-tile and persistent forms), attn_kernel (LDS-DMA path), igemm_halo_kernel, igemm_dma_kernel, igemm_gmx_kernel. Usage: soak_repeat.py [reps]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,6 +33,12 @@ for tier in (torch.bfloat16, torch.float32):
     x2 = (torch.randn(1, 147456, 320, generator=g) * 0.5).to(dt).to(dev)
     p2 = ops.pack_linear_weight(torch.randn(320, 320, generator=g) * 320 ** -0.5, None, device=dev)
     total += soak(f"[{tag}] dma linear 147456x320->320", lambda: ops.linear(x2, p2, out_dtype=ops.OUT_BF16), reps)
+# the mixed-precision GEMM (accurate tier only: fp16 K-steps then block-scaled fp8 K-steps behind a run-time ring stage)
+ops.set_compute_dtype(torch.float32)
+for M, C, N in [(147456, 320, 320), (36864, 640, 2560), (9216, 1280, 1280)]:
+    xm = ops.to_operand((torch.randn(1, M, C, generator=g) * 0.5).to(dev), 3)
+    pm = ops.pack_linear_weight(torch.randn(N, C, generator=g) * C ** -0.5, torch.randn(N, generator=g), device=dev, split=3)
+    total += soak(f"[accurate] gmx linear {M}x{C}->{N}", lambda: ops.linear(xm, pm), reps)
 ops.set_compute_dtype(torch.bfloat16)
 print("TOTAL differing:", total)
 sys.exit(1 if total else 0)
