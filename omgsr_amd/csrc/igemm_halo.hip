@@ -58,7 +58,7 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, con
         if (rc != 0) return rc;
         attr_set = true;
     }
-    const dim3 grid = (phase && g.interleave) ? dim3(4 * g.ntm * g.ntn) : dim3(g.ntm * g.ntn, phase ? 4 : 1, 1);
+    const dim3 grid = (phase && g.interleave) ? dim3(32 * ((g.ntm * g.ntn + 7) / 8)) : dim3(g.ntm * g.ntn, phase ? 4 : 1, 1);
     static const char* abl = ablation_env("OMGSR_HALO_ABLATE");      // timing experiments only: results are garbage (needs OMGSR_ABLATION_OK=1; bf16 only)
     static const char* var = getenv("OMGSR_HALO_VARIANT");     // A/B runs: "0" = LDS-DMA issued in front of the step's MFMAs
     if (phase) hipLaunchKernelGGL((igemm_halo_kernel<T, 0, false, false, 4>), grid, dim3(256), LDS_BYTES, st, a, g);

@@ -348,17 +348,43 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
     }
 }
 
+// Block b of an x-only phase-form grid -> (logical tile, phase). T = tiles of the problem; n8 = its 8-aligned block range in a multi-problem
+// launch (every XCD then owns n8 / 8 tiles, tiles >= T are fillers), 0 = single problem (XCD ranges as xcd_remap hands them out; the grid is
+// 8 x 4 x ceil(T / 8) blocks). chunked: see igemm_halo_kernel. Returns false for a filler block.
+OMGSR_DEVINL bool phase_block_map(const int b, const int T, const int n8, const bool chunked, int& tile, int& phase) {
+    constexpr int CH = 64;                             // one round of workgroups per XCD: 32 CUs x 2
+    const int xcd = b & 7, idx = b >> 3;
+    int base, cnt;
+    if (n8 > 0) { cnt = n8 >> 3; base = xcd * cnt; }
+    else {
+        const int q = T >> 3, r = T & 7;
+        base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        cnt = xcd < r ? q + 1 : q;
+    }
+    if (idx >= 4 * cnt) return false;
+    if (chunked) {
+        const int chunk = idx / (4 * CH), r = idx - chunk * 4 * CH;
+        const int left = cnt - chunk * CH, sz = left < CH ? left : CH;
+        phase = r / sz;
+        tile = base + chunk * CH + (r - phase * sz);
+    } else {
+        tile = base + (idx >> 2); phase = idx & 3;
+    }
+    return tile < T;
+}
+
 template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     int tile, phase;
-    // Phase form (TAPS = 4). The four phases of a tile read the SAME low-res patch. With blockIdx.y = phase the grid ran phase 0 over every
-    // tile, then phase 1 ...: the input (1.5 GB at the decoder's last upsampler, far beyond L2 + MALL) came from HBM four times (8.7 GB
-    // measured against 4.0 GB algorithmic per launch, profiles/r04_*traffic*.json). Interleaved: logical block L = 4 tile + phase of an
-    // x-only grid; the XCD remap hands each XCD a contiguous L range, so a tile's phases are dispatched together (blocks b, b + 8, b + 16,
-    // b + 24) onto one XCD and three of the four patch reads hit its L2.
+    // Phase form (TAPS = 4). The four phases of a tile read the SAME low-res patch and each its own phase-summed weights. Three block orders:
+    //  0  blockIdx.y = phase: phase 0 sweeps every tile, then phase 1 ...: one phase's weights stay hot in an XCD's L2, but the input comes
+    //     back after a whole sweep (1.5 GB at the decoder's last upsampler: beyond L2 + MALL, i.e. from DRAM four times)
+    //  1  phases of a tile adjacent (logical block 4 tile + phase): the patch is shared in L2, but the weights of all four phases stream
+    //     through every L2 at once (measured: FETCH_SIZE +35 % on the decoder's upsamplers, x2 on the UNet's whose weights are 26-105 MB)
+    //  2  (default) CHUNKED: per XCD, phase 0 of 64 tiles (one round of its workgroups), then phase 1 of the same 64 tiles, ...: one
+    //     phase's weights hot at a time AND the input chunk (a few MB) re-read one tile-time later, out of L2 / MALL
     if (TAPS == 4 && g.interleave) {
-        const int L = xcd_remap((int)blockIdx.x, 4 * g.ntm * g.ntn);
-        tile = L >> 2; phase = L & 3;
+        if (!phase_block_map((int)blockIdx.x, g.ntm * g.ntn, 0, g.interleave == 2, tile, phase)) return;
     } else {
         tile = xcd_remap((int)blockIdx.x, g.ntm * g.ntn); phase = (int)blockIdx.y;
     }
@@ -379,13 +405,9 @@ struct HaloMulti {
 template <typename T, bool NARROW, int TAPS, bool MX = false>
 __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMulti m) {
     int s = 0, tile, phase;
-    if (TAPS == 4 && m.g[0].interleave) {      // x-only grid of 4 x the 8-aligned ranges: logical block L = 4 tile + phase inside each problem's range (see igemm_halo_kernel)
+    if (TAPS == 4 && m.g[0].interleave) {      // x-only grid of 4 x the 8-aligned ranges; block order inside a problem's range: see igemm_halo_kernel
         while (s + 1 < m.count && (int)blockIdx.x >= 4 * m.start[s + 1]) ++s;      // wave-uniform
-        const int b = (int)blockIdx.x - 4 * m.start[s];
-        const int q = (m.start[s + 1] - m.start[s]) >> 1;                       // blocks per XCD of this range (4 x n8 / 8), a multiple of 4
-        const int L = (b & 7) * q + (b >> 3);
-        tile = L >> 2; phase = L & 3;
-        if (tile >= m.g[s].ntm * m.g[s].ntn) return;                            // filler tile of the 8-aligned range
+        if (!phase_block_map((int)blockIdx.x - 4 * m.start[s], m.g[s].ntm * m.g[s].ntn, m.start[s + 1] - m.start[s], m.g[0].interleave == 2, tile, phase)) return;
     } else {
         while (s + 1 < m.count && (int)blockIdx.x >= m.start[s + 1]) ++s;          // wave-uniform
         const int bid = (int)blockIdx.x - m.start[s];
@@ -402,8 +424,8 @@ static inline bool halo_geo(const omgsr_igemm_args& a, IgemmGeo& g, const bool p
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     static const char* mp = getenv("OMGSR_HALO_MAINPRIO");         // A/B runs: "1" | "2" = waves raise their priority for the K loop
     g.main_prio = mp ? atoi(mp) : 0;
-    static const char* il = getenv("OMGSR_PHASE_INTERLEAVE");      // A/B runs: "0" = blockIdx.y = phase (every phase sweeps the whole map)
-    g.interleave = (phase && !(il && il[0] == '0')) ? 1 : 0;
+    static const char* il = getenv("OMGSR_PHASE_INTERLEAVE");      // A/B runs: "0" = blockIdx.y = phase, "1" = phases adjacent, "2" = chunked (default)
+    g.interleave = phase ? (il ? atoi(il) : 2) : 0;
     g.nk = a.Cin / 32;
     g.tiles_x = ((phase ? a.W : a.Wo) + TW - 1) / TW;          // phase form: tiles of the LOW-res map, four phases each
     g.tiles_y = ((phase ? a.H : a.Ho) + TH - 1) / TH;

@@ -28,7 +28,7 @@ int igemm_halo_launch_mx(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) 
     halo_geo(a, g, a.upsample != 0);
     const int rc = mx_attrs();
     if (rc != 0) return rc;
-    if (a.upsample) hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 4, true>), g.interleave ? dim3(4 * g.ntm * g.ntn) : dim3(g.ntm * g.ntn, 4), dim3(256), LDS_BYTES, st, a, g);
+    if (a.upsample) hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 4, true>), g.interleave ? dim3(32 * ((g.ntm * g.ntn + 7) / 8)) : dim3(g.ntm * g.ntn, 4), dim3(256), LDS_BYTES, st, a, g);
     else hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 9, true>), dim3(g.ntm * g.ntn), dim3(256), LDS_BYTES, st, a, g);
     return (int)hipGetLastError();
 }

@@ -221,6 +221,12 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
         if constexpr (YEL == 3) store8_mx<T>(y, pix * 4 * C, C, cc8 * 8, v);
         else store8<T, YEL>(y, pix * ldy + cc8 * 8, C, v);
     };
+    // second output: x itself as an operand - plain, two-term split, or (Y2EL 3, round 4) the mixed-precision form of a 1x1 shortcut
+    // conv that runs as an MX GEMM
+    auto put2 = [&](const int64_t pix, const int cc8, const float (&v)[8]) {
+        if constexpr (Y2EL == 3) store8_mx<T>(y2, pix * 4 * C, C, cc8 * 8, v);
+        else if constexpr (Y2EL >= 0) store8<T, Y2EL>(y2, pix * (Y2EL == 2 ? 2 * C : C) + cc8 * 8, C, v);
+    };
     // two chunks (4 x 16-byte loads of an fp32 row) in flight per thread
     int i = t;
     for (; i + 256 < total; i += 512) {
@@ -231,8 +237,8 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
         load8<T, XF32>(x, (pix0 + pxb) * C + c8b * 8, h);
         if constexpr (Y2EL >= 0) {
             note8(f); note8(h);
-            store8<T, Y2EL>(y2, (pix0 + px) * (Y2EL == 2 ? 2 * C : C) + c8 * 8, C, f);
-            store8<T, Y2EL>(y2, (pix0 + pxb) * (Y2EL == 2 ? 2 * C : C) + c8b * 8, C, h);
+            put2(pix0 + px, c8, f);
+            put2(pix0 + pxb, c8b, h);
         }
         transform(f, c8);
         transform(h, c8b);
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
     for (; i < total; i += 256) {
         float f[8];
         load8<T, XF32>(x, (pix0 + px) * C + c8 * 8, f);
-        if constexpr (Y2EL >= 0) { note8(f); store8<T, Y2EL>(y2, (pix0 + px) * (Y2EL == 2 ? 2 * C : C) + c8 * 8, C, f); }
+        if constexpr (Y2EL >= 0) { note8(f); put2(pix0 + px, c8, f); }
         transform(f, c8);
         put(pix0 + px, c8, f);
         advance(c8, px);
@@ -617,7 +623,8 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
     if (!x || !y || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
     if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT && y_el != OMGSR_EL_MX)) return OMGSR_E_BADARG;
     if (y_el == OMGSR_EL_MX && ((C & 63) || omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;        // fp16 compute type, whole 64-channel fp8 chunks
-    if (y2 && (x_el != OMGSR_EL_F32 || (y2_el != OMGSR_EL_16 && y2_el != OMGSR_EL_SPLIT))) return OMGSR_E_BADARG;
+    if (y2 && (x_el != OMGSR_EL_F32 || (y2_el != OMGSR_EL_16 && y2_el != OMGSR_EL_SPLIT && y2_el != OMGSR_EL_MX))) return OMGSR_E_BADARG;
+    if (y2 && y2_el == OMGSR_EL_MX && ((C & 63) || omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
     if ((C & 7) || (C % G) || C > 8192) return OMGSR_E_SHAPE;
     if (act != OMGSR_ACT_NONE && act != OMGSR_ACT_SILU) return OMGSR_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -628,12 +635,17 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
     if (ppb < 1) ppb = 1;
     const int nblk = (int)((HW + ppb - 1) / ppb);
     omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, ((x_el == OMGSR_EL_F32 ? 4.0 : 2.0) + (y_el == OMGSR_EL_16 ? 2.0 : 4.0) +
-                                             (y2 ? (y2_el == OMGSR_EL_SPLIT ? 4.0 : 2.0) : 0.0)) * N * (double)HW * C, st);
+                                             (y2 ? (y2_el == OMGSR_EL_16 ? 2.0 : 4.0) : 0.0)) * N * (double)HW * C, st);
     const size_t lds = 2 * C * sizeof(float);
     const dim3 grid(nblk, N);
 #define OMGSR_GN_ANY2(YE, Y2) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, true, YE, Y2>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf))
 #define OMGSR_GN_ANY(XF, YE) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, XF, YE>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows))
-    if (y_el == OMGSR_EL_MX) {
+    if (y2 && y2_el == OMGSR_EL_MX) {        // the shortcut's operand in the mixed-precision form (fp16 compute type)
+        using T = f16_t;
+        if (y_el == OMGSR_EL_MX) hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 3, 3>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf);
+        else if (y_el == OMGSR_EL_SPLIT) hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 2, 3>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf);
+        else hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 0, 3>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf);
+    } else if (y_el == OMGSR_EL_MX) {
         using T = f16_t;
         if (y2 && y2_el == OMGSR_EL_SPLIT) hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 3, 2>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf);
         else if (y2) hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 3, 0>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf);

@@ -828,7 +828,7 @@ def _cast_twin(x: torch.Tensor, xel: int, also_cast: int):
 def group_norm_apply_shared(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma, beta, groups: int,
                             act: int = ACT_NONE, split: int = 1, also_cast: int = 0):
     """x [T*N, ..., C] tile-major; mean / rstd [N, G]: row r is normalised with the statistics of image r % N.
-    also_cast 1 | 2: returns (y, x as a plain / split operand) - see group_norm_apply."""
+    also_cast 1 | 2 | 3: returns (y, x as a plain / split / mixed-precision operand) - see group_norm_apply."""
     xel = _el(x, "x")
     rows, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (rows * Cc)
@@ -838,7 +838,7 @@ def group_norm_apply_shared(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Ten
     check(_lib.load().omgsr_groupnorm_apply_shared(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
                                                    _ptr(beta), rows, HW, Cc, groups, act, mean.shape[0], xel,
                                                    _el_of_split(split), y2.data_ptr() if fused else None,
-                                                   EL_SPLIT if also_cast == 2 else EL_16, _ovf(x.device) if fused else None, _stream()),
+                                                   _el_of_split(also_cast) if also_cast else EL_16, _ovf(x.device) if fused else None, _stream()),
           "omgsr_groupnorm_apply_shared")
     return (y, y2) if also_cast else y
 
@@ -846,8 +846,8 @@ def group_norm_apply_shared(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Ten
 def group_norm_apply(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: Optional[torch.Tensor],
                      beta: Optional[torch.Tensor], groups: int, act: int = ACT_NONE, inplace: bool = False, split: int = 1,
                      also_cast: int = 0):
-    """Stream tensor -> normalised (+SiLU) MFMA operand [..., split*C]. also_cast 1 | 2: additionally returns x itself as a
-    plain / two-term split operand (the input of a ResnetBlock's 1x1 shortcut conv), written by the same pass."""
+    """Stream tensor -> normalised (+SiLU) MFMA operand [..., split*C]. also_cast 1 | 2 | 3: additionally returns x itself as a
+    plain / two-term split / mixed-precision operand (the input of a ResnetBlock's 1x1 shortcut conv), written by the same pass."""
     xel = _el(x, "x")
     N, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * Cc)
@@ -856,7 +856,7 @@ def group_norm_apply(x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, ga
     fused = y2 is not None and y2 is not x
     check(_lib.load().omgsr_groupnorm_apply(x.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
                                             _ptr(beta), N, HW, Cc, groups, act, xel, _el_of_split(split),
-                                            y2.data_ptr() if fused else None, EL_SPLIT if also_cast == 2 else EL_16,
+                                            y2.data_ptr() if fused else None, _el_of_split(also_cast) if also_cast else EL_16,
                                             _ovf(x.device) if fused else None, _stream()),
           "omgsr_groupnorm_apply")
     return (y, y2) if also_cast else y

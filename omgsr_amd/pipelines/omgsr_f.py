@@ -73,7 +73,6 @@ class OMGSR_F_Infer(torch.nn.Module):
             resolve(precision_policy, vae=self.vae, flux=self.flux_transformer)
         self.range_fallback = RangeFallback(self.vae, self.flux_transformer)
         from .graphed import GraphCache          # hipGraph replay of forward()'s body: off by default, enable_graphs() / OMGSR_GRAPH=1
-        import os
         self.graphs = GraphCache()
         self.graphs.enabled = os.environ.get("OMGSR_GRAPH", "0") == "1"
         self.range_fallback.on_mode_change = self.graphs.clear

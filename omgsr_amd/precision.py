@@ -104,8 +104,10 @@ FLUX_ACT, FLUX_W = FLUX_DEFAULT, FLUX_DEFAULT
 # Cin % 64 == 0 whose operand a GroupNorm pass writes (ResnetBlock conv1 / conv2); they always take the halo-tile kernel.
 # ... and the nearest-2x upsampling convs (phase-decomposed form), whose operand the previous block's conv / linear epilogue writes.
 _DEC_UPS = r"^decoder\..*upsamplers\.0\.conv$"
-VAE_MX = [r"^encoder\..*resnets\.\d+\.conv[12]$", r"^decoder\.(mid_block|up_blocks\.0)\.resnets\.\d+\.conv[12]$", _DEC_UPS]
-UNET_MX = [_L64 + r"resnets\.\d+\.conv[12]$", _L32 + r"resnets\.\d+\.conv[12]$", r"upsamplers\.0\.conv$"]
+# ... and (round 4) the ResnetBlocks' 1x1 shortcut convs: GEMM-shaped, they run on igemm_gmx_kernel; their operand is the second output of
+# norm1's apply pass (also_cast 3)
+VAE_MX = [r"^encoder\..*resnets\.\d+\.conv[12]$", r"^decoder\.(mid_block|up_blocks\.0)\.resnets\.\d+\.conv[12]$", _DEC_UPS, r"\.conv_shortcut$"]
+UNET_MX = [_L64 + r"resnets\.\d+\.conv[12]$", _L32 + r"resnets\.\d+\.conv[12]$", r"upsamplers\.0\.conv$", r"\.conv_shortcut$"]
 
 
 def set_operand_split(model: nn.Module, patterns: Iterable[str], split: int = 2) -> int:
@@ -177,8 +179,9 @@ def set_mx_linear(model: nn.Module, patterns: Iterable[str]) -> int:
 
 
 def set_mx(model: nn.Module, patterns: Iterable[str]) -> int:
-    """Move the both-sides split of the matching 3x3 stride-1 convolutions (Cin % 64 == 0, >= 96 output channels) to the
-    mixed-precision form (op_split 3); layers that do not qualify keep what they had. OMGSR_MX=0 switches the form off (A/B runs).
+    """Move the both-sides split of the matching 3x3 stride-1 (halo-tile kernel) and 1x1 (MX GEMM kernel) convolutions (Cin % 64 == 0,
+    >= 96 output channels) to the mixed-precision form (op_split 3); layers that do not qualify keep what they had. OMGSR_MX=0
+    switches the form off (A/B runs).
     Returns how many layers were moved."""
     import os
     if os.environ.get("OMGSR_MX", "1") == "0":
@@ -187,7 +190,9 @@ def set_mx(model: nn.Module, patterns: Iterable[str]) -> int:
     n = 0
     for name, m in model.named_modules():
         if isinstance(m, Conv2d) and any(r.search(name) for r in regs):
-            if m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.in_channels % 64 == 0 and m.out_channels >= 96 \
+            conv3 = m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)          # halo-tile kernel
+            conv1 = m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0)          # GEMM-shaped: igemm_gmx_kernel (round 4)
+            if (conv3 or conv1) and m.in_channels % 64 == 0 and m.out_channels >= 96 \
                     and m.out_channels % 8 == 0 and m.op_split == 2 and m.w_split == 2:
                 m.op_split = 3
                 n += 1

@@ -337,6 +337,36 @@ def test_linear_mx_geglu_transposed_and_chained_outputs():
     assert _rel(vt[..., :L], vref) < 6e-4 and _rel(vt[..., :L].float(), vref.to(torch.float16).float()) < 1.5e-4
 
 
+def test_shortcut_conv_mx_from_groupnorm_second_output():
+    """A ResnetBlock's 1x1 shortcut in the mixed-precision form (round 4): norm1's apply pass writes conv1's operand AND x itself as an
+    OMGSR_EL_MX operand (also_cast 3) in one pass; the 1x1 conv consumes it on igemm_gmx_kernel. Through the module and op by op."""
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api.autoencoder_kl import ResnetBlock2D
+    from omgsr_amd.precision import set_mx, set_operand_split, set_weight_split
+    N, H, W, C, Co = 2, 40, 56, 256, 128
+    x = torch.randn(N, H, W, C, generator=_g(90)) * 1.5 + 0.2
+    xd = x.to(DEV)
+    gamma, beta = 1.0 + 0.1 * torch.randn(C, generator=_g(91)), 0.05 * torch.randn(C, generator=_g(92))
+    for ysplit in (1, 2, 3):
+        y, x3 = ops.group_norm(xd, gamma.to(DEV), beta.to(DEV), 32, 1e-6, ops.ACT_SILU, split=ysplit, also_cast=3)
+        assert torch.equal(x3, ops.to_operand(xd, 3))                      # the twin is exactly the cast kernel's MX operand
+        assert torch.equal(y, ops.group_norm(xd, gamma.to(DEV), beta.to(DEV), 32, 1e-6, ops.ACT_SILU, split=ysplit))
+    w = torch.randn(Co, C, 1, 1, generator=_g(93)) * C ** -0.5
+    b = 0.1 * torch.randn(Co, generator=_g(94))
+    pw = ops.pack_conv_weight(w, b, device=DEV, cout_multiple=8, split=3)
+    got = ops.conv2d(x3, pw, pad=0)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double()).permute(0, 2, 3, 1)
+    assert got.dtype == torch.float32 and _rel(got, ref) < 2e-5
+    blk = ResnetBlock2D(C, Co, None, 32, 1e-6).to(DEV)
+    from omgsr_amd.testing import seeded_init_
+    seeded_init_(blk, 5, rounded=False)
+    set_operand_split(blk, [r"."]); set_weight_split(blk, [r"."])
+    two = blk.nhwc(xd)
+    assert set_mx(blk, [r"conv[12]$", r"conv_shortcut$"]) == 3 and blk.conv_shortcut.op_split == 3
+    mx = blk.nhwc(xd)
+    assert _rel(mx, two.double()) < 2e-5                                     # the MX block against the three-fp16-segment block
+
+
 def test_attention_writes_mx_operand():
     """omgsr_attention with o_mx: the output projection's operand leaves the attention epilogue in the mixed-precision form; hi is
     bit-identical to the plain output, hi + lo' 2^-11 equals the two-term split's hi + lo to fp8 accuracy of the low part."""
