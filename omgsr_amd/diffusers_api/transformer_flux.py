@@ -168,13 +168,13 @@ class FluxSingleTransformerBlock(nn.Module):
         csp = self.proj_out.in_split()
         qk, vt, cat = ws["qk"], ws["vt"], ws["cat2" if csp == 2 else "cat"]
         Kc = D + self.mlp_hidden                           # the [attn | mlp] operand of proj_out; split form: [hi (Kc) | lo (Kc)]
-        ops.linear_into(xn.reshape(B * L, -1), at.qk_packed(), qk.reshape(B * L, -1), 0, 0)
+        ops.linear_into(xn.reshape(B * L, -1), at.qk_packed(), qk.reshape(B * L, -1), 0, 0, sample_rows=L)
         ops.linear_t_into(xn, at.to_v.packed(), vt, 0)
         ops.rmsnorm_rope_(qk, at.norm_table(), rope[0], rope[1], 2 * at.heads, at.head_dim, pos0=0)
         ops.attention(qk, qk, vt, at.heads, at.head_dim, at.scale, q_col=0, k_col=at.inner, Lk=L, out=cat,
                       out_split=csp, o_lo_col=Kc)
         cat2d = cat.reshape(B * L, -1)
-        ops.linear_into(xn.reshape(B * L, -1), self.proj_mlp.packed(), cat2d, 0, D, act=ops.ACT_GELU_TANH, out_split=csp, lo_col0=Kc + D)
+        ops.linear_into(xn.reshape(B * L, -1), self.proj_mlp.packed(), cat2d, 0, D, act=ops.ACT_GELU_TANH, out_split=csp, lo_col0=Kc + D, sample_rows=L)
         return self.proj_out.nhwc(cat, residual=x, gate=mod["g"])
 
 

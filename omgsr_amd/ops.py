@@ -134,10 +134,15 @@ def overflow_seen(reset: bool = True) -> bool:
     return seen
 
 
+_BATCH_INVARIANT = False
+
+
 def set_batch_invariant(on: bool) -> None:
     """Process-wide: make kernel-family / split-K choices depend on one sample's size instead of the batch's (omgsr_set_batch_invariant):
     a batch of B then equals B batch-1 calls bit for bit, at some cost in speed for small batches."""
+    global _BATCH_INVARIANT
     check(_lib.load().omgsr_set_batch_invariant(int(bool(on))), "omgsr_set_batch_invariant")
+    _BATCH_INVARIANT = bool(on)
 
 
 STAGE_NONE, STAGE_ENCODE, STAGE_DENOISE, STAGE_DECODE = 0, 1, 2, 3
@@ -193,10 +198,13 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def _igemm(a: "IgemmArgs", device, what: str) -> None:
-    """Launch omgsr_igemm; when the library wants to split K (small-M / long-K problems) hand it an fp32 scratch."""
+def _igemm(a: "IgemmArgs", device, what: str, z_batched_api: bool = False) -> None:
+    """Launch omgsr_igemm; when the library wants to split K (small-M / long-K problems) hand it an fp32 scratch.
+    z_batched_api: the caller is one of the entry points that put the images of a call on grid.z (linear_into / linear_rows / bmm_nt).
+    The library cannot split K there when there is more than one image, so in batch-invariant mode it must not split the one-image
+    call either (round 4: OMGSR-F batch 1 == batch N bit for bit under ops.set_batch_invariant)."""
     lib = _lib.load()
-    need = lib.omgsr_igemm_workspace_bytes(C.byref(a))
+    need = 0 if (z_batched_api and _BATCH_INVARIANT) else lib.omgsr_igemm_workspace_bytes(C.byref(a))
     ws = None
     if need > 0:
         ws = torch.empty(need // 4, device=device, dtype=torch.float32)
@@ -576,7 +584,7 @@ def carry_gn(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
 
 def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int, col0: int, *, act: int = ACT_NONE,
                 residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, out_split: int = 1,
-                lo_col0: Optional[int] = None) -> None:
+                lo_col0: Optional[int] = None, sample_rows: int = 0) -> None:
     """out[row0:row0+M, col0:col0+Cout] = epilogue(x @ W^T): writes a projection straight into a slice of a
     larger 2-D operand buffer `out` [rows, ld] (joint text+image sequences, [attn | mlp] concat). out_split 2: the low
     halves of the two-term split go to columns lo_col0 ... lo_col0+Cout of the same rows (default col0 + Cout)."""
@@ -610,8 +618,8 @@ def linear_into(x: torch.Tensor, pw: PackedWeight, out: torch.Tensor, row0: int,
     a.out_ld = ld
     a.batch, a.alpha = Bz, 1.0
     a.in_bstride, a.w_bstride, a.out_bstride = M * K, 0, nrows * ld
-    a.sample_rows = M
-    _igemm(a, x.device, "omgsr_igemm(linear_into)")
+    a.sample_rows = sample_rows or M              # rows of ONE image when the caller flattened a batch into M (batch-invariant dispatch)
+    _igemm(a, x.device, "omgsr_igemm(linear_into)", z_batched_api=True)
 
 
 def linear_rows(x_buf: torch.Tensor, row0: int, rows: int, pw: PackedWeight, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,

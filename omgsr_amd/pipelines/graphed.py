@@ -57,6 +57,8 @@ class GraphCache:
             self.replays += 1
             return static_out.clone()
         n = self._seen.get(full, 0)
+        if len(self._seen) > 4096:       # keys are cheap (ints / shapes), but a service that sees ever-new prompts must not grow without bound
+            self._seen.clear()
         self._seen[full] = n + 1
         if n == 0:                       # first sight: eager (warms packed weights, folded constants, kernel attributes, the allocator)
             return fn(*dynamic)

@@ -147,3 +147,46 @@ def test_batch_invariant_mode_is_exact_full_size(wd):
     finally:
         ops.set_batch_invariant(False)
         ops.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("wd", [torch.bfloat16, torch.float32], ids=["bf16", "accurate"])
+def test_flux_batch_invariant_mode_is_exact_full_width(wd):
+    """The same property for the Flux executor ('no Flux batch-invariance test'), FLUX.1-dev width, 2 + 2 blocks, 4096 + 512
+    tokens: with ops.set_batch_invariant(True) a batch of 3 equals three batch-1 calls BIT FOR BIT. Without the switch the two differ by
+    ~28 % of the tier's own error (batch 1's small-M GEMMs take split-K; profiles/r04_experiments.md): in batch-invariant mode the entry
+    points that put the images on grid.z never split K, and the flattened single-stream GEMMs are dispatched on one image's rows."""
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api import FluxTransformer2DModel
+    from omgsr_amd.pipelines.omgsr_f import get_flux_setting_timesteps, prepare_latent_image_ids
+    from omgsr_amd.testing import seeded_init_device_
+    try:
+        ops.set_compute_dtype(wd)
+        ops.set_batch_invariant(True)
+        with torch.device("meta"):
+            f = FluxTransformer2DModel(num_layers=2, num_single_layers=2)
+        f = f.to_empty(device=DEV)
+        seeded_init_device_(f, 404)
+        f = f.to(wd).eval()
+        if wd == torch.float32:
+            from omgsr_amd.precision import apply_default_policy
+            apply_default_policy(flux=f)
+        g = torch.Generator().manual_seed(1)
+        tok = torch.randn(3, 4096, 64, generator=g).to(DEV, wd)
+        pe, pooled = torch.randn(1, 512, 4096, generator=g).to(DEV, wd), torch.randn(1, 768, generator=g).to(DEV, wd)
+        tids, iids = torch.zeros(512, 3, device=DEV, dtype=wd), prepare_latent_image_ids(64, 64, DEV, wd)
+        t = torch.tensor([get_flux_setting_timesteps()[-(244 + 1)]], device=DEV)
+
+        def fwd(x):
+            with torch.no_grad():
+                return f(hidden_states=x, timestep=t, guidance=torch.full((x.shape[0],), 1.0, device=DEV), pooled_projections=pooled,
+                         encoder_hidden_states=pe, txt_ids=tids, img_ids=iids, return_dict=False)[0]
+        full = fwd(tok)
+        for i in range(3):
+            one = fwd(tok[i:i + 1].contiguous())
+            assert torch.equal(one, full[i:i + 1]), f"{wd} image {i}: batch-3 and batch-1 bits differ"
+        ops.set_batch_invariant(False)
+        d = ((fwd(tok[:1].contiguous()).float() - fwd(tok)[:1].float()).norm() / full[:1].float().norm()).item()
+        print(f"Flux 2+2, {wd}: default dispatch, batch 1 vs batch 3: rel-L2 {d:.3e} (summation order -> decorrelated rounding noise)")
+    finally:
+        ops.set_batch_invariant(False)
+        ops.set_compute_dtype(torch.bfloat16)
