@@ -212,11 +212,17 @@ bool igemm_p8_wanted(const omgsr_igemm_args& a, const IgemmGeo& g) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     const int64_t t256 = (int64_t)((g.M + BM - 1) / BM) * ((logical_cols + BN - 1) / BN) * a.batch;
     const int cols256 = ((logical_cols + 255) / 256) * 256, cols128 = ((logical_cols + 127) / 128) * 128;
-    // K >= 1536: with fewer K-tiles the six half-tiles of prologue and the 129 KB of LDS (one workgroup per CU) cost more than the
-    // schedule wins (the UNet's GEGLU projections, K = 640 / 1280: S-1024 step 165.1 -> 165.7 ms with them on this kernel)
+    // (round 2: K >= 1536, because with fewer K-tiles the six half-tiles of prologue and the 129 KB of LDS (one workgroup per CU) cost more
+    // than the schedule wins: the UNet's GEGLU projections, K = 640 / 1280: S-1024 step 165.1 -> 165.7 ms with them on this kernel)
     static const char* mt = getenv("OMGSR_P8_MIN_TILES");          // A/B runs
     const int min_tiles = mt ? atoi(mt) : 128;      // half the CUs: 192 tiles (Flux context tokens, M = 4096) run 25 % faster here than as 384 tiles of 256 x 128
-    return t256 >= min_tiles && cols256 * 16 <= cols128 * 17 && a.Cin >= 24 * BK;
+    // K threshold: round 2 set 1536 (shorter K loses to the exposed prologue / epilogue of one workgroup per CU). Round 4 measured why the
+    // 256 x 128 tile is slow on the same problems - its operand stream moves 1.5x the bytes through the LDS-DMA path, which is what bounds a
+    // short-K GEMM (profiles/r04_experiments.md) - and re-ran the A/B: K >= 640 is 0.3-0.8 % faster on both tiers' S-1024 steps
+    // (bf16 130.1 -> 129.1 ms: 52 launches move, dma -5.6 ms, p8 +5.0 ms), K >= 1280 is in between. OMGSR_P8_MIN_K for A/B.
+    static const char* mk = getenv("OMGSR_P8_MIN_K");
+    const int min_k = mk ? atoi(mk) : 10 * BK;
+    return t256 >= min_tiles && cols256 * 16 <= cols128 * 17 && a.Cin >= min_k;
 }
 
 int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
