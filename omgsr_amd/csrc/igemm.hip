@@ -560,7 +560,17 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         }
     }
     // GEMM-shaped problem over a mixed-precision operand (the UNet's transformer-block linears in the accurate tier)
-    if (a.mx_chunks16 > 0 && omgsr::igemm_gmx_ok(a)) { ts.rec.variant = 9; return omgsr::igemm_gmx_launch(a, g, st); }
+    if (a.mx_chunks16 > 0 && omgsr::igemm_gmx_ok(a)) {
+        // wide projections (GEGLU, q|k, N >= 1280): the ping-pong kernel's 256 x 256 tile moves 2/3 of the operand bytes of 256 x 128 through the
+        // LDS-DMA path, which is what bounds these short-K problems (profiles/r04_experiments.md). OMGSR_P8_MX=0 for A/B.
+        static const char* pm = getenv("OMGSR_P8_MX");
+        if (!(pm && pm[0] == '0') && !omgsr::g_batch_invariant && a.batch == 1 && omgsr::igemm_p8_wanted(a, g)) {
+            ts.rec.variant = 5;
+            return omgsr::igemm_p8_launch(a, g, st);
+        }
+        ts.rec.variant = 9;
+        return omgsr::igemm_gmx_launch(a, g, st);
+    }
     // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
     if (use_halo_phase(a)) { ts.rec.variant = 6; return omgsr::igemm_halo_launch(a, g, st, true); }
     if (use_halo(a)) { ts.rec.variant = 3; return omgsr::igemm_halo_launch(a, g, st); }

@@ -48,7 +48,11 @@ OMGSR_DEVINL void glds16_sv(const unsigned voff, const void* sbase, const unsign
         : "memory");
 }
 
-template <typename T>
+// MX (round 4, T = fp16 only): the operand / weight rows are OMGSR_EL_MX rows (see igemm_gmx.hip): the first mx_chunks16 / 2 K-tiles hold 64
+// fp16 slots, the others 128 fp8 channels - two v_mfma_scale_f32_32x32x64_f8f6f4 per fragment pair instead of four fp16 MFMAs, the same 256
+// matrix-pipe cycles per phase. K-tiles come in (E, O) pairs, so the contraction is three loops: fp16 pairs, ONE mixed pair when the number
+// of fp16 K-tiles is odd (C = 320: 5 + 5 K-tiles), fp8 pairs. Fragments live in i32x8 tuples whose halves the fp16 phases use as they are.
+template <typename T, bool MX = false>
 __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63;
@@ -126,6 +130,107 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const omgsr_igemm_args
     asm volatile("" ::: "memory");
     if (wr == 1) __builtin_amdgcn_s_barrier();         // group 1 runs half a phase behind group 0 from here on
 
+    if constexpr (MX) {
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        i32x8_t a8[2][2], b08[2], b18[2];              // [ii][i] / [i]: k-steps 2 i (low half) and 2 i + 1 (high half) of a K-tile
+        const int n16t = p.mx_chunks16 >> 1;           // fp16 K-tiles
+        const int cbytes = p.Cin >> 1;                 // C: bytes of each fp8 segment of a row (a_lo' | a_hi')
+        auto ld8 = [&](const unsigned lo, const unsigned hi) {
+            return __builtin_shufflevector(*reinterpret_cast<const i32x4_t*>(lds + lo), *reinterpret_cast<const i32x4_t*>(lds + hi), 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto lo4 = [](const i32x8_t v) { return __builtin_bit_cast(x8_t<T>, __builtin_shufflevector(v, v, 0, 1, 2, 3)); };
+        auto hi4 = [](const i32x8_t v) { return __builtin_bit_cast(x8_t<T>, __builtin_shufflevector(v, v, 4, 5, 6, 7)); };
+        auto phase = [&](auto P_c, auto f8_c, const int kt) {
+            constexpr int P = decltype(P_c)::value, X = P >> 2, q = P & 3;
+            constexpr bool F8 = decltype(f8_c)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (q == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) b08[i] = ld8(fb[X][2 * i], fb[X][2 * i + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a8[ii][i] = ld8(fa[X][2 * i] + ii * 4096, fa[X][2 * i + 1] + ii * 4096);
+            } else if constexpr (q == 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) b18[i] = ld8(fb[X][2 * i] + 4096, fb[X][2 * i + 1] + 4096);
+            } else if constexpr (q == 2) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a8[ii][i] = ld8(fa[X][2 * i] + (2 + ii) * 4096, fa[X][2 * i + 1] + (2 + ii) * 4096);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (P == 0) stage(1, 0, kt + 1);
+            else if constexpr (P == 1) stage(1, 1, kt + 1);
+            else if constexpr (P == 2) stage(0, 2, kt + 2);
+            else if constexpr (P == 3) stage(0, 3, kt + 2);
+            else if constexpr (P == 4) stage(0, 0, kt + 2);
+            else if constexpr (P == 5) stage(0, 1, kt + 2);
+            else if constexpr (P == 6) stage(1, 2, kt + 3);
+            else stage(1, 3, kt + 3);
+            // E8M0 scale operands of this K-tile's two 64-byte halves: a half belongs to the a_lo' x w_hi' segment while its byte offset in the
+            // fp8 part of the row is below C, to a_hi' x w_lo' from there on (C = 320: the third fp8 K-tile straddles the two). VGPRs written
+            // by VALU moves in front of the waits (the asm MFMAs that read them are invisible to the compiler's hazard padding).
+            int sw[2] = {0, 0}, sa[2] = {0, 0};
+            if constexpr (F8) {
+                const int off = (kt + X - n16t) * 128;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool seg2 = off + 64 * i >= cbytes;
+                    sw[i] = seg2 ? p.mx_scale_w2 : p.mx_scale_w1;
+                    sa[i] = seg2 ? p.mx_scale_a2 : p.mx_scale_a1;
+                    asm volatile("" : "+v"(sw[i]), "+v"(sa[i]));
+                }
+            }
+            if constexpr (q == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            constexpr int i0 = (q >= 2) ? 2 : 0;
+            constexpr int j = (q == 1 || q == 2) ? 1 : 0;
+            if constexpr (F8) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+                        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+                                     : "+v"(acc[i0 + ii][j]) : "v"(j ? b18[i] : b08[i]), "v"(a8[ii][i]), "v"(sw[i]), "v"(sa[i]));   // transposed tile
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) acc[i0 + ii][j] = mfma32(lo4(j ? b18[i] : b08[i]), lo4(a8[ii][i]), acc[i0 + ii][j]);
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) acc[i0 + ii][j] = mfma32(hi4(j ? b18[i] : b08[i]), hi4(a8[ii][i]), acc[i0 + ii][j]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto pair = [&](auto fe_c, auto fo_c, const int kt) {
+            phase(std::integral_constant<int, 0>{}, fe_c, kt);
+            phase(std::integral_constant<int, 1>{}, fe_c, kt);
+            phase(std::integral_constant<int, 2>{}, fe_c, kt);
+            phase(std::integral_constant<int, 3>{}, fe_c, kt);
+            phase(std::integral_constant<int, 4>{}, fo_c, kt);
+            phase(std::integral_constant<int, 5>{}, fo_c, kt);
+            phase(std::integral_constant<int, 6>{}, fo_c, kt);
+            phase(std::integral_constant<int, 7>{}, fo_c, kt);
+        };
+        int kt = 0;
+        for (; kt + 1 < n16t; kt += 2) pair(std::false_type{}, std::false_type{}, kt);
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");        // (the asm MFMAs below are invisible to the compiler's hazard padding)
+        if (kt < n16t) { pair(std::false_type{}, std::true_type{}, kt); kt += 2; }
+        for (; kt < nkt; kt += 2) pair(std::true_type{}, std::true_type{}, kt);
+        // the last asm MFMAs (16 passes each) must have written the accumulators before the epilogue's VALU reads them
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    } else {
     x8_t<T> af[2][4], b0[4], b1[4];
     auto phase = [&](auto P_c, const int kt) {
         constexpr int P = decltype(P_c)::value, X = P >> 2, q = P & 3;
@@ -187,6 +292,7 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const omgsr_igemm_args
         phase(std::integral_constant<int, 6>{}, kt);
         phase(std::integral_constant<int, 7>{}, kt);
     }
+    }
     if (wr == 0) __builtin_amdgcn_s_barrier();         // re-align the groups
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the dummy pieces of the last phases
 
@@ -237,6 +343,16 @@ int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(g.ntm * g.ntn, 1, a.batch);
+    if (a.mx_chunks16 > 0) {            // mixed-precision rows (fp16 compute type; the dispatcher checked igemm_gmx_ok)
+        static bool mx_attr = false;
+        if (!mx_attr) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_p8_kernel<f16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+            mx_attr = true;
+        }
+        hipLaunchKernelGGL((igemm_p8_kernel<f16_t, true>), grid, dim3(512), LDS_BYTES, st, a, g);
+        return (int)hipGetLastError();
+    }
     OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_p8_kernel<T>), grid, dim3(512), LDS_BYTES, st, a, g));
     return (int)hipGetLastError();
 }

@@ -275,11 +275,15 @@ def _mx_decode(y, C):
     return hi, lo, hi8
 
 
-@pytest.mark.parametrize("M,C,Nn", [(300, 320, 320), (147456, 320, 320), (36864, 640, 1280), (9216, 1280, 1280), (4100, 64, 192), (20000, 1280, 320)])
+@pytest.mark.parametrize("M,C,Nn", [(300, 320, 320), (147456, 320, 320), (36864, 640, 1280), (9216, 1280, 1280), (4100, 64, 192), (20000, 1280, 320),
+                                    (147456, 320, 2560), (33000, 320, 1280), (40000, 448, 512)])
 def test_linear_mx(M, C, Nn):
-    """a Linear in the mixed-precision form on igemm_gmx_kernel - a_hi w_hi in fp16 MFMAs, a_lo w_hi + a_hi w_lo as
-    block-scaled fp8 MFMAs, one fp32 accumulator - from a full-mantissa fp32 operand and weight: ~1e-5 of the fp64 product where one
-    fp16 rounding of each side leaves ~3e-4; fp32 output with fp32 residual, ragged M, every K-step count mod 3 (C / 32 = 10, 20, 40, 2)."""
+    """a Linear in the mixed-precision form - a_hi w_hi in fp16 MFMAs, a_lo w_hi + a_hi w_lo as block-scaled fp8 MFMAs,
+    one fp32 accumulator - from a full-mantissa fp32 operand and weight: ~1e-5 of the fp64 product where one fp16 rounding of each side
+    leaves ~3e-4; fp32 output with fp32 residual, ragged M. Narrow problems run on igemm_gmx_kernel (every K-step count mod 3: C / 32 = 10,
+    20, 40, 2), wide ones (N >= 256-friendly, >= 128 tiles) on the ping-pong kernel's MX instantiation: an even number of fp16 K-tiles
+    (C = 640, 1280), an odd one = the mixed fp16 / fp8 pair with the scale switch inside a K-tile (C = 320), and C = 448 (7 + 7 K-tiles,
+    the a_lo' / a_hi' boundary in the middle of a K-tile pair)."""
     from omgsr_amd import ops
     x = torch.randn(1, M, C, generator=_g(60))
     w = torch.randn(Nn, C, generator=_g(61)) * C ** -0.5
@@ -331,6 +335,14 @@ def test_linear_mx_geglu_transposed_and_chained_outputs():
     e = _rel(y, ref)
     print(f"LayerNorm -> GEGLU (MX) -> FF out (MX) + residual: rel {e:.2e}")
     assert y.dtype == torch.float32 and e < 3e-5
+    # the same chain at a size whose GEGLU projection takes the ping-pong kernel's MX instantiation (36864 rows x 2 x 2560 packed columns)
+    xb = torch.randn(1, 36864, C, generator=_g(78)).to(DEV)
+    xnb = ops.layer_norm(xb, g.to(DEV), bb.to(DEV), 1e-5, split=3)
+    hb = ops.linear(xnb, ops.pack_geglu_weight(w1, b1, device=DEV, split=3), out_dtype=ops.OUT_BF16, out_split=3)
+    lnb = F.layer_norm(xb.double(), (C,), g.to(DEV).double(), bb.to(DEV).double(), 1e-5)
+    ab, gb = (lnb @ w1.to(DEV).double().t() + b1.to(DEV).double()).chunk(2, dim=-1)
+    hhb, hlb, _ = _mx_decode(hb.cpu(), 4 * C)
+    assert _rel(hhb + hlb, (ab * F.gelu(gb)).cpu()) < 4e-5
     vt = ops.linear_t(xn, ops.pack_linear_weight(wv, None, device=DEV, split=3), L)          # [B, C, L8] fp16
     vref = (ln @ wv.double().t()).transpose(1, 2)
     # one fp16 rounding of the exact product; against the ROUNDED exact product only the values that sit on a rounding boundary differ

@@ -38,7 +38,7 @@ ops.set_compute_dtype(torch.float32)
 for M, C, N in [(147456, 320, 320), (36864, 640, 2560), (9216, 1280, 1280)]:
     xm = ops.to_operand((torch.randn(1, M, C, generator=g) * 0.5).to(dev), 3)
     pm = ops.pack_linear_weight(torch.randn(N, C, generator=g) * C ** -0.5, torch.randn(N, generator=g), device=dev, split=3)
-    total += soak(f"[accurate] gmx linear {M}x{C}->{N}", lambda: ops.linear(xm, pm), reps)
+    total += soak(f"[accurate] MX linear {M}x{C}->{N} (gmx | p8-MX)", lambda: ops.linear(xm, pm), reps)
 ops.set_compute_dtype(torch.bfloat16)
 print("TOTAL differing:", total)
 sys.exit(1 if total else 0)
