@@ -32,13 +32,6 @@
 namespace {
 
 constexpr int TH = 8, TW = 32;
-// Weight-slice prefetch distance in K-steps (A/B builds: -DOMGSR_HALO_BDIST=3 = a four-stage ring filled three steps ahead; 2 = the
-// three-stage ring of the 3 x 3 form, stage = tap % 3 a compile-time constant)
-#ifndef OMGSR_HALO_BDIST
-#define OMGSR_HALO_BDIST 2
-#endif
-constexpr int BDIST = OMGSR_HALO_BDIST;
-static_assert(BDIST == 2 || BDIST == 3, "weight-slice prefetch distance");
 // Geometry of the two tap sets. 3 x 3: patch (8+2) x (32+2) = 340 pixels = 22 1-KiB DMA pieces (16 patch rows each), every wave
 // issues 6 so the vmcnt arithmetic is uniform (pieces 22, 23 copy the zero page to a dummy KiB), weight ring 3 deep (9 % 3 == 0:
 // stage = tap % 3). 2 x 2 (phase-decomposed upsampling): patch 9 x 33 = 297 pixels = 19 pieces, 5 per wave, ring 4 deep (stage = tap).
@@ -47,7 +40,7 @@ template <int TAPS> struct HaloGeo {
     static constexpr int PW = TW + KS - 1, PH = TH + KS - 1, PROWS = PH * PW;
     static constexpr int APIECES = (PROWS + 15) / 16, APW = (APIECES + 3) / 4;
     static constexpr int A_BYTES = APIECES * 1024;
-    static constexpr int NB = (TAPS == 9 && BDIST == 2) ? 3 : 4;
+    static constexpr int NB = TAPS == 9 ? 3 : 4;
     static constexpr int DUMMY_OFF = 2 * A_BYTES, B_OFF = DUMMY_OFF + 2048;
     static constexpr int LDS_BYTES = B_OFF + NB * 128 * 64;
 };
@@ -194,7 +187,6 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         issue_a(0, 0);
         issue_b(0);
         issue_b(1);
-        if constexpr (BDIST == 3) issue_b(2);          // nsteps >= TAPS >= 4
     }
 
     // one K-step with compile-time tap and patch parity
@@ -212,19 +204,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         // is free to sink MFMAs (and the lgkmcnt wait in front of them) below the barrier, and a ds_read still queued
         // there raced the next LDS-DMA write about once per 10^5 tiles (one wave, a few weight rows of one K-step: found by
         // the bit-repeatability test; the s_setprio variant pins the MFMAs and never showed it)
-        // ring stage of step s = cc * TAPS + tap: tap % 3 in the three-stage ring (9 % 3 == 0); s & 3 in the four-stage ring = (cc + tap) & 3
-        // for nine taps (a wave-uniform run-time value: two VALU adds per step on the fragment addresses), tap for four
-        const int st = NB == 3 ? tap % 3 : (TAPS == 9 ? ((cc + tap) & 3) : tap);
         if constexpr (ABL == 2) {
-        } else if constexpr (BDIST == 3) {
-            // in flight behind slice s: the slices of steps s + 1, s + 2 (two pieces each) and, if they were issued in between (tap 0
-            // issues the next chunk's patch in front of its slice), the APW patch pieces
-            const int left = nsteps - 1 - s;
-            const bool patch = (tap == 1 || tap == 2) && cc + 1 < ncc;
-            if (patch) { if constexpr (APW == 6) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); }
-            else if (left >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else if (left == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else if constexpr (tap == 1) {
             // the previous step (tap 0) issued the next chunk's patch (APW pieces) and one weight slice (2)
             if (cc + 1 < ncc) { if constexpr (APW == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); }
@@ -245,15 +225,14 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         auto issue_dma = [&]() {
             if constexpr (ABL != 2) {
                 if constexpr (tap == 0) { if (cc + 1 < ncc) issue_a(par ^ 1, cc + 1); }
-                if constexpr (BDIST == 3) { if (s + 3 < nsteps) issue_b((st + 3) & 3); }
-                else if (s + 2 < nsteps) issue_b((tap + 2) % NB);
+                if (s + 2 < nsteps) issue_b((tap + 2) % NB);
             }
         };
         if constexpr (!LATE) issue_dma();
         if constexpr (ABL == 3) return;
 
         const unsigned char* As = lds + par * A_BYTES;
-        const unsigned char* Bs = lds + B_OFF + st * B_BYTES;
+        const unsigned char* Bs = lds + B_OFF + (tap % NB) * B_BYTES;
         if constexpr (F8) {
             typedef int i32x4_t __attribute__((ext_vector_type(4)));
             // the scale operands are VGPRs written by VALU moves: set them up in front of the fragment reads (the asm MFMAs that read them
