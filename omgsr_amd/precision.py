@@ -86,7 +86,13 @@ import os as _os
 _TRIM = int(_os.environ.get("OMGSR_POLICY_TRIM", "1"))
 _VAE_SINGLE = (r"decoder\.(mid_block|up_blocks\.[0123])\.resnets\.\d+\.conv[12]$" if _TRIM >= 2 else
                r"decoder\.up_blocks\.[123]\.resnets\.\d+\.conv[12]$")
-VAE_ACT = [r"^(?!" + _VAE_SINGLE + r"|.*attentions\.)"]
+# Round 4, 40 weight x 2 input draws (profiles/r04_robustness_40x2.log): 78 of 80 at 2.9e-4 ... 6.0e-4, one at 8.1e-4, one at 1.26e-3 - under this
+# policy AND under round 3's. The emulator on the 1.26e-3 draw (--test-draw 16,0: 1.51e-3 emulated, 228 units): all of it is the single-term
+# OPERAND of the VAE's mid-block attention projections (228 -> 44 with that operand split and nothing else changed; decoder resnets: no change).
+# On the reference draw the same operand costs 0.2-0.5 units: a 4096-key softmax over one 512-wide head amplifies the rounding of q and k by
+# the magnitude of that draw's logits. Eight tiny GEMMs (+0.5 ms per S-1024 step at three K segments): split. OMGSR_POLICY_VAE_ATTN=0 = before.
+_VAE_ATTN_SINGLE = _os.environ.get("OMGSR_POLICY_VAE_ATTN", "1") == "0"
+VAE_ACT = [r"^(?!" + _VAE_SINGLE + (r"|.*attentions\." if _VAE_ATTN_SINGLE else "") + r")"]
 VAE_W = [r"^(?!" + _VAE_SINGLE + r")"]
 _L32 = r"^(down_blocks\.1|up_blocks\.2)\."
 _L16 = r"^(down_blocks\.2|up_blocks\.1)\."

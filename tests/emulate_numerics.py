@@ -52,7 +52,11 @@ class Scheme:
     def _q(x, dt):
         return x if dt is None else x.to(dt).float()
 
+    attn_exact = ()          # stages whose attention internals (q, k, v, P roundings) are kept exact: --attn-exact enc,dec
+
     def op(self, x, kind="conv", sub="", mod=None):
+        if kind == "attn" and self.stage in self.attn_exact:
+            return x
         if self.names is not None and kind != "attn":
             if mod is None:
                 if kind != "lat":
@@ -155,8 +159,15 @@ def unet(S: Scheme, u, sample, timestep, ehs):
 def vae_attn(S: Scheme, at, x):
     B, Cc, H, W = x.shape
     g = S.op(at.group_norm(x.view(B, Cc, H * W)), "lin", "", at.to_q).transpose(1, 2)
-    q, k, v = S.op(at.to_q(g), "attn"), S.op(at.to_k(g), "attn"), S.op(at.to_v(g), "attn")
-    p = S.op((torch.matmul(q, k.transpose(-1, -2)) * at.scale).softmax(dim=-1), "attn")
+    # --attn-exact enc:qk / dec:qk / enc:pv / dec:pv: only the q, k (or P, v) roundings of that stage's attention stay exact
+    qk_exact, pv_exact = (S.stage + ":qk") in S.attn_exact, (S.stage + ":pv") in S.attn_exact
+    q, k = at.to_q(g), at.to_k(g)
+    if not qk_exact:
+        q, k = S.op(q, "attn"), S.op(k, "attn")
+    v = at.to_v(g) if pv_exact else S.op(at.to_v(g), "attn")
+    p = (torch.matmul(q, k.transpose(-1, -2)) * at.scale).softmax(dim=-1)
+    if not pv_exact:
+        p = S.op(p, "attn")
     o = at.to_out[0](S.op(torch.matmul(p, v), "lin", "", at.to_out[0]))
     return S.st(o.transpose(-1, -2).reshape(B, Cc, H, W) + x)
 
@@ -294,7 +305,9 @@ def main():
     ap.add_argument("--xseed", type=int, default=1234)
     ap.add_argument("--test-draw", default="", help="W,X: the weights / input / prompt / noise of weight draw W, input draw X of "
                                                     "tests/test_fullsize_parity_gpu.py::test_accurate_tier_full_mantissa_weights_over_seeds")
+    ap.add_argument("--attn-exact", default="", help="comma list of stages (enc, unet, dec) whose attention internals stay exact")
     a = ap.parse_args()
+    Scheme.attn_exact = tuple(v for v in a.attn_exact.split(",") if v)
     torch.set_num_threads(a.threads)
     if a.test_draw:
         w_, x_ = (int(v) for v in a.test_draw.split(","))

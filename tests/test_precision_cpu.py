@@ -31,9 +31,9 @@ def test_shipped_policy_assignment_on_sd21_shapes():
     P.apply_default_policy(vae=v, unet=u)
     fv, fu = _forms(v), _forms(u)
     # VAE: 30 resnet convs + 3 upsampling convs + (round 4) the 4 1x1 shortcut convs in the mixed-precision form, the decoder's 18 resnet
-    # convs above 64 px single, the 8 attention linears weight-split only, everything else (samplers, conv_in / out, quant convs) split
-    # on both sides
-    assert fv == {(3, 2): 37, (1, 1): 18, (1, 2): 8, (2, 2): 9}
+    # convs above 64 px single, everything else (samplers, conv_in / out, quant convs and - since the 40 x 2-draw sweep of round 4 - the 8
+    # mid-block attention linears) split on both sides
+    assert fv == {(3, 2): 37, (1, 1): 18, (2, 2): 17}
     mx = [n for n, m in v.named_modules() if getattr(m, "op_split", 0) == 3]
     assert all(("resnets" in n or "upsamplers" in n) for n in mx) and not any(("decoder.up_blocks.1.resnets" in n and "shortcut" not in n) for n in mx)
     # UNet convs: the 64 x 64 and 32 x 32 resnet convs + the three upsampling convs + every 1x1 shortcut in the mixed-precision form; 16 x 16 resnets and
