@@ -130,15 +130,21 @@ class VaeAttention(nn.Module):
         L = H * W
         x = residual
         g = g.reshape(N, L, Cg)
-        q = self.to_q.nhwc(g, out_dtype=ops.OUT_BF16)
         Lp = ops._round_up(L, 128)
-        k = self.to_k.nhwc(g, out_dtype=ops.OUT_BF16)
-        if Lp != L:
+        # qk_split (accurate tier, omgsr_amd/precision.py VAE_QK_SPLIT): q and k leave their projections as two-term splits and the
+        # score GEMM runs q_hi k_hi + q_lo k_hi + q_hi k_lo - the logits of a 4096-key softmax over ONE 512-wide head are where this
+        # block's rounding is amplified (13 of the 44 units of the worst of 80 draws; tests/emulate_numerics.py --attn-exact dec:qk)
+        qk2 = ops.precise() and getattr(self, "qk_split", False)
+        q = self.to_q.nhwc(g, out_dtype=ops.OUT_BF16, out_split=2 if qk2 else 1)
+        k = self.to_k.nhwc(g, out_dtype=ops.OUT_BF16, out_split=2 if qk2 else 1)
+        if qk2:
+            k = ops.split_rows_hhl(k, Lp)
+        elif Lp != L:
             kp = torch.zeros((N, Lp, Cc), device=x.device, dtype=ops.act_dtype())
             kp[:, :L] = k
             k = kp
         vt = ops.linear_t(g, self.to_v.packed(), L, ld=Lp)                    # [N, C, Lp], zero padded keys
-        s = ops.bmm_nt(q, k, alpha=self.scale, out_dtype=ops.OUT_F32)         # [N, L, Lp] fp32 scores
+        s = ops.bmm_nt(q, k, alpha=self.scale, out_dtype=ops.OUT_F32, both_split=qk2)         # [N, L, Lp] fp32 scores
         p = ops.softmax_rows(s, valid=L)
         del s
         o = ops.bmm_nt(p, vt, out_split=self.to_out[0].in_split())            # [N, L, C] operand of the output projection

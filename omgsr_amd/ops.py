@@ -704,20 +704,27 @@ def linear_t(x: torch.Tensor, pw: PackedWeight, rows_per_batch: int, ld: Optiona
     return out
 
 
-def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_dtype: int = OUT_BF16, out_split: int = 1) -> torch.Tensor:
+def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_dtype: int = OUT_BF16, out_split: int = 1,
+           both_split: bool = False) -> torch.Tensor:
     """out[b] = alpha * a[b] @ b[b]^T ; a [B, M, K], b [B, Npad, K] operands with Npad % 128 == 0, K % 32 == 0.
     Returns [B, M, Npad] (OUT_F32: fp32; OUT_BF16: a 16-bit operand, [B, M, 2*Npad] as a two-term split when out_split 2).
-    (d=512 VAE attention scores / PV product.)"""
+    (d=512 VAE attention scores / PV product.)
+    both_split: BOTH factors carry two-term splits - a = [a_hi | a_lo] ([B, M, 2C], what a GEMM epilogue writes with out_split 2) and
+    b = [b_hi | b_hi | b_lo] ([B, Npad, 3C], split_rows_hhl): the contraction runs the three segments a_hi b_hi + a_lo b_hi + a_hi b_lo,
+    the third one wrapping back to a_hi (omgsr_igemm_args.in_ld) exactly like a Linear with operand and weight splits."""
     _req(a_mat, act_dtype(), "a")
     _req(b_mat, act_dtype(), "b")
     B, M, K = a_mat.shape
     Bb, Np, Kb = b_mat.shape
-    if Bb != B or Kb != K or K % 32:
+    if both_split:
+        if Bb != B or K % 64 or Kb * 2 != K * 3:
+            raise ValueError(f"bmm_nt(both_split): incompatible shapes {tuple(a_mat.shape)} x {tuple(b_mat.shape)}")
+    elif Bb != B or Kb != K or K % 32:
         raise ValueError(f"bmm_nt: incompatible shapes {tuple(a_mat.shape)} x {tuple(b_mat.shape)}")
     if Np % 128:    # reduced test configs only (the real VAE has 512 channels / 128-padded key counts)
-        bp = torch.zeros((B, _round_up(Np, 128), K), device=b_mat.device, dtype=act_dtype())
+        bp = torch.zeros((B, _round_up(Np, 128), Kb), device=b_mat.device, dtype=act_dtype())
         bp[:, :Np] = b_mat
-        full = bmm_nt(a_mat, bp, alpha=alpha, out_dtype=out_dtype, out_split=out_split)
+        full = bmm_nt(a_mat, bp, alpha=alpha, out_dtype=out_dtype, out_split=out_split, both_split=both_split)
         Npp = bp.shape[1]
         if out_split == 2 and out_dtype == OUT_BF16:
             return torch.cat([full[:, :, :Np], full[:, :, Npp:Npp + Np]], dim=-1).contiguous()
@@ -726,17 +733,32 @@ def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_
     out = torch.empty((B, M, Np * split), device=a_mat.device, dtype=act_dtype() if out_dtype == OUT_BF16 else torch.float32)
     a = IgemmArgs()
     a.in_, a.weight, a.bias, a.gate, a.residual, a.out = a_mat.data_ptr(), b_mat.data_ptr(), None, None, None, out.data_ptr()
-    a.N, a.H, a.W, a.Cin = 1, 1, M, K
-    a.Cout, a.Cout_pad, a.K_pad = Np, Np, K
+    a.N, a.H, a.W, a.Cin = 1, 1, M, Kb
+    a.Cout, a.Cout_pad, a.K_pad = Np, Np, Kb
+    if both_split:
+        a.in_ld, a.in_split, a.w_split = K, 1, 1
+        a.overflow_flag = _ovf(a_mat.device)
     a.R, a.S, a.stride, a.pad_top, a.pad_left, a.upsample = 1, 1, 1, 0, 0, 0
     a.Ho, a.Wo = 1, M
     a.act, a.out_dtype, a.out_layout = ACT_NONE, out_dtype, LAYOUT_NHWC
     a.t_rows, a.t_ld = 0, 0
     a.out_lo_off = Np if split == 2 else 0
     a.out_ld = Np * split if split == 2 else 0
-    a.batch, a.in_bstride, a.w_bstride, a.out_bstride = B, M * K, Np * K, M * Np * split
+    a.batch, a.in_bstride, a.w_bstride, a.out_bstride = B, M * K, Np * Kb, M * Np * split
     a.alpha = alpha
     check(_lib.load().omgsr_igemm(C.byref(a), _stream()), "omgsr_igemm(bmm_nt)")
+    return out
+
+
+def split_rows_hhl(x: torch.Tensor, pad_rows: int = 0) -> torch.Tensor:
+    """[B, L, 2C] two-term split rows [hi | lo] -> [B, max(L, pad_rows), 3C] rows [hi | hi | lo] (zero rows past L): the second factor of
+    bmm_nt(both_split=True). Plain device copies (a few MB: the keys of the VAE's one-head attention)."""
+    B, L, C2 = x.shape
+    Cc = C2 // 2
+    out = (torch.zeros if pad_rows > L else torch.empty)((B, max(L, pad_rows), 3 * Cc), device=x.device, dtype=x.dtype)
+    out[:, :L, :Cc] = x[:, :, :Cc]
+    out[:, :L, Cc:2 * Cc] = x[:, :, :Cc]
+    out[:, :L, 2 * Cc:] = x[:, :, Cc:]
     return out
 
 

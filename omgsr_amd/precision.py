@@ -91,7 +91,12 @@ _VAE_SINGLE = (r"decoder\.(mid_block|up_blocks\.[0123])\.resnets\.\d+\.conv[12]$
 # OPERAND of the VAE's mid-block attention projections (228 -> 44 with that operand split and nothing else changed; decoder resnets: no change).
 # On the reference draw the same operand costs 0.2-0.5 units: a 4096-key softmax over one 512-wide head amplifies the rounding of q and k by
 # the magnitude of that draw's logits. Eight tiny GEMMs (+0.5 ms per S-1024 step at three K segments): split. OMGSR_POLICY_VAE_ATTN=0 = before.
+# What is left of that draw (44 units, 7.2e-4 measured) is the block's INTERNAL rounding: q and k of the decoder's attention 13.5, of the
+# encoder's 2.7, P and v of both 7.4 (--attn-exact dec:qk | enc:qk,dec:qk | enc,dec). The decoder's q / k therefore leave their projections as
+# two-term splits and its score GEMM runs three segments (VAE_QK_SPLIT; OMGSR_POLICY_VAE_QK=0 none, 2 = the encoder's too: A/B runs).
 _VAE_ATTN_SINGLE = _os.environ.get("OMGSR_POLICY_VAE_ATTN", "1") == "0"
+_VAE_QK = int(_os.environ.get("OMGSR_POLICY_VAE_QK", "1"))
+VAE_QK_SPLIT = [] if _VAE_QK <= 0 else ([r"^decoder\.mid_block\.attentions\.\d+$"] if _VAE_QK == 1 else [r"mid_block\.attentions\.\d+$"])
 VAE_ACT = [r"^(?!" + _VAE_SINGLE + (r"|.*attentions\." if _VAE_ATTN_SINGLE else "") + r")"]
 VAE_W = [r"^(?!" + _VAE_SINGLE + r")"]
 _L32 = r"^(down_blocks\.1|up_blocks\.2)\."
@@ -216,6 +221,18 @@ def set_inner16(model: nn.Module, patterns: Iterable[str]) -> int:
     return n
 
 
+def set_qk_split(model: nn.Module, patterns: Iterable[str]) -> int:
+    """Mark the VAE attention blocks (modules with group_norm + to_q: one head over the whole map) whose q and k leave their projections
+    as two-term splits, so the score GEMM runs q_hi k_hi + q_lo k_hi + q_hi k_lo (autoencoder_kl.VaeAttention.attend); returns how many."""
+    regs = [re.compile(p) for p in patterns]
+    n = 0
+    for name, m in model.named_modules():
+        if hasattr(m, "to_q") and hasattr(m, "group_norm"):
+            m.qk_split = any(r.search(name) for r in regs)
+            n += int(m.qk_split)
+    return n
+
+
 def policy_fingerprint(model: nn.Module) -> str:
     """Hash of the per-layer (op_split, w_split, out_inner16) assignment: constants folded under one policy (cross-attention
     K / V^T, omgsr_amd.constants) are refused under another."""
@@ -224,6 +241,8 @@ def policy_fingerprint(model: nn.Module) -> str:
     for name, m in model.named_modules():
         if isinstance(m, (Conv2d, Linear)):
             h.update(f"{name}:{m.op_split}:{m.w_split}:{int(m.out_inner16)};".encode())
+        elif getattr(m, "qk_split", False):
+            h.update(f"{name}:qk;".encode())
     return h.hexdigest()[:16]
 
 
@@ -268,6 +287,7 @@ def apply_default_policy(vae: Optional[nn.Module] = None, unet: Optional[nn.Modu
         set_weight_split(vae, VAE_W)
         set_mx(vae, VAE_MX)
         set_inner16(vae, VAE_INNER16)
+        set_qk_split(vae, VAE_QK_SPLIT)
     if unet is not None:
         import os
         set_operand_split(unet, UNET_ACT)
@@ -293,7 +313,7 @@ def resolve(policy, **models) -> None:
         if m is None:
             continue
         if policy == "all":
-            apply_policy(m, [r"."], [r"."])
+            apply_policy(m, [r"."], [r"."], qk=[r"."])
         elif isinstance(policy, dict):
             if key in policy:
                 apply_policy(m, **policy[key])
@@ -386,9 +406,12 @@ class RangeFallback:
         return out
 
 
-def apply_policy(model: nn.Module, act: Iterable[str], weight: Iterable[str] = (), inner16: Iterable[str] = ()) -> None:
+def apply_policy(model: nn.Module, act: Iterable[str], weight: Iterable[str] = (), inner16: Iterable[str] = (), qk=None) -> None:
     """An explicit policy for one model (pipelines: `precision_policy=` / the CLI's --precision_policy all): lists of regular
-    expressions over module names; [r"."] splits every layer (activation and weight to 2^-22: 3x the MFMA work)."""
+    expressions over module names; [r"."] splits every layer (activation and weight to 2^-22: 3x the MFMA work). qk: the VAE attention
+    blocks whose q / k carry splits (None leaves the marks as they are: the range-guard fallback keeps them)."""
     set_operand_split(model, list(act))
     set_weight_split(model, list(weight))
     set_inner16(model, list(inner16))
+    if qk is not None:
+        set_qk_split(model, list(qk))

@@ -34,7 +34,7 @@ class Scheme:
     """only: optional set of (stage, kind) pairs whose OPERAND roundings are kept (all others exact) - error budget runs.
     stage in {enc, unet, dec, lat}; kind in {conv, lin, attn, lat}."""
 
-    def __init__(self, operand, inner, stream, only=None, hilo=None, hilo_fn=None, names=None, act_split=None, inner16=None):
+    def __init__(self, operand, inner, stream, only=None, hilo=None, hilo_fn=None, names=None, act_split=None, inner16=None, qk=None):
         """names / act_split: name-based policy (the product's own form, omgsr_amd/precision.py): names maps id(module) ->
         (model key, qualified name), act_split maps model key -> list of regular expressions; an operand whose CONSUMER module
         matches is carried as the two-term split. Operands without a consumer module (latents) count as exact."""
@@ -43,6 +43,7 @@ class Scheme:
         self.names = names
         self.act_regs = {k: [re.compile(r) for r in v] for k, v in (act_split or {}).items()}
         self.inner_regs = {k: [re.compile(r) for r in v] for k, v in (inner16 or {}).items()}
+        self.qk_regs = {k: [re.compile(r) for r in v] for k, v in (qk or {}).items()}      # attention blocks whose q / k carry two-term splits
         self.stage = "lat"
         self.seen = set()
         self.seen4 = set()
@@ -79,6 +80,16 @@ class Scheme:
             hi = self._q(x, self.operand)
             return hi + self._q(x - hi, self.operand)
         return self._q(x, self.operand)
+
+    def qk_is_split(self, attn_mod) -> bool:
+        if self.names is None or id(attn_mod) not in self.names:
+            return False
+        model, name = self.names[id(attn_mod)]
+        return any(r.search(name) for r in self.qk_regs.get(model, ()))
+
+    def split2(self, x):
+        hi = self._q(x, self.operand)
+        return hi + self._q(x - hi, self.operand)
 
     def inn(self, x, mod=None):
         if self.names is not None:           # name-based: the PRODUCING conv's output stays 16-bit where the inner16 list says so
@@ -163,7 +174,7 @@ def vae_attn(S: Scheme, at, x):
     qk_exact, pv_exact = (S.stage + ":qk") in S.attn_exact, (S.stage + ":pv") in S.attn_exact
     q, k = at.to_q(g), at.to_k(g)
     if not qk_exact:
-        q, k = S.op(q, "attn"), S.op(k, "attn")
+        q, k = (S.split2(q), S.split2(k)) if S.qk_is_split(at) else (S.op(q, "attn"), S.op(k, "attn"))
     v = at.to_v(g) if pv_exact else S.op(at.to_v(g), "attn")
     p = (torch.matmul(q, k.transpose(-1, -2)) * at.scale).softmax(dim=-1)
     if not pv_exact:
@@ -278,7 +289,8 @@ def named_policies():
     for k in ("VAE_ACT", "UNET_ACT", "VAE_W", "UNET_W"):
         if not hasattr(Pn, k):
             return out
-    out["shipped"] = dict(act=dict(vae=Pn.VAE_ACT, unet=Pn.UNET_ACT), inner16=dict(vae=Pn.VAE_INNER16), w=dict(vae=Pn.VAE_W, unet=Pn.UNET_W))
+    out["shipped"] = dict(act=dict(vae=Pn.VAE_ACT, unet=Pn.UNET_ACT), inner16=dict(vae=Pn.VAE_INNER16), w=dict(vae=Pn.VAE_W, unet=Pn.UNET_W),
+                          qk=dict(vae=getattr(Pn, "VAE_QK_SPLIT", [])))
     return out
 
 SCHEMES = {
@@ -343,7 +355,7 @@ def main():
                 pol = pols[name]
                 v2, u2 = weights_as_packed(vae, pol["w"]["vae"]), weights_as_packed(u, pol["w"]["unet"])
                 v2.posterior_noise = eps
-                S = Scheme(torch.float16, None, None, names=names_of(v2, u2), act_split=pol["act"], inner16=pol.get("inner16"))
+                S = Scheme(torch.float16, None, None, names=names_of(v2, u2), act_split=pol["act"], inner16=pol.get("inner16"), qk=pol.get("qk"))
                 got = omgsr_s(S, v2, u2, alpha_t, x, ehs, eps, 64, 32)
                 e = rel_l2(got, ref)
                 print(f"{name:16s} rel-L2 {e:.3e}  var {e * e * 1e8:.1f}  PSNR {psnr(got, ref):.1f} dB  unnamed operands: {sorted(S.unnamed)}", flush=True)

@@ -115,8 +115,11 @@ def test_flux_full_width_vs_oracle():
 ROBUST_REL_L2 = 8e-4          # 25 % head-room under the north-star's 1e-3
 
 
-# OMGSR_ROBUST_DRAWS=<n> widens the sweep beyond the three weight draws the suite runs by default (DESIGN.md §4 records a 12-draw run)
-@pytest.mark.parametrize("wseed", list(range(int(os.environ.get("OMGSR_ROBUST_DRAWS", "3")))))
+# OMGSR_ROBUST_DRAWS=<n> widens the sweep beyond the three weight draws the suite runs by default (DESIGN.md §4 records a 40-draw run).
+# Draw 16 is the sentinel of that sweep: 1.26e-3 on its input draw 0 under the policies of rounds 3 and 4 until the VAE's mid-attention
+# operands (and the decoder's q / k) were split (omgsr_amd/precision.py), 6.2e-4 since - the worst of the 80 cases; it always runs.
+_NDRAWS = int(os.environ.get("OMGSR_ROBUST_DRAWS", "3"))
+@pytest.mark.parametrize("wseed", list(range(_NDRAWS)) + ([16] if _NDRAWS <= 16 else []))
 def test_accurate_tier_full_mantissa_weights_over_seeds(wseed):
     """OMGSR-S 128->512 at SD2.1 shapes with weights that carry FULL fp32 mantissas (nothing pre-rounded to a 16-bit-representable
     value: what a checkpoint looks like after the reference's fp32 LoRA merge, infer/omgsr_s_infer_model.py:16-23), three weight

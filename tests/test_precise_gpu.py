@@ -691,3 +691,68 @@ def test_pipeline_falls_back_to_bf16_operands_on_fp16_overflow():
     e_clip, e = rel_l2(clipped, ref), rel_l2(got, ref)
     print(f"fp16 operands clipped: rel-L2 {e_clip:.3e}; bf16-operand fallback: rel-L2 {e:.3e}")
     assert torch.isfinite(got).all() and e <= 1e-2 and e_clip > 3 * e
+
+
+@pytest.mark.parametrize("B,M,Nk,C", [(2, 200, 256, 512), (1, 1024, 1000, 512), (3, 96, 130, 128)])
+def test_bmm_nt_both_factors_split(B, M, Nk, C):
+    """Score GEMM of the VAE's one-head attention with q AND k as two-term splits (ops.bmm_nt both_split: q_hi k_hi + q_lo k_hi + q_hi k_lo,
+    the third segment wrapping back to q_hi): 2^-20-ish against fp64, where the single-term form sits at 2^-11; ragged key counts are padded
+    with zero rows by split_rows_hhl."""
+    from omgsr_amd import ops
+    q, k = torch.randn(B, M, C, generator=_g(70)) * 2, torch.randn(B, Nk, C, generator=_g(71)) * 2
+    ref = torch.einsum("bmc,bnc->bmn", q.double(), k.double()) * C ** -0.5
+    q2, k2 = ops.to_operand(q.to(DEV), 2), ops.to_operand(k.to(DEV), 2)
+    Np = ops._round_up(Nk, 128)
+    kh = ops.split_rows_hhl(k2, Np)
+    assert tuple(kh.shape) == (B, Np, 3 * C) and torch.equal(kh[:, :Nk, :C], kh[:, :Nk, C:2 * C]) and torch.equal(kh[:, :Nk, 2 * C:], k2[..., C:])
+    assert Np == Nk or (kh[:, Nk:] == 0).all()
+    s = ops.bmm_nt(q2, kh, alpha=C ** -0.5, out_dtype=ops.OUT_F32, both_split=True)
+    assert tuple(s.shape) == (B, M, Np) and s.dtype == torch.float32
+    e2 = _rel(s[..., :Nk], ref)
+    s1 = ops.bmm_nt(ops.to_operand(q.to(DEV), 1), ops.split_rows_hhl(k2, Np)[..., :C].contiguous(), alpha=C ** -0.5, out_dtype=ops.OUT_F32)
+    e1 = _rel(s1[..., :Nk], ref)
+    assert e2 < 3e-6 and e1 > 20 * e2, (e1, e2)
+    assert Np == Nk or (s[..., Nk:] == 0).all()
+
+
+def test_vae_attention_qk_split_path():
+    """VaeAttention with the policy's qk_split mark (omgsr_amd/precision.py VAE_QK_SPLIT) against the fp64 block. The logits of the marked
+    block are exact to ~2^-20 (single-term q / k: 2^-11 x the logit spread); on the block's OUTPUT that shows only when a row has several
+    comparable keys (a dominant key's own perturbation cancels in the normalisation), so the block-level bound is 'no worse, and a different
+    result', the logit-level one is the strict one."""
+    from omgsr_amd import ops, precision as P
+    from omgsr_amd.diffusers_api.autoencoder_kl import VaeAttention
+    torch.manual_seed(5)
+    C, H, W = 128, 24, 20
+    L, Lp = H * W, 512
+    a = VaeAttention(C, 32)
+    with torch.no_grad():
+        for n, p_ in a.named_parameters():
+            p_.copy_(torch.randn(p_.shape, generator=_g(80 + len(n))) * (1.7 * C ** -0.5 if ("to_q.weight" in n or "to_k.weight" in n) else C ** -0.5 if p_.dim() == 2 else 0.1))
+        a.group_norm.weight.add_(1.0)
+    x = torch.randn(1, C, H, W, generator=_g(81)) * 2
+    xd = x.double()
+    g64 = F.group_norm(xd, 32, a.group_norm.weight.double(), a.group_norm.bias.double(), 1e-6).reshape(1, C, L).transpose(1, 2)
+    q64, k64, v64 = (F.linear(g64, m.weight.double(), m.bias.double()) for m in (a.to_q, a.to_k, a.to_v))
+    s64 = q64 @ k64.transpose(1, 2) * C ** -0.5
+    want = F.linear(s64.softmax(-1) @ v64, a.to_out[0].weight.double(), a.to_out[0].bias.double()).transpose(1, 2).reshape(1, C, H, W) + xd
+    a = a.to(DEV)
+    P.apply_policy(a, [r"."], [r"."], qk=[])
+    with torch.no_grad():
+        plain = a(x.to(DEV)).float().cpu()
+        assert not a.qk_split
+        P.set_qk_split(a, [r"^$"])                     # the root module's own name is ""
+        assert a.qk_split
+        sharp = a(x.to(DEV)).float().cpu()
+        # the logits themselves, through the module's own projections
+        g = a.group_norm.nhwc(x.to(DEV).permute(0, 2, 3, 1).contiguous(), split=2).reshape(1, L, 2 * C)
+        q2, k2 = a.to_q.nhwc(g, out_dtype=ops.OUT_BF16, out_split=2), a.to_k.nhwc(g, out_dtype=ops.OUT_BF16, out_split=2)
+        s2 = ops.bmm_nt(q2, ops.split_rows_hhl(k2, Lp), alpha=a.scale, out_dtype=ops.OUT_F32, both_split=True)[..., :L]
+        q1, k1 = a.to_q.nhwc(g, out_dtype=ops.OUT_BF16), a.to_k.nhwc(g, out_dtype=ops.OUT_BF16)
+        kp = torch.zeros((1, Lp, C), device=DEV, dtype=k1.dtype); kp[:, :L] = k1
+        s1 = ops.bmm_nt(q1, kp, alpha=a.scale, out_dtype=ops.OUT_F32)[..., :L]
+    e1, e2 = _rel(s1, s64), _rel(s2, s64)
+    e_plain, e_sharp = _rel(plain - x, want - xd), _rel(sharp - x, want - xd)
+    print(f"VAE attention: logits q / k single {e1:.2e} -> split {e2:.2e}; branch output {e_plain:.2e} -> {e_sharp:.2e}")
+    assert e2 < 3e-6 and e1 > 30 * e2, (e1, e2)
+    assert not torch.equal(plain, sharp) and e_sharp <= 1.05 * e_plain and e_sharp < 4e-4, (e_plain, e_sharp)

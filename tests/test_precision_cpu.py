@@ -34,6 +34,7 @@ def test_shipped_policy_assignment_on_sd21_shapes():
     # convs above 64 px single, everything else (samplers, conv_in / out, quant convs and - since the 40 x 2-draw sweep of round 4 - the 8
     # mid-block attention linears) split on both sides
     assert fv == {(3, 2): 37, (1, 1): 18, (2, 2): 17}
+    assert [n for n, m in v.named_modules() if getattr(m, "qk_split", False)] == ["decoder.mid_block.attentions.0"]     # q / k of the decoder's attention split
     mx = [n for n, m in v.named_modules() if getattr(m, "op_split", 0) == 3]
     assert all(("resnets" in n or "upsamplers" in n) for n in mx) and not any(("decoder.up_blocks.1.resnets" in n and "shortcut" not in n) for n in mx)
     # UNet convs: the 64 x 64 and 32 x 32 resnet convs + the three upsampling convs + every 1x1 shortcut in the mixed-precision form; 16 x 16 resnets and
