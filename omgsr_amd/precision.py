@@ -58,7 +58,7 @@ VAE_INNER16 = [r"^decoder\.up_blocks\.[23]\.resnets\.\d+\.conv1$"]
 #   UNet beyond round 2's list   64 x 64 q / k / v 0.4 / 6.4   32 x 32 resnets 1.4 / 1.0, linears 3.0 / 5.0   16 x 16 resnets 0.3 / 0.2,
 #                                linears 0.9 / 1.2   8 x 8 + mid 0.1 / 0.0
 # The shipped policy splits BOTH sides of everything whose share per FLOP is not negligible and leaves out the decoder's resnet convs
-# above 64 px (6.7 units for 52 % of the decoder's FLOPs), the VAE attention operands, the UNet's 16 x 16 resnets and 8 x 8 level on
+# above 64 px (6.7 units for 52 % of the decoder's FLOPs), the VAE attention operands (until round 4's 40-draw sweep: see VAE_ACT below), the UNet's 16 x 16 resnets and 8 x 8 level on
 # the operand side and the 64 x 64 q / k / v operand (its GEMMs are HBM-bound: a split operand doubles their bytes for 0.4 units):
 # 11.1 units emulated = 3.3e-4 on the reference draw; measured over 3 weight x 2 input draws 3.4e-4 ... 4.3e-4
 # (tests/test_fullsize_parity_gpu.py).
