@@ -33,6 +33,8 @@ int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 bool igemm_gmx_ok(const omgsr_igemm_args& a);
 int igemm_gmx_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 int igemm_halo_tiles(const omgsr_igemm_args& a, bool phase = false);
+int igemm_halo_flat(const omgsr_igemm_args& a);      // pitch of the FLAT form the halo kernel would use for this problem (narrow maps), 0 = spatial tiles
+int igemm_halo_tiles_form(const omgsr_igemm_args& a, int flat);
 int igemm_halo_gn_slots(const omgsr_igemm_args& a, bool phase = false);
 }
 
@@ -310,9 +312,10 @@ bool use_halo(const omgsr_igemm_args& a_real) {
     if (mode && !strcmp(mode, "halo")) return true;
     // the halo tile is 32 pixels wide: on narrow maps (the UNet's 16 x 16 level) half of every tile would be padding
     const int padded_w = ((a.Wo + 31) / 32) * 32;
-    if (padded_w * 3 > a.Wo * 4) return false;      // > 1/3 of the columns wasted
+    if (padded_w * 3 > a.Wo * 4 && !omgsr::igemm_halo_flat(a)) return false;      // > 1/3 of the columns wasted (the FLAT form wastes 2 of W + 2)
     const int tiles = omgsr::igemm_halo_tiles(a);
-    return (tiles > a.group_tiles ? tiles : a.group_tiles) >= 192;          // group_tiles: the launch group this problem belongs to (omgsr_igemm_multi_plan)
+    const int gt = a.group_tiles < 0 ? -a.group_tiles : a.group_tiles;       // group_tiles: the launch group this problem belongs to (omgsr_igemm_multi_plan; < 0: on the FLAT form)
+    return (tiles > gt ? tiles : gt) >= 192;
 }
 
 // Nearest-2x upsampling + 3x3 conv as four 2 x 2 convolutions of the low-res map (weight_ph: phase-summed kernels), 4 / 9 of the MFMA work
@@ -329,7 +332,8 @@ bool use_halo_phase(const omgsr_igemm_args& a_real) {
     const int padded_w = ((a.W + 31) / 32) * 32;
     if (padded_w * 3 > a.W * 4) return false;
     const int tiles = omgsr::igemm_halo_tiles(a, true);
-    return (tiles > a.group_tiles ? tiles : a.group_tiles) >= 192;
+    const int gt = a.group_tiles < 0 ? -a.group_tiles : a.group_tiles;
+    return (tiles > gt ? tiles : gt) >= 192;
 }
 
 }  // namespace
@@ -454,14 +458,20 @@ Geo geo_of(const omgsr_igemm_args& a) {
 extern "C" int omgsr_igemm_multi_plan(omgsr_igemm_args* args, int32_t count) {
     if (!args || count <= 0) return OMGSR_E_BADARG;
     static const char* off = getenv("OMGSR_MULTI");           // A/B runs: "0" = every problem its own launch
-    int total = 0, total_ph = 0;
+    int total = 0, total_ph = 0, total_flat = 0;
+    bool all_flat_ok = true;
     for (int i = 0; i < count; ++i) {
         args[i].group_tiles = 0;
-        total += omgsr::igemm_halo_tiles(args[i], false);
+        total += omgsr::igemm_halo_tiles_form(args[i], 0);
         total_ph += omgsr::igemm_halo_tiles(args[i], true);
+        const int tf = omgsr::igemm_halo_tiles_form(args[i], 1);
+        all_flat_ok = all_flat_ok && tf > 0;
+        total_flat += tf > 0 ? tf : 0;
     }
     if ((off && off[0] == '0') || omgsr::g_batch_invariant) return 0;       // batch-invariant mode: every decision from one sample alone
-    for (int i = 0; i < count; ++i) args[i].group_tiles = (args[i].upsample && args[i].weight_ph) ? total_ph : total;
+    // one form per group: FLAT (group_tiles < 0) when every problem can run it and the group then needs fewer workgroup tiles
+    const bool flat = all_flat_ok && total_flat < total;
+    for (int i = 0; i < count; ++i) args[i].group_tiles = (args[i].upsample && args[i].weight_ph) ? total_ph : (flat ? -total_flat : total);
     return 0;
 }
 
@@ -496,7 +506,7 @@ extern "C" int omgsr_igemm_multi(const omgsr_igemm_args* args, int32_t count, vo
                           a.res_el == grp[0].res_el && (a.residual != nullptr) == (grp[0].residual != nullptr) &&
                           (a.gn_partial != nullptr) == (grp[0].gn_partial != nullptr) && a.gn_entries == grp[0].gn_entries && a.bias == grp[0].bias &&
                           a.gate == grp[0].gate && a.alpha == grp[0].alpha && a.upsample == grp[0].upsample && a.mx_chunks16 == grp[0].mx_chunks16 && a.out_mx == grp[0].out_mx &&
-                          ((a.Cout <= 32) == (grp[0].Cout <= 32));
+                          ((a.Cout <= 32) == (grp[0].Cout <= 32)) && ((omgsr::igemm_halo_flat(a) != 0) == (omgsr::igemm_halo_flat(grp[0]) != 0));
         if (m < 0) {                     // not a halo problem: its own launch, in order
             rc = flush();
             if (rc == 0) rc = omgsr_igemm(&args[i], stream);

@@ -23,9 +23,12 @@ OMGSR_DEVINL void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "me
 template <typename T, int WTN, int FM, int FN, bool RES32>
 OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
                                       const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
-                                      float* gn_dst, const int gn_howo, const int pxs) {
+                                      float* gn_dst, const int gn_howo, const int pxs, const int flat_base) {
     // pxs: distance in output pixels between consecutive rows of a fragment row block (1; 2 when the block is one phase of a
-    // phase-decomposed upsampling conv: its pixels land on every other column). A residual is not supported with pxs != 1.
+    // phase-decomposed upsampling conv: its pixels land on every other column). A residual is not supported with pxs == 2.
+    // pxs < 0 (halo kernel, FLAT form, fast path only): the rows of a block are consecutive positions f = mb[i] + row of the image's
+    // FLATTENED PADDED map of pitch P = -pxs (f = y P + x', x' = 0 and x' = P - 1 are the zero border columns): position f is output
+    // pixel flat_base + y (P - 2) + x' - 1 of the dense NHWC tensor, border positions are dropped (from the GroupNorm partials too).
     constexpr int EPI_LD = WTN + 4;
     static_assert(WTN == FN * 32, "wave tile width");
     const int half = lane >> 5, px = lane & 31;
@@ -58,6 +61,16 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
         }
     };
     const bool vec_ok = (p.Cout & 7) == 0 && (ldo & 7) == 0;
+    const float flat_rp = pxs < 0 ? 1.0f / (float)(-pxs) : 0.0f;
+    // output pixel of row `row` of block i, and whether it is stored
+    auto opix = [&](const int i, const int row, bool& ok) -> int {
+        if (pxs > 0) { ok = row < nvalid[i]; return mb[i] + row * pxs; }
+        const int P = -pxs, f = mb[i] + row;
+        const int y = (int)(((float)f + 0.5f) * flat_rp);         // exact: f < 2^20
+        const int x = f - y * P;
+        ok = row < nvalid[i] && x >= 1 && x <= P - 2;
+        return flat_base + f - 2 * y - 1;
+    };
 
     // a lane's output columns are the same for every row pass: fetch bias / gate ONCE (per-pass scalar
     // loads made the epilogue latency-bound: ~30 % of a 128-channel conv's time)
@@ -106,8 +119,10 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
                     const int row = ps * rows_per_pass + lrow;
 #pragma unroll
                     for (int w = 0; w < RV; ++w) dst[ps][w] = (u32x4_t){0u, 0u, 0u, 0u};
-                    if (ps < npass && row < nvalid[i] && col_ok) {
-                        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(resb + (int64_t)(mb[i] + row) * p.Cout + n_out);
+                    bool rok;
+                    const int rpix = opix(i, row, rok);
+                    if (ps < npass && rok && col_ok) {
+                        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(resb + (int64_t)rpix * p.Cout + n_out);
 #pragma unroll
                         for (int w = 0; w < RV; ++w) dst[ps][w] = src[w];
                     }
@@ -213,15 +228,17 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rf[e];
                     }
-                    if (row < nvalid[i] && col_ok) {
-                        const int64_t o = (int64_t)(mb[i] + row * pxs) * ldo + n_out;
+                    bool sok;
+                    const int spix = opix(i, row, sok);
+                    if (sok && col_ok) {
+                        const int64_t o = (int64_t)spix * ldo + n_out;
                         if (gn_on) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
                         }
                         if (p.out_mx) {          // the mixed-precision operand form of the next conv (OMGSR_EL_MX: 4 Cout bytes per pixel)
                             note8(v);
-                            store8_mx<T>(outb, (int64_t)(mb[i] + row * pxs) * 4 * p.Cout, p.Cout, n_out, v);
+                            store8_mx<T>(outb, (int64_t)spix * 4 * p.Cout, p.Cout, n_out, v);
                         } else if (osplit) {
                             u32x4_t hi, lo;
                             note8(v);
@@ -389,9 +406,9 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
 template <typename T, int WTN, int FM, int FN>
 OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
                                  const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
-                                 float* gn_dst = nullptr, const int gn_howo = 0, const int pxs = 1) {
-    if (p.res_el == OMGSR_EL_F32 && p.residual) igemm_epilogue_impl<T, WTN, FM, FN, true>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo, pxs);
-    else igemm_epilogue_impl<T, WTN, FM, FN, false>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo, pxs);
+                                 float* gn_dst = nullptr, const int gn_howo = 0, const int pxs = 1, const int flat_base = 0) {
+    if (p.res_el == OMGSR_EL_F32 && p.residual) igemm_epilogue_impl<T, WTN, FM, FN, true>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo, pxs, flat_base);
+    else igemm_epilogue_impl<T, WTN, FM, FN, false>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo, pxs, flat_base);
 }
 
 // linear-M helper for the GEMM-shaped kernels: row block i starts at m_base + 32*i
@@ -419,6 +436,8 @@ struct IgemmGeo {
     int ntm, ntn;   // tile counts
     int main_prio;  // halo-tile kernel (A/B switch OMGSR_HALO_MAINPRIO): s_setprio level of a wave while it is in its K loop (0 = off); its
                     // prologue / epilogue run at priority 0, so the co-resident workgroup's MFMA stream is not delayed by epilogue VALU / LDS traffic
+    int flat;       // halo-tile kernel, FLAT form (narrow maps, W <= 45): pitch P = W + 2 of the flattened padded map a tile walks (256 consecutive
+                    // positions per workgroup; the nine taps are the uniform shifts dy P + dx); 0 = the 8 x 32 spatial tile
     int interleave; // halo-tile kernel, phase form: 1 = the four output phases of a tile are consecutive logical blocks of ONE x-only grid
                     // (they share an XCD's L2: the low-res patch is fetched from HBM once, not four times); 0 = blockIdx.y = phase
 };

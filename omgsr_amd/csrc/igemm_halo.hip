@@ -36,12 +36,14 @@ static int prio_min_cin() {
 }
 
 int igemm_halo_launch_mx(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
+int igemm_halo_flat_launch(const omgsr_igemm_args& a, const IgemmGeo& g, hipStream_t st);       // igemm_halo_flat.hip
 int igemm_halo_launch_f16(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, bool phase, bool narrow);      // igemm_halo_f16.hip
 
 // one problem per grid, bf16 compute type (the fp16 instantiations are a translation unit of their own: hipcc compiles the files in parallel)
 int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, const bool phase) {
     if (a.mx_chunks16 > 0) return igemm_halo_launch_mx(a, g, st);
     const bool narrow = halo_geo(a, g, phase);
+    if (g.flat) return igemm_halo_flat_launch(a, g, st);
     if (omgsr::compute_dtype() == 1) return igemm_halo_launch_f16(a, g, st, phase, narrow);
     using T = bf16_t;
     static bool attr_set = false;
@@ -74,11 +76,20 @@ int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, con
 
 int igemm_halo_gn_slots(const omgsr_igemm_args& a, const bool phase) {
     if (phase) return 2 * 4 * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    if (const int P = halo_flat_pitch(a)) return 2 * ((a.Ho * P + TH * TW - 1) / (TH * TW));
     return 2 * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
 }
 int igemm_halo_tiles(const omgsr_igemm_args& a, const bool phase) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     if (phase) return a.N * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * ((logical_cols + BN - 1) / BN) * 4;
+    if (const int P = halo_flat_pitch(a)) return a.N * ((a.Ho * P + TH * TW - 1) / (TH * TW)) * ((logical_cols + BN - 1) / BN);
     return a.N * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH) * ((logical_cols + BN - 1) / BN);
+}
+int igemm_halo_flat(const omgsr_igemm_args& a) { return halo_flat_pitch(a); }
+// tiles of the problem in ONE given form (0: spatial, 1: FLAT; -1 when the FLAT form cannot run it): what omgsr_igemm_multi_plan sums over a group
+int igemm_halo_tiles_form(const omgsr_igemm_args& a, const int flat) {
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    if (flat && !halo_flat_eligible(a)) return -1;
+    return a.N * (flat ? halo_flat_tiles_per_image(a) : halo_grid_tiles_per_image(a)) * ((logical_cols + BN - 1) / BN);
 }
 }  // namespace omgsr

@@ -69,7 +69,7 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 // NARROW: Cout <= 32 (the VAE's conv_out, 128 -> 3): the four waves split the 8 tile rows (2 each) over ONE 32-column
 // fragment instead of 2 x 2 waves over 128 columns. The im2col kernels gather every input pixel nine times out of L2
 // (3.2 GB for a 1.4 MPixel x 128-channel map: 350 us, L2-bound at 70 TFLOP/s); here the patch is read once.
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false>
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, bool FLAT = false>
 OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const int tile, const int bidy) {      // tile: logical (XCD-remapped) tile index
     constexpr int WTN = NARROW ? 32 : 64, FM = NARROW ? 2 : 4, FN = NARROW ? 1 : 2, BNK = NARROW ? 32 : 128;
     using HG = HaloGeo<TAPS>;
@@ -91,6 +91,13 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
     const int trem = tm - img * per_img;
     const int ty = trem / g.tiles_x, tx = trem - ty * g.tiles_x;
     const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BNK;
+    // FLAT form (g.flat = P = W + 2, nine taps, no upsampling): the tile is 256 consecutive positions f0 .. f0 + 255 of the image's flattened
+    // padded map (f = y P + x', x' = x + 1; x' = 0 and P - 1 are zero border columns), the patch the positions f0 - P - 1 .. f0 + 256 + P:
+    // a tap (ky, kx) is the uniform shift ky P + kx inside the patch, whatever row of the image a position belongs to. A narrow map
+    // (the tiled VAE's 1/8-resolution tile images are 36-40 pixels wide) then wastes 2 of P columns instead of up to half of a 32-pixel tile.
+    // FLAT is a template parameter so that the spatial instantiations keep their compile-time fragment geometry (and their register count)
+    const int FP = (FLAT && TAPS == 9 && !NARROW) ? g.flat : 0;
+    const int f0 = trem * (TH * TW);
 
     const T* __restrict__ in = (const T*)p.in;
     // phase form: weight_ph holds the four phase-summed 2 x 2 kernels back to back, [4][Cin/32][4 taps][Cout_pad][32]
@@ -109,11 +116,17 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
         const int pr = 16 * (wave * APW + i) + lrow;
-        const int py = pr / PW, px = pr - py * PW;
+        int py = pr / PW, px = pr - py * PW;
+        bool in_patch = pr < PROWS;
+        if (FP) {               // patch position pr is flattened position f0 - P - 1 + pr = row py, padded column px of the image
+            const int fq = f0 - 1 + FP + pr;                  // + 2 P: non-negative
+            py = fq / FP - 1; px = fq - (py + 1) * FP;           // row y = py - 1, padded column x' = px: (vy, vx) below = (y, x' - 1)
+            in_patch = pr < TH * TW + 2 * FP + 2;
+        }
         // (vy, vx): coordinates in the virtual (optionally nearest-2x upsampled) input = output coordinates; phase form: the tile
         // lives on the LOW-res grid and phase (a, b) reads input rows y - 1 + a, y + a (columns likewise)
-        const int vy = y0 - 1 + (PHASE ? ph_a : 0) + py, vx = x0 - 1 + (PHASE ? ph_b : 0) + px;
-        const bool ok = (wave * APW + i) < APIECES && pr < PROWS && (unsigned)vy < (unsigned)(PHASE ? p.H : p.Ho) && (unsigned)vx < (unsigned)(PHASE ? p.W : p.Wo);
+        const int vy = (FP ? 0 : y0) - 1 + (PHASE ? ph_a : 0) + py, vx = (FP ? 0 : x0) - 1 + (PHASE ? ph_b : 0) + px;
+        const bool ok = (wave * APW + i) < APIECES && in_patch && (unsigned)vy < (unsigned)(PHASE ? p.H : p.Ho) && (unsigned)vx < (unsigned)(PHASE ? p.W : p.Wo);
         const int iy = PHASE ? vy : (vy >> p.upsample), ix = PHASE ? vx : (vx >> p.upsample);
         const int64_t pix = ((int64_t)img * p.H + iy) * p.W + ix;
         a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * ild + kc * 8)
@@ -174,12 +187,15 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
     const int bsw = (frow >> 2) & 3;
     const int boff0 = (wn * WTN) * 64 + frow * 64 + ((half) ^ bsw) * 16;
     const int boff1 = (wn * WTN) * 64 + frow * 64 + ((2 + half) ^ bsw) * 16;
-    int aoff[TAPS][FM];
+    // FLAT: consecutive row blocks of a wave are 32 patch rows apart - the swizzle term ((row >> 2) & 3) is the same for all of them and the
+    // 2 KiB between them is an immediate of the ds_read: 9 address registers instead of 36
+    constexpr int AFM = FLAT ? 1 : FM, AIMM = FLAT ? TW * 64 : 0;
+    int aoff[TAPS][AFM];
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int row = (FM * wm + i) * PW + frow + (tp / KS) * PW + (tp % KS);
+        for (int i = 0; i < AFM; ++i) {
+            const int row = FLAT ? (FM * wm + i) * TW + frow + (tp / KS) * FP + (tp % KS) : (FM * wm + i) * PW + frow + (tp / KS) * PW + (tp % KS);
             aoff[tp][i] = row * 64 + ((half ^ ((row >> 2) & 3)) << 4);
         }
 
@@ -242,8 +258,8 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
             i32x8_t a8[FM], b8[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                a8[i] = __builtin_shufflevector(*reinterpret_cast<const i32x4_t*>(As + aoff[tap][i]), *reinterpret_cast<const i32x4_t*>(As + (aoff[tap][i] ^ 32)),
-                                                0, 1, 2, 3, 4, 5, 6, 7);
+                a8[i] = __builtin_shufflevector(*reinterpret_cast<const i32x4_t*>(As + i * AIMM + aoff[tap][FLAT ? 0 : i]),
+                                                *reinterpret_cast<const i32x4_t*>(As + i * AIMM + (aoff[tap][FLAT ? 0 : i] ^ 32)), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int j = 0; j < FN; ++j)
                 b8[j] = __builtin_shufflevector(*reinterpret_cast<const i32x4_t*>(Bs + j * 32 * 64 + boff0), *reinterpret_cast<const i32x4_t*>(Bs + j * 32 * 64 + boff1),
@@ -270,8 +286,8 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         x8_t<T> af[2][FM], bf[2][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            af[0][i] = *reinterpret_cast<const x8_t<T>*>(As + aoff[tap][i]);
-            af[1][i] = *reinterpret_cast<const x8_t<T>*>(As + (aoff[tap][i] ^ 32));
+            af[0][i] = *reinterpret_cast<const x8_t<T>*>(As + i * AIMM + aoff[tap][FLAT ? 0 : i]);
+            af[1][i] = *reinterpret_cast<const x8_t<T>*>(As + i * AIMM + (aoff[tap][FLAT ? 0 : i] ^ 32));
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -336,6 +352,11 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         // phase form: low-res pixel (y, x0 + j) of phase (a, b) is output pixel (2y + a, 2 (x0 + j) + b): stride 2 along the row
         mb[i] = PHASE ? (img * p.Ho + 2 * y + ph_a) * p.Wo + 2 * x0 + ph_b : (img * p.Ho + y) * p.Wo + x0;
         nv[i] = (y < (PHASE ? p.H : p.Ho)) ? colsv : 0;
+        if (FP) {               // block i = positions f0 + 32 (FM wm + i) .. + 31; positions past the last row of the map are dropped
+            mb[i] = f0 + TW * (FM * wm + i);
+            const int left = p.Ho * FP - mb[i];
+            nv[i] = left < 0 ? 0 : (left > TW ? TW : left);
+        }
     }
     if constexpr (ABL == 1) { if (p.alpha != 12345.0f) return; }      // timing experiment: no epilogue (never true at run time)
     {
@@ -344,7 +365,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         // ... phase form: four launches' worth of slots per spatial tile, [N][tiles][2][4 phases][G][2]
         const int64_t slot = PHASE ? ((int64_t)(img * per_img + trem) * 2 + wm) * 4 + bidy : (int64_t)(img * per_img + trem) * 2 + wm;
         float* gn_dst = (p.gn_partial && !NARROW) ? p.gn_partial + slot * p.gn_entries * 2 : nullptr;
-        igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0, gn_dst, 0, PHASE ? 2 : 1);
+        igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0, gn_dst, 0, PHASE ? 2 : (FP ? -FP : 1), FP ? img * p.Ho * p.Wo : 0);
     }
 }
 
@@ -373,7 +394,7 @@ OMGSR_DEVINL bool phase_block_map(const int b, const int T, const int n8, const 
     return tile < T;
 }
 
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false>
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, bool FLAT = false>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     int tile, phase;
     // Phase form (TAPS = 4). The four phases of a tile read the SAME low-res patch and each its own phase-summed weights. Three block orders:
@@ -388,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     } else {
         tile = xcd_remap((int)blockIdx.x, g.ntm * g.ntn); phase = (int)blockIdx.y;
     }
-    halo_body<T, ABL, PRIO, NARROW, TAPS, MX>(p, g, tile, phase);
+    halo_body<T, ABL, PRIO, NARROW, TAPS, MX, FLAT>(p, g, tile, phase);
 }
 
 // Several problems that share weights and epilogue options in ONE launch (the tiled VAE runs every layer once per tile-shape group:
@@ -402,7 +423,7 @@ struct HaloMulti {
     int start[HALO_MULTI_MAX + 1];
     int count;
 };
-template <typename T, bool NARROW, int TAPS, bool MX = false>
+template <typename T, bool NARROW, int TAPS, bool MX = false, bool FLAT = false>
 __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMulti m) {
     int s = 0, tile, phase;
     if (TAPS == 4 && m.g[0].interleave) {      // x-only grid of 4 x the 8-aligned ranges; block order inside a problem's range: see igemm_halo_kernel
@@ -414,9 +435,34 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMult
         if (bid >= m.g[s].ntm * m.g[s].ntn) return;                                 // filler block of the 8-aligned range
         tile = xcd_remap(bid, m.g[s].ntm * m.g[s].ntn); phase = (int)blockIdx.y;
     }
-    halo_body<T, 0, false, NARROW, TAPS, MX>(m.p[s], m.g[s], tile, phase);
+    halo_body<T, 0, false, NARROW, TAPS, MX, FLAT>(m.p[s], m.g[s], tile, phase);
 }
 
+
+// FLAT form of the nine-tap kernel (see halo_body): pitch P = W + 2 when the map is narrow enough for the patch (256 + 2 P + 2 <= 352 positions:
+// the same 22 LDS-DMA pieces). halo_flat_eligible: what the form can run at all (the epilogue maps positions to pixels on its 16-byte-row path
+// only). halo_flat_pitch: the decision - for a problem on its own, when walking the flattened padded map takes fewer workgroup tiles than the
+// 8 x 32 spatial grid; for a problem of a launch group (omgsr_igemm_multi_plan), what the plan decided for the WHOLE group (group_tiles < 0 =
+// every problem of the group in the FLAT form: the tile-shape groups of a tiled-VAE level are 40 x 40, 40 x 32, 32 x 40, 32 x 32 - the 32-wide
+// ones gain nothing on their own, but a launch runs one form). OMGSR_HALO_FLAT=0 switches the form off (A/B runs).
+static inline int halo_flat_eligible(const omgsr_igemm_args& a) {
+    static const char* off = getenv("OMGSR_HALO_FLAT");
+    if (off && off[0] == '0') return 0;
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    const int64_t ldo = a.out_ld > 0 ? a.out_ld : a.Cout;
+    if (a.R != 3 || a.S != 3 || a.stride != 1 || a.upsample || a.Wo != a.W || a.Ho != a.H || a.Wo > 45 || a.Wo < 4 || logical_cols < 96 || (a.Cout & 7) || (ldo & 7) ||
+        a.out_layout != OMGSR_LAYOUT_NHWC || a.act == OMGSR_ACT_GEGLU) return 0;
+    return a.Wo + 2;
+}
+static inline int halo_flat_tiles_per_image(const omgsr_igemm_args& a) { return (a.Ho * (a.Wo + 2) + TH * TW - 1) / (TH * TW); }
+static inline int halo_grid_tiles_per_image(const omgsr_igemm_args& a) { return ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH); }
+static inline int halo_flat_pitch(const omgsr_igemm_args& a) {
+    const int P = halo_flat_eligible(a);
+    if (!P) return 0;
+    if (a.group_tiles < 0) return P;               // the plan put the whole launch group on the FLAT form
+    if (a.group_tiles > 0) return 0;               // ... or on the spatial form
+    return halo_flat_tiles_per_image(a) < halo_grid_tiles_per_image(a) ? P : 0;
+}
 
 // tile grid of one problem (the host side of both translation units: igemm_halo.hip launches one problem per grid, igemm_halo_multi.hip
 // several problems / the mixed-precision form)
@@ -429,6 +475,8 @@ static inline bool halo_geo(const omgsr_igemm_args& a, IgemmGeo& g, const bool p
     g.nk = a.Cin / 32;
     g.tiles_x = ((phase ? a.W : a.Wo) + TW - 1) / TW;          // phase form: tiles of the LOW-res map, four phases each
     g.tiles_y = ((phase ? a.H : a.Ho) + TH - 1) / TH;
+    g.flat = phase ? 0 : halo_flat_pitch(a);
+    if (g.flat) { g.tiles_x = (a.Ho * g.flat + TH * TW - 1) / (TH * TW); g.tiles_y = 1; }
     g.ntm = a.N * g.tiles_x * g.tiles_y;
     const bool narrow = logical_cols <= 32 && !phase;
     g.ntn = narrow ? 1 : (logical_cols + BN - 1) / BN;

@@ -20,7 +20,8 @@ static int multi_attrs() {
     return 0;
 }
 
-int igemm_halo_launch_multi_mx(const void* halo_multi, unsigned blocks, hipStream_t st);       // igemm_halo_mx.hip (HaloMulti has no linkage: same header, opaque pointer)
+int igemm_halo_launch_multi_mx(const void* halo_multi, unsigned blocks, hipStream_t st);
+int igemm_halo_flat_launch_multi(const void* halo_multi, unsigned blocks, hipStream_t st);      // igemm_halo_flat.hip       // igemm_halo_mx.hip (HaloMulti has no linkage: same header, opaque pointer)
 
 // `count` problems (<= HALO_MULTI_MAX) in one launch; all of them take the same kernel shape (the caller checks: same weights,
 // Cin / Cout, epilogue options; `phase`, narrow-ness and the mixed-precision form therefore agree). The workgroup looks its problem up
@@ -30,11 +31,12 @@ int igemm_halo_launch_multi(const omgsr_igemm_args* a, const IgemmGeo* g0, const
     HaloMulti m;
     m.count = count;
     int at = 0;
-    bool narrow = false;
+    bool narrow = false, flat = false;
     for (int i = 0; i < count; ++i) {
         m.p[i] = a[i];
         m.g[i] = g0[i];
         narrow = halo_geo(a[i], m.g[i], phase);
+        flat = flat || m.g[i].flat != 0;                 // (omgsr_igemm_multi groups problems by form: all of a launch's problems agree)
         m.start[i] = at;
         at += (m.g[i].ntm * m.g[i].ntn + 7) & ~7;
     }
@@ -42,6 +44,7 @@ int igemm_halo_launch_multi(const omgsr_igemm_args* a, const IgemmGeo* g0, const
     const int rc = multi_attrs();
     if (rc != 0) return rc;
     const dim3 grid = (phase && m.g[0].interleave) ? dim3(4 * at) : dim3(at, phase ? 4 : 1, 1);
+    if (flat) return igemm_halo_flat_launch_multi(&m, (unsigned)at, st);
     if (a[0].mx_chunks16 > 0) return igemm_halo_launch_multi_mx(&m, (unsigned)at, st);
     if (phase) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_multi_kernel<T, false, 4>), grid, dim3(256), LDS_BYTES, st, m));
     else if (narrow) OMGSR_DISPATCH_T(hipLaunchKernelGGL((igemm_halo_multi_kernel<T, true, 9>), grid, dim3(256), LDS_BYTES, st, m));

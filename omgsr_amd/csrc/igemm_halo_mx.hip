@@ -24,8 +24,10 @@ int igemm_halo_launch_multi_mx(const void* halo_multi, unsigned blocks, hipStrea
     else hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, true>), dim3(blocks), dim3(256), LDS_BYTES, st, m);
     return (int)hipGetLastError();
 }
+int igemm_halo_flat_launch(const omgsr_igemm_args& a, const IgemmGeo& g, hipStream_t st);       // igemm_halo_flat.hip
 int igemm_halo_launch_mx(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     halo_geo(a, g, a.upsample != 0);
+    if (g.flat) return igemm_halo_flat_launch(a, g, st);
     const int rc = mx_attrs();
     if (rc != 0) return rc;
     if (a.upsample) hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 4, true>), g.interleave ? dim3(32 * ((g.ntm * g.ntn + 7) / 8)) : dim3(g.ntm * g.ntn, 4), dim3(256), LDS_BYTES, st, a, g);

@@ -88,6 +88,11 @@ CONV_CASES = [
     (9, 192, 256, 118, 122, 2, (1, 1, 1, 1), False, True, False, 1),   # stride 2, ragged, 33 792 rows (last tile partial)
     (144, 256, 256, 8, 8, 1, (1, 1, 1, 1), True, False, False, 0),     # nearest-2x upsampling to 16 x 16
     (40, 512, 512, 40, 40, 1, (1, 1, 1, 1), False, True, True, 0),     # 40-wide maps (tiled-VAE encoder's last level)
+    # narrow maps on the halo kernel's FLAT form (256 consecutive positions of the flattened padded map per workgroup)
+    (30, 128, 256, 38, 38, 1, (1, 1, 1, 1), False, True, True, 1),
+    (64, 128, 128, 36, 45, 1, (1, 1, 1, 1), False, False, False, 0),
+    (100, 64, 128, 20, 20, 1, (1, 1, 1, 1), False, True, True, 0),     # a 32-position run spans three image rows
+    (40, 96, 160, 37, 41, 1, (1, 1, 1, 1), False, True, False, 0),     # ragged Cout (two column tiles, the second 32 wide)
 ]
 
 
@@ -514,7 +519,7 @@ def test_tile_stitch_ops():
 
 
 @pytest.mark.parametrize("N,C,Cout,H,W,res", [(2, 128, 128, 128, 192, False), (2, 256, 256, 80, 160, True), (2, 512, 512, 64, 96, True),
-                                               (2, 128, 256, 86, 150, False)])      # >= 192 halo tiles each
+                                               (2, 128, 256, 86, 150, False), (40, 128, 256, 38, 40, True)])      # >= 192 halo tiles each; the last on the FLAT form
 def test_conv_fused_groupnorm_statistics(N, C, Cout, H, W, res):
     """omgsr_igemm's gn_partial: the conv epilogue emits the (sum, sum of squares) of what it stores; GroupNorm of
     the result must equal F.group_norm of the conv output, and must not launch the statistics read pass."""
