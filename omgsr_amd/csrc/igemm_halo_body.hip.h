@@ -35,10 +35,12 @@ constexpr int TH = 8, TW = 32;
 // Geometry of the two tap sets. 3 x 3: patch (8+2) x (32+2) = 340 pixels = 22 1-KiB DMA pieces (16 patch rows each), every wave
 // issues 6 so the vmcnt arithmetic is uniform (pieces 22, 23 copy the zero page to a dummy KiB), weight ring 3 deep (9 % 3 == 0:
 // stage = tap % 3). 2 x 2 (phase-decomposed upsampling): patch 9 x 33 = 297 pixels = 19 pieces, 5 per wave, ring 4 deep (stage = tap).
-template <int TAPS> struct HaloGeo {
+// BIG (FLAT form only): a 27-piece patch (432 rows) for maps up to 80 pixels wide - 2 x 27 KB + 2 KB + 24 KB = exactly the 80 KB that still let two
+// workgroups share a CU
+template <int TAPS, bool BIG = false> struct HaloGeo {
     static constexpr int KS = TAPS == 9 ? 3 : 2;
     static constexpr int PW = TW + KS - 1, PH = TH + KS - 1, PROWS = PH * PW;
-    static constexpr int APIECES = (PROWS + 15) / 16, APW = (APIECES + 3) / 4;
+    static constexpr int APIECES = BIG ? 27 : (PROWS + 15) / 16, APW = (APIECES + 3) / 4;
     static constexpr int A_BYTES = APIECES * 1024;
     static constexpr int NB = TAPS == 9 ? 3 : 4;
     static constexpr int DUMMY_OFF = 2 * A_BYTES, B_OFF = DUMMY_OFF + 2048;
@@ -47,6 +49,8 @@ template <int TAPS> struct HaloGeo {
 constexpr int BN = 128, B_BYTES = BN * 64, BPW = 2;       // BN / B_BYTES: the wide shape; the narrow one uses 2 KB of each stage
 constexpr int LDS_BYTES = HaloGeo<9>::LDS_BYTES > HaloGeo<4>::LDS_BYTES ? HaloGeo<9>::LDS_BYTES : HaloGeo<4>::LDS_BYTES;   // <= 72 KB: two workgroups per CU
 static_assert(HaloGeo<9>::APIECES == 22 && HaloGeo<9>::APW == 6 && HaloGeo<4>::APIECES == 19 && HaloGeo<4>::APW == 5, "piece counts");
+constexpr int LDS_BYTES_BIG = HaloGeo<9, true>::LDS_BYTES;
+static_assert(HaloGeo<9, true>::APW == 7 && LDS_BYTES_BIG == 81920, "big FLAT patch: two workgroups per CU");
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_h[4] = {0u, 0u, 0u, 0u};
 
@@ -69,10 +73,10 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 // NARROW: Cout <= 32 (the VAE's conv_out, 128 -> 3): the four waves split the 8 tile rows (2 each) over ONE 32-column
 // fragment instead of 2 x 2 waves over 128 columns. The im2col kernels gather every input pixel nine times out of L2
 // (3.2 GB for a 1.4 MPixel x 128-channel map: 350 us, L2-bound at 70 TFLOP/s); here the patch is read once.
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, bool FLAT = false>
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, int FLAT = 0>      // FLAT: 0 spatial tiles, 1 FLAT form, 2 FLAT form with the 27-piece patch
 OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const int tile, const int bidy) {      // tile: logical (XCD-remapped) tile index
     constexpr int WTN = NARROW ? 32 : 64, FM = NARROW ? 2 : 4, FN = NARROW ? 1 : 2, BNK = NARROW ? 32 : 128;
-    using HG = HaloGeo<TAPS>;
+    using HG = HaloGeo<TAPS, FLAT == 2>;
     constexpr int KS = HG::KS, PW = HG::PW, PROWS = HG::PROWS, APIECES = HG::APIECES, APW = HG::APW, A_BYTES = HG::A_BYTES;
     constexpr int NB = HG::NB, DUMMY_OFF = HG::DUMMY_OFF, B_OFF = HG::B_OFF;
     constexpr bool PHASE = TAPS == 4;
@@ -223,7 +227,11 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         if constexpr (ABL == 2) {
         } else if constexpr (tap == 1) {
             // the previous step (tap 0) issued the next chunk's patch (APW pieces) and one weight slice (2)
-            if (cc + 1 < ncc) { if constexpr (APW == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); }
+            if (cc + 1 < ncc) {
+                if constexpr (APW == 7) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+                else if constexpr (APW == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+            }
             else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         } else if constexpr (tap == TAPS - 1) {
             if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
@@ -394,7 +402,7 @@ OMGSR_DEVINL bool phase_block_map(const int b, const int T, const int n8, const 
     return tile < T;
 }
 
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, bool FLAT = false>
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, int FLAT = 0>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     int tile, phase;
     // Phase form (TAPS = 4). The four phases of a tile read the SAME low-res patch and each its own phase-summed weights. Three block orders:
@@ -423,7 +431,7 @@ struct HaloMulti {
     int start[HALO_MULTI_MAX + 1];
     int count;
 };
-template <typename T, bool NARROW, int TAPS, bool MX = false, bool FLAT = false>
+template <typename T, bool NARROW, int TAPS, bool MX = false, int FLAT = 0>
 __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMulti m) {
     int s = 0, tile, phase;
     if (TAPS == 4 && m.g[0].interleave) {      // x-only grid of 4 x the 8-aligned ranges; block order inside a problem's range: see igemm_halo_kernel
@@ -448,9 +456,11 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMult
 static inline int halo_flat_eligible(const omgsr_igemm_args& a) {
     static const char* off = getenv("OMGSR_HALO_FLAT");
     if (off && off[0] == '0') return 0;
+    static const char* mw = getenv("OMGSR_HALO_FLAT_MAXW");        // A/B runs: 45 = only the 22-piece patch
+    static const int maxw = mw ? atoi(mw) : 80;                   // 256 + 2 (W + 2) + 2 <= 432 patch rows (27 pieces)
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     const int64_t ldo = a.out_ld > 0 ? a.out_ld : a.Cout;
-    if (a.R != 3 || a.S != 3 || a.stride != 1 || a.upsample || a.Wo != a.W || a.Ho != a.H || a.Wo > 45 || a.Wo < 4 || logical_cols < 96 || (a.Cout & 7) || (ldo & 7) ||
+    if (a.R != 3 || a.S != 3 || a.stride != 1 || a.upsample || a.Wo != a.W || a.Ho != a.H || a.Wo > maxw || a.Wo < 4 || logical_cols < 96 || (a.Cout & 7) || (ldo & 7) ||
         a.out_layout != OMGSR_LAYOUT_NHWC || a.act == OMGSR_ACT_GEGLU) return 0;
     return a.Wo + 2;
 }
@@ -482,10 +492,10 @@ static inline bool halo_geo(const omgsr_igemm_args& a, IgemmGeo& g, const bool p
     g.ntn = narrow ? 1 : (logical_cols + BN - 1) / BN;
     return narrow;
 }
-static inline int halo_set_lds_attr(const void* const* fns, const int n) {
+static inline int halo_set_lds_attr(const void* const* fns, const int n, const int bytes = LDS_BYTES) {
     hipError_t e = hipSuccess;
     for (int i = 0; i < n; ++i)
-        if (e == hipSuccess) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     return (int)e;
 }
 

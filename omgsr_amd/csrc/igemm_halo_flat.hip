@@ -13,7 +13,16 @@ static int flat_attrs() {
                              reinterpret_cast<const void*>(igemm_halo_multi_kernel<bf16_t, false, 9, false, true>),
                              reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 9, false, true>),
                              reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 9, true, true>)};
-        const int rc = halo_set_lds_attr(fns, 6);
+        int rc = halo_set_lds_attr(fns, 6);
+        if (rc != 0) return rc;
+        // ... and with the 27-piece patch (maps 46-80 pixels wide: pitch > 47)
+        const void* big[] = {reinterpret_cast<const void*>(igemm_halo_kernel<bf16_t, 0, false, false, 9, false, 2>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, false, 9, false, 2>),
+                             reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, false, 9, true, 2>),
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<bf16_t, false, 9, false, 2>),
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 9, false, 2>),
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 9, true, 2>)};
+        rc = halo_set_lds_attr(big, 6, LDS_BYTES_BIG);
         if (rc != 0) return rc;
         attr_set = true;
     }
@@ -24,6 +33,12 @@ int igemm_halo_flat_launch(const omgsr_igemm_args& a, const IgemmGeo& g, hipStre
     const int rc = flat_attrs();
     if (rc != 0) return rc;
     const dim3 grid(g.ntm * g.ntn);
+    if (g.flat > 47) {          // 256 + 2 P + 2 patch rows > 352: the 27-piece patch
+        if (a.mx_chunks16 > 0) hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 9, true, 2>), grid, dim3(256), LDS_BYTES_BIG, st, a, g);
+        else if (omgsr::compute_dtype() == 1) hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 9, false, 2>), grid, dim3(256), LDS_BYTES_BIG, st, a, g);
+        else hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 0, false, false, 9, false, 2>), grid, dim3(256), LDS_BYTES_BIG, st, a, g);
+        return (int)hipGetLastError();
+    }
     if (a.mx_chunks16 > 0) hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 9, true, true>), grid, dim3(256), LDS_BYTES, st, a, g);
     else if (omgsr::compute_dtype() == 1) hipLaunchKernelGGL((igemm_halo_kernel<f16_t, 0, false, false, 9, false, true>), grid, dim3(256), LDS_BYTES, st, a, g);
     else hipLaunchKernelGGL((igemm_halo_kernel<bf16_t, 0, false, false, 9, false, true>), grid, dim3(256), LDS_BYTES, st, a, g);
@@ -34,6 +49,14 @@ int igemm_halo_flat_launch_multi(const void* halo_multi, unsigned blocks, hipStr
     const HaloMulti& m = *reinterpret_cast<const HaloMulti*>(halo_multi);
     const int rc = flat_attrs();
     if (rc != 0) return rc;
+    bool big = false;
+    for (int i = 0; i < m.count; ++i) big = big || m.g[i].flat > 47;         // one kernel per launch: the 27-piece patch serves the narrower problems too
+    if (big) {
+        if (m.p[0].mx_chunks16 > 0) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, true, 2>), dim3(blocks), dim3(256), LDS_BYTES_BIG, st, m);
+        else if (omgsr::compute_dtype() == 1) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, false, 2>), dim3(blocks), dim3(256), LDS_BYTES_BIG, st, m);
+        else hipLaunchKernelGGL((igemm_halo_multi_kernel<bf16_t, false, 9, false, 2>), dim3(blocks), dim3(256), LDS_BYTES_BIG, st, m);
+        return (int)hipGetLastError();
+    }
     if (m.p[0].mx_chunks16 > 0) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, true, true>), dim3(blocks), dim3(256), LDS_BYTES, st, m);
     else if (omgsr::compute_dtype() == 1) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, false, true>), dim3(blocks), dim3(256), LDS_BYTES, st, m);
     else hipLaunchKernelGGL((igemm_halo_multi_kernel<bf16_t, false, 9, false, true>), dim3(blocks), dim3(256), LDS_BYTES, st, m);

@@ -55,10 +55,10 @@ def test_the_tight_kernels_are_where_design_says(tables):
         if k.startswith(("igemm_halo", "igemm_dma", "igemm_p8", "igemm_gmx", "attn_kernel")):
             assert b["occupancy"] >= 2, (k, b)
     # template arguments end with (TAPS, MX, FLAT): nine-tap MX instantiations, spatial and FLAT form
-    mx = [b for k, b in built.items() if k.startswith("igemm_halo") and (k.endswith(",9,1,0>") or k.endswith(",9,1,1>"))]
-    assert len(mx) == 4 and all(b["spill_vgpr"] <= 16 and b["scratch"] <= 64 for b in mx), mx
-    flat = [b for k, b in built.items() if k.startswith("igemm_halo") and k.endswith(",1>")]         # the FLAT form: 9 fragment-address registers instead of 36
-    assert len(flat) == 6 and all(b["spill_vgpr"] <= 4 for b in flat), flat
+    mx = [b for k, b in built.items() if k.startswith("igemm_halo") and (k.endswith(",9,1,0>") or k.endswith(",9,1,1>") or k.endswith(",9,1,2>"))]
+    assert len(mx) == 6 and all(b["spill_vgpr"] <= 16 and b["scratch"] <= 64 for b in mx), mx
+    flat = [b for k, b in built.items() if k.startswith("igemm_halo") and (k.endswith(",1>") or k.endswith(",2>"))]    # the FLAT form (22- and 27-piece patch): 9 fragment-address registers instead of 36
+    assert len(flat) == 12 and all(b["spill_vgpr"] <= 4 for b in flat), flat
     for k, b in built.items():
-        if k.startswith("igemm_halo") and not k.endswith(",9,1,0>") and not k.endswith(",1>") and ",0,1,0,9,0,0>" not in k:      # (the s_setprio A/B instantiation spills 8)
+        if k.startswith("igemm_halo") and not k.endswith(",9,1,0>") and not k.endswith(",1>") and not k.endswith(",2>") and ",0,1,0,9,0,0>" not in k:      # (the s_setprio A/B instantiation spills 8)
             assert b["spill_vgpr"] == 0, (k, b)

@@ -93,6 +93,10 @@ CONV_CASES = [
     (64, 128, 128, 36, 45, 1, (1, 1, 1, 1), False, False, False, 0),
     (100, 64, 128, 20, 20, 1, (1, 1, 1, 1), False, True, True, 0),     # a 32-position run spans three image rows
     (40, 96, 160, 37, 41, 1, (1, 1, 1, 1), False, True, False, 0),     # ragged Cout (two column tiles, the second 32 wide)
+    # ... with the 27-piece patch (maps 46-80 pixels wide)
+    (16, 128, 256, 75, 75, 1, (1, 1, 1, 1), False, True, True, 1),
+    (8, 128, 128, 64, 80, 1, (1, 1, 1, 1), False, False, False, 0),
+    (12, 64, 128, 50, 46, 1, (1, 1, 1, 1), False, True, True, 0),
 ]
 
 
@@ -519,7 +523,7 @@ def test_tile_stitch_ops():
 
 
 @pytest.mark.parametrize("N,C,Cout,H,W,res", [(2, 128, 128, 128, 192, False), (2, 256, 256, 80, 160, True), (2, 512, 512, 64, 96, True),
-                                               (2, 128, 256, 86, 150, False), (40, 128, 256, 38, 40, True)])      # >= 192 halo tiles each; the last on the FLAT form
+                                               (2, 128, 256, 86, 150, False), (40, 128, 256, 38, 40, True), (16, 128, 256, 75, 72, True)])      # >= 192 halo tiles each; the last on the FLAT form
 def test_conv_fused_groupnorm_statistics(N, C, Cout, H, W, res):
     """omgsr_igemm's gn_partial: the conv epilogue emits the (sum, sum of squares) of what it stores; GroupNorm of
     the result must equal F.group_norm of the conv output, and must not launch the statistics read pass."""

@@ -179,7 +179,7 @@ def test_group_norm_mx_operand(C, G, HW):
 
 
 # N, H, W, C, Cout: halo-tile kernel with fp16 + block-scaled fp8 chunks; small and ragged maps included (MX problems always take it)
-_MX_CASES = [(2, 64, 64, 128, 128), (1, 64, 96, 320, 320), (2, 16, 16, 1280, 640), (1, 40, 43, 512, 512), (1, 32, 32, 960, 640), (1, 9, 33, 64, 128), (4, 38, 38, 256, 256)]
+_MX_CASES = [(2, 64, 64, 128, 128), (1, 64, 96, 320, 320), (2, 16, 16, 1280, 640), (1, 40, 43, 512, 512), (1, 32, 32, 960, 640), (1, 9, 33, 64, 128), (4, 38, 38, 256, 256), (4, 75, 75, 256, 512)]
 
 
 @pytest.mark.parametrize("N,H,W,C,Cout", _MX_CASES)
