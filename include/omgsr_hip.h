@@ -145,7 +145,9 @@ typedef struct omgsr_igemm_args {
                               kernel choice and the GroupNorm-statistics layout use max(own tiles, group_tiles) */
     uint32_t* overflow_flag; /* optional (fp16 compute type only): a device word the epilogue ORs 1 into when a value it writes as a 16-bit
                               output lies beyond +-65504 (the stores saturate there). The accurate tier's range guard: the pipelines
-                              check it once per call, at the sync the reference's forward() already has | NULL */
+                              check it once per call, at the sync the reference's forward() already has | NULL.
+                              Bit 1 (value 2, diagnostic only): a value beyond +-448 was written into an OMGSR_EL_MX output - its fp8 correction
+                              fields saturate (fixed scales), that element keeps single-rounding fp16 accuracy */
 } omgsr_igemm_args;
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
 /* The problems of ONE layer that differ only in tensors and spatial extents (the tiled VAE runs every layer once per tile-shape group:

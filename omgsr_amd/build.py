@@ -75,9 +75,15 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         remarks = [ln for ln in r.stderr.splitlines() if "remark:" in ln]
         # (each remark is followed by a source excerpt and a caret line; "In file included from" lines precede remarks in headers)
         rest, lines = [], r.stderr.splitlines()
+        in_remark = False           # the source excerpt / caret lines that FOLLOW a remark are dropped with it; those of warnings and errors stay
         for i, ln in enumerate(lines):
-            if "remark:" in ln or not ln.strip() or re.match(r"^\s*\d*\s*\|", ln):
+            if "remark:" in ln:
+                in_remark = True
                 continue
+            is_excerpt = bool(re.match(r"^\s*\d*\s*\|", ln)) or not ln.strip()
+            if in_remark and is_excerpt:
+                continue
+            in_remark = False
             if ln.startswith("In file included from") and i + 1 < len(lines) and ("remark:" in lines[i + 1] or lines[i + 1].startswith("In file included")):
                 continue
             if re.match(r"^\d+ (warning|remark)s? generated", ln):
@@ -160,7 +166,10 @@ def kernel_resources() -> dict:
             elif cur is not None and k in keys:
                 cur[keys[k]] = int(v)
     for m, rec in mangled:
-        out[_short_name(m)] = rec
+        k = _short_name(m)
+        if "?" in k or k in out:            # an undecoded template argument / two instantiations under one short name: key on the mangled name
+            k = m
+        out[k] = rec
     return out
 
 

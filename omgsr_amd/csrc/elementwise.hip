@@ -82,6 +82,7 @@ __global__ void to_operand_kernel(const float* __restrict__ x, void* __restrict_
     }
     if constexpr (std::is_same<T, f16_t>::value) {           // fp16 range guard (see omgsr_igemm_args.overflow_flag)
         if (ovf && __any(amax > 65504.0f) && (threadIdx.x & 63) == 0) atomicOr(ovf, 1u);
+        if (YEL == 3 && ovf && __any(amax > 448.0f) && (threadIdx.x & 63) == 0) atomicOr(ovf, 2u);      // MX: correction fields saturated (diagnostic bit)
     }
 }
 

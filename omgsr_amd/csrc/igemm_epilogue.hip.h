@@ -58,6 +58,10 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
     auto flush_ovf = [&]() {
         if constexpr (OVF_CHK) {
             if (p.overflow_flag && p.out_dtype == OMGSR_OUT_BF16 && __any(amax > 65504.0f) && lane == 0) atomicOr(p.overflow_flag, 1u);
+            // MX output: the fp8 correction fields use fixed scales and clamp at +-448 (store8_mx), so an element beyond that keeps only its
+            // fp16 main term (single-rounding accuracy, nothing becomes NaN). Bit 1 of the same word counts as a DIAGNOSTIC, not an error:
+            // ops.mx_saturation_seen() (real SD2.1 feed-forward / attention activations reach the hundreds; seeded weights never do)
+            if (p.overflow_flag && p.out_mx && __any(amax > 448.0f) && lane == 0) atomicOr(p.overflow_flag, 2u);
         }
     };
     const bool vec_ok = (p.Cout & 7) == 0 && (ldo & 7) == 0;

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
     }
     if constexpr (Y2EL >= 0 && std::is_same<T, f16_t>::value) {
         if (ovf && __any(amax > 65504.0f) && (t & 63) == 0) atomicOr(ovf, 1u);
+        if (Y2EL == 3 && ovf && __any(amax > 448.0f) && (t & 63) == 0) atomicOr(ovf, 2u);     // MX twin: correction fields saturated (diagnostic bit)
     }
 }
 

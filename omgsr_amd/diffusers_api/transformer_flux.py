@@ -30,7 +30,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..nn import InputCache, LayerNorm, Linear, RMSNormWeight, _key
+from ..nn import InputCache, LayerNorm, Linear, RMSNormWeight, _key, bump_cache_epoch
 from .modeling_utils import ConfigDict, ModelMixin
 from .unet_2d_condition import TimestepEmbedding, timestep_sinusoid
 
@@ -44,6 +44,7 @@ class _Cached:
         k = _key(*tensors)
         slot = self.__dict__.setdefault("_pk_cache", {})
         if name not in slot or slot[name][0] != k:
+            bump_cache_epoch()
             slot[name] = (k, builder())
         return slot[name][1]
 

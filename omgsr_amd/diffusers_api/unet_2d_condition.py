@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..nn import Conv2d, GroupNorm, InputCache, LayerNorm, Linear, _key
+from ..nn import Conv2d, GroupNorm, InputCache, LayerNorm, Linear, _key, bump_cache_epoch
 from .autoencoder_kl import Downsample2D, ResnetBlock2D, Upsample2D
 from .modeling_utils import ConfigDict, ModelMixin
 
@@ -129,6 +129,7 @@ class GEGLU(nn.Module):
         sp, wsp = self.proj.in_split(), self.proj.in_wsplit()
         k = _key(self.proj.weight, self.proj.bias, sp, wsp)
         if getattr(self, "_pk_key", None) != k:
+            bump_cache_epoch()
             self._pk, self._pk_key = ops.pack_geglu_weight(self.proj.weight, self.proj.bias, split=sp, w_split=wsp), k
         return self._pk
 
@@ -269,6 +270,7 @@ class UNet2DConditionModel(ModelMixin):
         key = self._fold_key(timestep)
         t = key[0]
         if key not in self._temb_cache:
+            bump_cache_epoch()
             dev = self.conv_in.weight.device
             with torch.no_grad():
                 tt = torch.tensor([t], dtype=torch.int64, device=dev)

@@ -26,6 +26,22 @@ def _key(*tensors) -> tuple:
     return ops.mode_key() + tuple((t.data_ptr(), t._version, str(t.device), t.dtype, tuple(t.shape)) if torch.is_tensor(t) else t for t in tensors)
 
 
+# Every rebuild of a cached device value (packed weights, folded constants, cross-attention K / V^T, modulation / rope tables) bumps this
+# counter. A captured hipGraph bakes the ADDRESSES of those values into its launches, and the one-slot caches free the old value when they
+# rebuild: pipelines/graphed.py stamps each graph with the epoch it was captured under and drops it when any cache has rebuilt since
+# (prompt A -> prompt B -> prompt A would otherwise replay graph A against freed or re-used K / V^T memory).
+_CACHE_EPOCH = 0
+
+
+def cache_epoch() -> int:
+    return _CACHE_EPOCH
+
+
+def bump_cache_epoch() -> None:
+    global _CACHE_EPOCH
+    _CACHE_EPOCH += 1
+
+
 class InputCache:
     """One-slot cache keyed on per-call INPUT tensors (prompt embeddings, ids, pooled projections). The caching allocator
     reuses addresses, so an address is not an identity: the slot keeps a strong reference to every keyed tensor and
@@ -38,12 +54,14 @@ class InputCache:
         """Install a value computed elsewhere (omgsr_amd.constants: the serialised constant cache)."""
         self._value, self._inputs, self._wkey = value, tuple(inputs), wkey
         self._versions = tuple(None if t is None else t._version for t in inputs)
+        bump_cache_epoch()
 
     def get(self, inputs: tuple, wkey: tuple, builder):
         same = (self._inputs is not None and len(self._inputs) == len(inputs) and self._wkey == wkey and
                 all(a is b for a, b in zip(self._inputs, inputs)) and
                 self._versions == tuple(None if t is None else t._version for t in inputs))
         if not same:
+            bump_cache_epoch()
             self._value = builder()
             self._inputs, self._wkey = tuple(inputs), wkey
             self._versions = tuple(None if t is None else t._version for t in inputs)
@@ -56,6 +74,7 @@ class _Packed:
     def _packed(self, builder, *tensors):
         k = _key(*tensors)
         if getattr(self, "_pk_key", None) != k:
+            bump_cache_epoch()
             self._pk = builder()
             self._pk_key = k
         return self._pk

@@ -126,11 +126,34 @@ def overflow_seen(reset: bool = True) -> bool:
     seen = _weight_overflow
     if reset:
         _weight_overflow = False
+    global _mx_saturated
     for t in _ovf_words.values():
-        if bool(t.item()):
+        v = int(t.item())
+        if v & 2:
+            _mx_saturated = True
+        if v & 1:
             seen = True
+        if v and reset:
+            t.zero_()
+    return seen
+
+
+_mx_saturated = False
+
+
+def mx_saturation_seen(reset: bool = True) -> bool:
+    """Diagnostic: True when, since the last reset, a kernel wrote a value beyond +-448 into a mixed-precision (OMGSR_EL_MX)
+    operand. Its fp8 correction fields use fixed scales and clamp there, so that element carried single-rounding fp16 accuracy (nothing
+    becomes NaN, the fp16 main term is exact). The word is read with the range guard's (overflow_seen, at the pipelines' own sync)."""
+    global _mx_saturated
+    for t in _ovf_words.values():
+        if int(t.item()) & 2:
+            _mx_saturated = True
             if reset:
-                t.zero_()
+                t.bitwise_and_(1)
+    seen = _mx_saturated
+    if reset:
+        _mx_saturated = False
     return seen
 
 

@@ -23,18 +23,42 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 
 
+class WeightsStamp:
+    """Cheap identity of every parameter of the pipeline's models for the graph key: (owner, name, parameter) triples are cached and
+    re-walked when an owner no longer holds that object (load_state_dict(assign=True), swap_tensors-style conversion), and the stamp
+    folds each parameter's version AND storage address (`.to()` / `.data =` replace the storage without a version bump)."""
+
+    def __init__(self, *models):
+        self.models = [m for m in models if m is not None]
+        self._owners = None
+
+    def __call__(self) -> tuple:
+        own = self._owners
+        if own is None or not all(m._parameters.get(n) is p for m, n, p in own):
+            own = self._owners = [(sub, n, p) for model in self.models for sub in model.modules()
+                                  for n, p in sub._parameters.items() if p is not None]
+        v = a = 0
+        for _, _, p in own:
+            v += p._version
+            a ^= p.data_ptr()
+        return (len(own), v, a)
+
+
 class GraphCache:
     def __init__(self, max_graphs: int = 8):
         self.enabled = False
         self.max_graphs = max_graphs
         self._seen: Dict[tuple, int] = {}
-        self._graphs: Dict[tuple, Tuple[torch.cuda.CUDAGraph, list, torch.Tensor, tuple]] = {}
+        self._graphs: Dict[tuple, tuple] = {}
+        self._eager_only: set = set()       # keys whose capture failed: run eagerly from then on instead of retrying the capture per call
         self.replays = 0
         self.captures = 0
+        self.stale_drops = 0
 
     def clear(self) -> None:
         self._graphs.clear()
         self._seen.clear()
+        self._eager_only.clear()
 
     @staticmethod
     def _ident(t: Optional[torch.Tensor]):
@@ -43,19 +67,33 @@ class GraphCache:
     def call(self, key: tuple, dynamic: list, fixed: list, fn: Callable[..., torch.Tensor]) -> torch.Tensor:
         """fn(*dynamic_inputs) -> output tensor. `dynamic`: tensors whose VALUES change per call (the LQ image): copied into static
         buffers. `fixed`: tensors read by address (prompt embeddings, ids, posterior noise override): part of the key by identity and
-        version - a new tensor object, or an in-place edit, is a new graph."""
-        from .. import ops
+        version - a new tensor object, or an in-place edit, is a new graph.
+        A graph also reads, by address, device values that one-slot caches OWN (cross-attention K / V^T of the current prompt, FLUX
+        modulation / rope tables, packed weights): every cache rebuild bumps nn.cache_epoch(), each graph remembers the epoch it was
+        captured under, and a graph whose epoch is not the current one is dropped instead of replayed (prompt A -> B -> A: graph A's
+        K / V^T were freed when B's replaced them in the slot)."""
+        from .. import nn as onn, ops, precision
         if not self.enabled:
             return fn(*dynamic)
-        full = (key, ops.mode_key(), tuple((tuple(d.shape), d.dtype, str(d.device)) for d in dynamic), tuple(self._ident(t) for t in fixed))
+        # everything that selects kernels or packed-weight forms without touching a parameter: tier, precision policy, batch-invariant
+        # dispatch, the fp16 range guard (it adds the overflow word to every launch)
+        state = (ops.mode_key(), precision.policy_epoch(), ops._BATCH_INVARIANT, ops._GUARD)
+        full = (key, state, tuple((tuple(d.shape), d.dtype, str(d.device)) for d in dynamic), tuple(self._ident(t) for t in fixed))
         hit = self._graphs.get(full)
+        if hit is not None and hit[4] != onn.cache_epoch():
+            del self._graphs[full]              # some cache rebuilt since the capture: its old value (baked into the graph) may be freed
+            self._seen[full] = 0
+            self.stale_drops += 1
+            hit = None
         if hit is not None:
-            g, static_in, static_out, keep = hit
+            g, static_in, static_out, keep, _ = hit
             for s, d in zip(static_in, dynamic):
                 s.copy_(d)
             g.replay()
             self.replays += 1
             return static_out.clone()
+        if full in self._eager_only:
+            return fn(*dynamic)
         n = self._seen.get(full, 0)
         if len(self._seen) > 4096:       # keys are cheap (ints / shapes), but a service that sees ever-new prompts must not grow without bound
             self._seen.clear()
@@ -66,10 +104,24 @@ class GraphCache:
             self._graphs.pop(next(iter(self._graphs)))
         static_in = [d.clone() for d in dynamic]
         torch.cuda.synchronize()
+        epoch0 = onn.cache_epoch()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            static_out = fn(*static_in)
-        self._graphs[full] = (g, static_in, static_out, tuple(fixed))      # `fixed` kept alive: their addresses are baked into the graph
+        try:
+            with torch.cuda.graph(g):
+                static_out = fn(*static_in)
+        except Exception:
+            # a capture that throws (an op that synchronises, an allocation the graph pool refuses) must not be retried on every call
+            self._eager_only.add(full)
+            torch.cuda.synchronize()
+            return fn(*dynamic)
+        if onn.cache_epoch() != epoch0:
+            # a cache rebuilt DURING the capture: its value lives in the graph's private pool and the slot now points into it - do not
+            # keep such a graph (the eager warm-up call exists so that this never happens; if it does, stay eager for this key)
+            self._eager_only.add(full)
+            del g
+            torch.cuda.synchronize()
+            return fn(*dynamic)
+        self._graphs[full] = (g, static_in, static_out, tuple(fixed), epoch0)      # `fixed` kept alive: their addresses are baked into the graph
         self.captures += 1
         g.replay()
         self.replays += 1

@@ -71,7 +71,7 @@ class OMGSR_F_Infer(torch.nn.Module):
         if weight_dtype == torch.float32:
             from ..precision import resolve
             resolve(precision_policy, vae=self.vae, flux=self.flux_transformer)
-        self.range_fallback = RangeFallback(self.vae, self.flux_transformer)
+        self.range_fallback = RangeFallback(self.vae, self.flux_transformer, weight_dtype=weight_dtype)
         from .graphed import GraphCache          # hipGraph replay of forward()'s body: off by default, enable_graphs() / OMGSR_GRAPH=1
         self.graphs = GraphCache()
         self.graphs.enabled = os.environ.get("OMGSR_GRAPH", "0") == "1"
@@ -84,10 +84,11 @@ class OMGSR_F_Infer(torch.nn.Module):
         if not on:
             self.graphs.clear()
 
-    def _weights_stamp(self) -> int:
+    def _weights_stamp(self) -> tuple:
         if self._graph_params is None:
-            self._graph_params = list(self.vae.parameters()) + list(self.flux_transformer.parameters())
-        return sum(p._version for p in self._graph_params)
+            from .graphed import WeightsStamp
+            self._graph_params = WeightsStamp(self.vae, self.flux_transformer)
+        return self._graph_params()
 
     def _init_tiled_vae(self, encoder_tile_size=256, decoder_tile_size=256, fast_decoder=False, fast_encoder=False,
                         color_fix=False, vae_to_gpu=True):
@@ -105,6 +106,8 @@ class OMGSR_F_Infer(torch.nn.Module):
         # the same two tensors on every call (the DiT reads their value once per tensor: no per-image host synchronisation)
         key = (str(tok.device), B, float(self.t_curr), float(self.guidance_scale))
         if self.__dict__.get("_tg_key") != key:
+            from ..nn import bump_cache_epoch
+            bump_cache_epoch()          # captured hipGraphs read these two tensors by address (pipelines/graphed.py)
             self.__dict__["_tg"] = (torch.tensor([self.t_curr], device=tok.device),
                                     torch.full((B,), self.guidance_scale, device=tok.device, dtype=torch.float32))
             self.__dict__["_tg_key"] = key

@@ -53,7 +53,7 @@ class OMGSR_S_Infer(torch.nn.Module):
         if weight_dtype == torch.float32:       # which layers carry two-term split operands / weights (omgsr_amd/precision.py)
             from ..precision import resolve
             resolve(precision_policy, vae=self.vae, unet=self.unet)
-        self.range_fallback = RangeFallback(self.vae, self.unet)
+        self.range_fallback = RangeFallback(self.vae, self.unet, weight_dtype=weight_dtype)
         # hipGraph replay of forward()'s body (pipelines/graphed.py): off by default, enable_graphs() / OMGSR_GRAPH=1
         from .graphed import GraphCache
         self.graphs = GraphCache()
@@ -69,10 +69,11 @@ class OMGSR_S_Infer(torch.nn.Module):
         if not on:
             self.graphs.clear()
 
-    def _weights_stamp(self) -> int:
+    def _weights_stamp(self) -> tuple:
         if self._graph_params is None:
-            self._graph_params = list(self.vae.parameters()) + list(self.unet.parameters())
-        return sum(p._version for p in self._graph_params)
+            from .graphed import WeightsStamp
+            self._graph_params = WeightsStamp(self.vae, self.unet)
+        return self._graph_params()
 
     def _init_tiled_vae(self, encoder_tile_size=256, decoder_tile_size=256, fast_decoder=False, fast_encoder=False,
                         color_fix=False, vae_to_gpu=True):

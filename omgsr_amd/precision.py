@@ -121,10 +121,24 @@ VAE_MX = [r"^encoder\..*resnets\.\d+\.conv[12]$", r"^decoder\.(mid_block|up_bloc
 UNET_MX = [_L64 + r"resnets\.\d+\.conv[12]$", _L32 + r"resnets\.\d+\.conv[12]$", r"upsamplers\.0\.conv$", r"\.conv_shortcut$"]
 
 
+# Bumped by every setter below: captured hipGraphs (pipelines/graphed.py) key on it, so a policy edit after a capture is a new graph
+_POLICY_EPOCH = 0
+
+
+def policy_epoch() -> int:
+    return _POLICY_EPOCH
+
+
+def _touch() -> None:
+    global _POLICY_EPOCH
+    _POLICY_EPOCH += 1
+
+
 def set_operand_split(model: nn.Module, patterns: Iterable[str], split: int = 2) -> int:
     """Mark the Conv2d / Linear layers whose qualified name matches any pattern; returns how many were marked."""
     if split not in (1, 2):
         raise ValueError("split must be 1 or 2")
+    _touch()
     regs = [re.compile(p) for p in patterns]
     n = 0
     for name, m in model.named_modules():
@@ -141,6 +155,7 @@ def set_weight_split(model: nn.Module, patterns: Iterable[str], split: int = 2) 
     over the operand's hi half: +1x the layer's MFMA work, no change to any producer); returns how many were marked."""
     if split not in (1, 2):
         raise ValueError("split must be 1 or 2")
+    _touch()
     regs = [re.compile(p) for p in patterns]
     n = 0
     for name, m in model.named_modules():
@@ -167,6 +182,7 @@ def set_mx_linear(model: nn.Module, patterns: Iterable[str]) -> int:
     import os
     if os.environ.get("OMGSR_MX", "1") == "0" or os.environ.get("OMGSR_MX_LINEAR", "1") == "0":
         return 0
+    _touch()
     regs = [re.compile(p) for p in patterns]
     ok = lambda m: isinstance(m, Linear) and m.in_features % 64 == 0 and m.op_split == 2 and m.w_split == 2      # noqa: E731
     n = 0
@@ -197,6 +213,7 @@ def set_mx(model: nn.Module, patterns: Iterable[str]) -> int:
     import os
     if os.environ.get("OMGSR_MX", "1") == "0":
         return 0
+    _touch()
     regs = [re.compile(p) for p in patterns]
     n = 0
     for name, m in model.named_modules():
@@ -212,6 +229,7 @@ def set_mx(model: nn.Module, patterns: Iterable[str]) -> int:
 
 def set_inner16(model: nn.Module, patterns: Iterable[str]) -> int:
     """Mark the Conv2d layers whose output stays in the 16-bit compute type in the accurate tier; returns how many."""
+    _touch()
     regs = [re.compile(p) for p in patterns]
     n = 0
     for name, m in model.named_modules():
@@ -224,6 +242,7 @@ def set_inner16(model: nn.Module, patterns: Iterable[str]) -> int:
 def set_qk_split(model: nn.Module, patterns: Iterable[str]) -> int:
     """Mark the VAE attention blocks (modules with group_norm + to_q: one head over the whole map) whose q and k leave their projections
     as two-term splits, so the score GEMM runs q_hi k_hi + q_lo k_hi + q_hi k_lo (autoencoder_kl.VaeAttention.attend); returns how many."""
+    _touch()
     regs = [re.compile(p) for p in patterns]
     n = 0
     for name, m in model.named_modules():
@@ -341,6 +360,7 @@ def bf16_operand_fallback(*models):
         for rows in saved:
             for m, a, w, i16 in rows:
                 m.op_split, m.w_split, m.out_inner16 = a, w, i16
+        _touch()
         ops.set_compute_dtype(torch.float32)
 
 
@@ -351,8 +371,12 @@ class RangeFallback:
     a re-pack of every weight, a bf16 pass and a re-pack back. `count` = calls that overflowed; `sticky` = running range-safe;
     `reset()` returns to fp16 operands and the policy that was active when the pipeline was built."""
 
-    def __init__(self, *models):
+    def __init__(self, *models, weight_dtype=None):
         self.models = [m for m in models if m is not None]
+        # the tier this pipeline was built for (its --weight_dtype): the operand dtype is PROCESS-wide state (ops.set_compute_dtype), so
+        # every forward() re-asserts what its own pipeline needs - after pipeline A went sticky (fp32 stream, bf16 operands) a second
+        # accurate pipeline B would otherwise run its fp16-only policy (MX layers, q / k splits) under bf16 operands and fail every call
+        self.weight_dtype = weight_dtype
         self.count = 0
         self.sticky = False
         self._saved = None
@@ -373,8 +397,15 @@ class RangeFallback:
     def reassert(self) -> None:
         """Called at the top of every forward(): another pipeline may have switched the process-wide tier in between."""
         from . import ops
-        if self.sticky and (not ops.precise() or ops.act_dtype() != torch.bfloat16):
-            ops.set_compute_dtype(torch.float32, operand_dtype=torch.bfloat16)
+        if self.sticky:
+            if not ops.precise() or ops.act_dtype() != torch.bfloat16:
+                ops.set_compute_dtype(torch.float32, operand_dtype=torch.bfloat16)
+        elif self.weight_dtype == torch.float32:
+            if not ops.precise() or ops.act_dtype() != torch.float16:
+                ops.set_compute_dtype(torch.float32)
+        elif self.weight_dtype in (torch.bfloat16, torch.float16):
+            if ops.precise() or ops.act_dtype() != self.weight_dtype:
+                ops.set_compute_dtype(self.weight_dtype)
 
     def reset(self) -> None:
         from . import ops
@@ -383,6 +414,7 @@ class RangeFallback:
                 for m, a, w, i16 in rows:
                     m.op_split, m.w_split, m.out_inner16 = a, w, i16
             self._saved = None
+            _touch()
         if self.sticky:
             ops.set_compute_dtype(torch.float32)
         self.sticky = False

@@ -53,3 +53,49 @@ def test_range_fallback_state_machine_without_gpu(monkeypatch):
     rf.reset()
     assert not rf.sticky and state["act"] == torch.float16
     assert (net[0].op_split, net[0].w_split, net[1].op_split, net[1].w_split) == (3, 2, 2, 1)
+
+
+def test_two_pipelines_one_sticky_reassert_their_own_mode(monkeypatch):
+    """the operand dtype is process-wide. Pipeline A goes sticky (fp32 stream, bf16 operands); a second accurate pipeline B
+    and a bf16 pipeline C in the same process re-assert THEIR tier at the top of every run instead of inheriting A's."""
+    from omgsr_amd import ops, precision
+    from omgsr_amd.nn import Conv2d
+    state = dict(act=torch.float16, precise=True)
+    monkeypatch.setattr(ops, "set_compute_dtype", lambda dt, operand_dtype=None: state.update(
+        act=torch.bfloat16 if dt == torch.bfloat16 else (operand_dtype or torch.float16), precise=dt == torch.float32))
+    monkeypatch.setattr(ops, "precise", lambda: state["precise"])
+    monkeypatch.setattr(ops, "act_dtype", lambda: state["act"])
+    monkeypatch.setattr(ops, "overflow_seen", lambda reset=True: False)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    a = precision.RangeFallback(torch.nn.Sequential(Conv2d(32, 32, 3)), weight_dtype=torch.float32)
+    b = precision.RangeFallback(torch.nn.Sequential(Conv2d(32, 32, 3)), weight_dtype=torch.float32)
+    c = precision.RangeFallback(torch.nn.Sequential(Conv2d(32, 32, 3)), weight_dtype=torch.bfloat16)
+    a.enter()
+    assert state == dict(act=torch.bfloat16, precise=True)
+    seen = []
+    b.run(lambda: seen.append((state["act"], state["precise"])), "B")
+    c.run(lambda: seen.append((state["act"], state["precise"])), "C")
+    a.run(lambda: seen.append((state["act"], state["precise"])), "A")
+    b.run(lambda: seen.append((state["act"], state["precise"])), "B")
+    assert seen == [(torch.float16, True), (torch.bfloat16, False), (torch.bfloat16, True), (torch.float16, True)]
+    assert a.sticky and not b.sticky and not c.sticky
+
+
+def test_graph_cache_drops_entries_captured_under_an_older_cache_epoch():
+    """a captured graph reads the one-slot caches' values by address; any rebuild since the capture makes it stale."""
+    from omgsr_amd import nn as onn
+    from omgsr_amd.nn import InputCache
+    e0 = onn.cache_epoch()
+    c = InputCache()
+    t1, t2 = torch.zeros(1), torch.zeros(1)
+    c.get((t1,), (), lambda: 1)
+    assert onn.cache_epoch() == e0 + 1
+    c.get((t1,), (), lambda: 1)
+    assert onn.cache_epoch() == e0 + 1                         # a hit rebuilds nothing
+    c.get((t2,), (), lambda: 2)
+    c.get((t1,), (), lambda: 1)                                # A -> B -> A: two rebuilds
+    assert onn.cache_epoch() == e0 + 3
+    from omgsr_amd import precision
+    p0 = precision.policy_epoch()
+    precision.set_operand_split(torch.nn.Sequential(onn.Conv2d(32, 32, 3)), [r"."])
+    assert precision.policy_epoch() > p0

@@ -57,6 +57,79 @@ def test_omgsr_s_graph_replay_equals_eager(wd, tiled_vae):
         ops.set_compute_dtype(torch.bfloat16)
 
 
+def test_graph_prompt_a_b_a_drops_the_stale_graph():
+    """graph A bakes in the address of prompt A's cross-attention K / V^T, which the one-slot cache frees when prompt B
+    replaces it. Returning to prompt A (same tensor object: the key hits graph A) must not replay against that freed memory: the graph is
+    dropped (cache epoch), the call runs eagerly, the next one re-captures. Every result equals the eager result of its prompt."""
+    from omgsr_amd import ops
+    from omgsr_amd.testing import synthetic_lq
+    wd = torch.bfloat16
+    try:
+        pipe = _s_pipe(wd)
+        g = torch.Generator().manual_seed(7)
+        pa = torch.randn(1, 77, 128, generator=g).to(device=DEV, dtype=wd)
+        pb = torch.randn(1, 77, 128, generator=g).to(device=DEV, dtype=wd)
+        pipe.vae.posterior_noise = torch.randn(1, 4, 24, 24, generator=g).to(DEV)
+        x = synthetic_lq(1, 192, 192, seed=9).to(device=DEV, dtype=wd)
+        with torch.no_grad():
+            ref_a, ref_b = pipe(x, pa, 32, 8)[0], pipe(x, pb, 32, 8)[0]
+            assert not torch.equal(ref_a, ref_b)
+            pipe.enable_graphs(True)
+            for _ in range(3):
+                assert torch.equal(pipe(x, pa, 32, 8)[0], ref_a)           # eager, capture, replay
+            assert pipe.graphs.captures == 1
+            for _ in range(3):
+                assert torch.equal(pipe(x, pb, 32, 8)[0], ref_b)           # rebuilds the K / V^T slot: graph A is now stale
+            junk = [torch.full((1 << 20,), 7.0, device=DEV, dtype=wd) for _ in range(8)]      # re-use what the slot freed
+            for _ in range(3):
+                assert torch.equal(pipe(x, pa, 32, 8)[0], ref_a)           # dropped -> eager -> re-captured, never the stale replay
+            assert pipe.graphs.stale_drops >= 1
+            for _ in range(2):
+                assert torch.equal(pipe(x, pb, 32, 8)[0], ref_b)
+            del junk
+            # a policy / guard / batch-invariance switch after a capture is a new key, not a stale replay
+            ops.set_batch_invariant(True)
+            try:
+                inv = pipe(x, pa, 32, 8)[0]
+                pipe.enable_graphs(False)
+                assert torch.equal(pipe(x, pa, 32, 8)[0], inv)
+            finally:
+                ops.set_batch_invariant(False)
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
+
+
+def test_omgsr_f_graph_batch_1_2_1():
+    """The FLUX pipeline's cached timestep / guidance tensors are rebuilt per batch size: B = 1 -> 2 -> 1 under graphs equals eager."""
+    from omgsr_amd import ops
+    from omgsr_amd.diffusers_api import AutoencoderKL, FluxTransformer2DModel
+    from omgsr_amd.pipelines.omgsr_f import OMGSR_F_Infer, prepare_latent_image_ids
+    from omgsr_amd.testing import seeded_init_, synthetic_lq
+    wd = torch.bfloat16
+    try:
+        vae = seeded_init_(AutoencoderKL(block_out_channels=[32, 64, 128, 128], layers_per_block=1, latent_channels=16, scaling_factor=0.3611, shift_factor=0.1159), 3, rounded=False)
+        flux = seeded_init_(FluxTransformer2DModel(num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=64,
+                                                   pooled_projection_dim=32, in_channels=64), 4, rounded=False)
+        pipe = OMGSR_F_Infer(None, None, DEV, wd, 244, 1.0, vae=vae, flux_transformer=flux)
+        g = torch.Generator().manual_seed(6)
+        pe, pooled = torch.randn(1, 32, 64, generator=g).to(DEV, wd), torch.randn(1, 32, generator=g).to(DEV, wd)
+        tids, iids = torch.zeros(32, 3, device=DEV, dtype=wd), prepare_latent_image_ids(8, 8, DEV, wd)
+        x1, x2 = synthetic_lq(1, 128, 128, seed=1).to(DEV, wd), synthetic_lq(2, 128, 128, seed=2).to(DEV, wd)
+        n1, n2 = torch.randn(1, 16, 16, 16, generator=g).to(DEV), torch.randn(2, 16, 16, 16, generator=g).to(DEV)
+
+        def call(x, n):
+            pipe.vae.posterior_noise = n
+            return pipe(x, pe, pooled, tids, iids, 16, 8)[0]
+        with torch.no_grad():
+            r1, r2 = call(x1, n1), call(x2, n2)
+            pipe.enable_graphs(True)
+            for x, n, r in [(x1, n1, r1)] * 3 + [(x2, n2, r2)] * 3 + [(x1, n1, r1)] * 3 + [(x2, n2, r2)] * 2:
+                assert torch.equal(call(x, n), r)
+        assert pipe.graphs.stale_drops >= 1
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
+
+
 def test_omgsr_f_graph_replay_equals_eager():
     from omgsr_amd import ops
     from omgsr_amd.diffusers_api import AutoencoderKL, FluxTransformer2DModel

@@ -14,7 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def tables():
+    import shutil
     import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available: the resource table is read from the compiler's remarks at build time")
+    if os.environ.get("OMGSR_BUILD_ABLATIONS", "0") == "1" or os.environ.get("OMGSR_EXTRA_DEFS"):
+        pytest.skip("an ablation / variant build is not the shipped library the committed table describes")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from kernel_resources import GOLDEN, pinned
     from omgsr_amd.build import kernel_resources

@@ -240,14 +240,21 @@ def test_conv_mx_multi_launch_and_saturation():
     w = torch.randn(Cout, C, 3, 3, generator=_g(9)) * (9 * C) ** -0.5
     pw = ops.pack_conv_weight(w, None, device=DEV, split=3)
     xs = [torch.randn(n, h, wd, C, generator=_g(20 + i)) for i, (n, h, wd) in enumerate([(3, 40, 40), (1, 40, 32), (1, 32, 40), (1, 32, 32)])]
+    ops.overflow_seen(); ops.mx_saturation_seen()                 # clear both bits of the guard word
     ys = ops.conv2d_multi([x.to(DEV) for x in xs], pw, pad=1)
     for x, y in zip(xs, ys):
         ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
         assert _rel(y, ref) < 2e-5
+    torch.cuda.synchronize()
+    assert not ops.mx_saturation_seen()
     big = xs[0] * 3000.0                                          # |a| up to ~1e4: a_hi' clamps at 448, a_lo' 2^11 clamps too
     y = ops.conv2d(big.to(DEV), pw, pad=1)
     ref = F.conv2d(big.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
     assert torch.isfinite(y).all() and _rel(y, ref) < 1e-3
+    # the saturation of the fp8 correction fields is no longer silent - the MX producers raise the diagnostic bit of the guard
+    # word (here: the fp32 -> MX cast in front of the conv), and it is NOT an fp16 overflow (no fallback is triggered)
+    torch.cuda.synchronize()
+    assert ops.mx_saturation_seen() and not ops.overflow_seen() and not ops.mx_saturation_seen()
 
 
 @pytest.mark.parametrize("M,K,Nn", [(4608, 3072, 3072), (9216, 1536, 512), (300, 320, 1280), (147456, 320, 320)])
