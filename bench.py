@@ -155,16 +155,23 @@ def collect_timing(lib_mod):
     kinds, kernels, shapes, stages = {}, {}, {}, {}
     for i in range(n):
         e = buf[i]
-        k = kinds.setdefault(int(e.kind), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-        k["launches"] += 1; k["ms"] += e.ms; k["flops"] += e.flops; k["bytes"] += e.bytes
+        # MFMA work actually ISSUED, in fp16-equivalent matrix-pipe time: every K segment of the contraction as the
+        # kernel runs it (m x n x k with k = R S Cin_slots: a two-term split operand / weight adds a segment each, the mixed-precision form
+        # runs 2x the logical channels - its fp8 K-steps cover 64 channels in the time an fp16 step covers 32), the phase-decomposed
+        # upsampling convs 4 of their 9 taps. `flops` (omgsr_timing: work_of) is the work HANDED to the kernel: logical channels, 9 taps.
+        issued = e.flops
+        if e.kind == 1 and e.m > 0 and e.n > 0 and e.k > 0:
+            issued = 2.0 * e.m * e.n * e.k * (4.0 / 9.0 if int(e.variant) in (6, 8) else 1.0)
+        k = kinds.setdefault(int(e.kind), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, issued=0.0))
+        k["launches"] += 1; k["ms"] += e.ms; k["flops"] += e.flops; k["bytes"] += e.bytes; k["issued"] += issued
         sg = stages.setdefault(int(e.stage), dict(launches=0, ms=0.0, mfma_ms=0.0, mfma_flops=0.0))
         sg["launches"] += 1; sg["ms"] += e.ms
         if e.kind in (1, 2):
             sg["mfma_ms"] += e.ms; sg["mfma_flops"] += e.flops
         if e.kind in (1, 2):
             name = IGEMM_VARIANTS.get(int(e.variant), "igemm?") if e.kind == 1 else "attn_kernel"
-            kk = kernels.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-            kk["launches"] += 1; kk["ms"] += e.ms; kk["flops"] += e.flops; kk["bytes"] += e.bytes
+            kk = kernels.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, issued=0.0))
+            kk["launches"] += 1; kk["ms"] += e.ms; kk["flops"] += e.flops; kk["bytes"] += e.bytes; kk["issued"] += issued
             s = shapes.setdefault((name, int(e.m), int(e.n), int(e.k)), dict(launches=0, ms=0.0, flops=0.0))
             s["launches"] += 1; s["ms"] += e.ms; s["flops"] += e.flops
     table = os.environ.get("OMGSR_KERNEL_TABLE")
@@ -204,7 +211,9 @@ def dry_run_cpu(args) -> None:
     for _ in range(args.steps):
         time.sleep(0.001 * (hi - lo))          # stand-in for the step
     D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t1, torch.device("cpu"))
+    mine = time.perf_counter() - t1
+    elapsed = D.max_over_ranks(mine, torch.device("cpu"))
+    fastest = D.min_over_ranks(mine, torch.device("cpu"))
     seen = D.world_size_seen()
     if rank == 0:
         print(json.dumps({"metric": "SR images/sec", "value": round(B * world * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world,
@@ -214,6 +223,7 @@ def dry_run_cpu(args) -> None:
                                                       "images_rank0": [lo, hi],
                                                       "parallelism": f"dp{world} (images sharded, weight broadcast {moved / 2**20:.2f} MiB over {'gloo' if world > 1 else 'nothing'})",
                                                       "broadcast_bytes": moved, "world_size": world},
+                          "per_rank_ms_per_step": {"min": round(fastest / args.steps * 1e3, 3), "max": round(elapsed / args.steps * 1e3, 3)},
                           "n_ranks_seen": seen, "broadcast_bytes": moved}), flush=True)
     D.shutdown()
 
@@ -266,6 +276,8 @@ def main():
         torch.cuda.synchronize()
         D.barrier()
         elapsed = time.perf_counter() - t1
+    # the contract's number is the MAX over ranks; the fastest rank's time beside it shows stragglers in a SCALE run
+    fastest = D.min_over_ranks(elapsed, device)
     elapsed = D.max_over_ranks(elapsed, device)
     ranks_seen = D.world_size_seen()            # a collective: every rank takes part
     images = B * world * args.steps
@@ -320,6 +332,7 @@ def main():
                        "parallelism": f"dp{world} (images sharded, RCCL weight broadcast {moved / 2**20:.1f} MiB)", "world_size": world},
             "args": {"workload": args.workload, "weight_dtype": args.weight_dtype, "batch": B},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "per_rank_ms_per_step": {"min": round(fastest / args.steps * 1e3, 3), "max": round(elapsed / args.steps * 1e3, 3)},
             "n_ranks_seen": ranks_seen, "broadcast_bytes": int(moved),
             "setup_s": round(build_secs, 1), **extra,
         }
@@ -428,10 +441,18 @@ def roofline_leg(_lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, 
     _lib.check(lib.omgsr_mfma_peak(4096, C.byref(peak_meas), torch.cuda.current_stream().cuda_stream), "omgsr_mfma_peak")
     per_kernel = {}
     for name, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
-        ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        # per kernel: `handed_tflop` = the work it was handed (logical channels, split segments counted once, 9 taps for the phase form);
+        # `issued_mfma_tflop` = the MFMA work it ran for that, in fp16-equivalent matrix-pipe time (what SQ_VALU_MFMA_BUSY_CYCLES
+        # reconciles with); `achieved_tflops` / `frac` / `frac_of_measured_peak` are on the ISSUED work, so none can exceed the
+        # micro-benchmark ratio; `handed_tflops` is the rate on the handed work (above the issued rate only where the kernel does less
+        # work than it was handed: the phase-decomposed upsampling convs)
+        ach = k["issued"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        hand = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
         per_kernel[name] = {"launches": k["launches"], "total_ms": round(k["ms"], 3), "avg_us": round(k["ms"] * 1e3 / k["launches"], 2),
-                            "executed_tflop": round(k["flops"] / 1e12, 3), "achieved_tflops": round(ach, 1),
-                            "frac": round(ach / PEAK_DENSE_TFLOPS, 4), "bytes_per_launch": round(k["bytes"] / k["launches"])}
+                            "handed_tflop": round(k["flops"] / 1e12, 3), "issued_mfma_tflop": round(k["issued"] / 1e12, 3),
+                            "achieved_tflops": round(ach, 1), "handed_tflops": round(hand, 1),
+                            "frac": round(ach / PEAK_DENSE_TFLOPS, 4), "frac_of_measured_peak": round(ach / max(float(peak_meas.value), 1.0), 4),
+                            "bytes_per_launch": round(k["bytes"] / k["launches"])}
     roofline = None
     ig, at = kinds.get(1), kinds.get(2)
     if ig and ig["ms"] > 0 and per_kernel:
@@ -448,11 +469,16 @@ def roofline_leg(_lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, 
                     "frac_of_measured_peak": round(ach / max(float(peak_meas.value), 1.0), 4),
                     "traffic": None,
                     "launches": ig["launches"], "kernel_ms": round(ig["ms"], 3),
-                    "algorithmic_tflop": round(alg_igemm, 3), "executed_tflop": round(ig["flops"] / 1e12, 3),
+                    "algorithmic_tflop": round(alg_igemm, 3), "handed_tflop": round(ig["flops"] / 1e12, 3),
+                    "issued_mfma_tflop": round(ig["issued"] / 1e12, 3),
+                    "issued_frac_of_peak": round(ig["issued"] / (ig["ms"] * 1e-3) / 1e12 / PEAK_DENSE_TFLOPS, 4),
+                    "issued_frac_of_measured_peak": round(ig["issued"] / (ig["ms"] * 1e-3) / 1e12 / max(float(peak_meas.value), 1.0), 4),
+                    # the whole step (every kernel, HBM-bound ones included) on the same algorithmic basis, driver-checkable: tflop_per_img x B / ms_per_step
+                    "pipeline_frac_of_mfma_peak": round(tflop_per_img * B * steps / elapsed / PEAK_DENSE_TFLOPS, 4) if world == 1 else None,
                     # `frac` divides the §8(d) ALGORITHMIC FLOPs by the kernels' time: the accurate tier's extra K segments (split operands /
                     # weights: up to 3 MFMA passes per layer) and the tiled VAE's overlap recompute are overhead there, not work. The
                     # kernels' own rate on the work they were handed (per-launch FLOPs incl. tile overlap, split segments counted once):
-                    "frac_of_launched_work": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12 / PEAK_DENSE_TFLOPS, 4),
+                    "frac_of_handed_work": round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12 / PEAK_DENSE_TFLOPS, 4),
                     "algorithmic_basis": f"{tflop_per_img} TFLOP/image x {B} images (SURVEY 8(d), untiled VAE) minus {attn_tflop:.3f} TFLOP run by attn_kernel",
                     "achieved_all_mfma_kernels": round(tflop_per_img * B / (mfma_ms * 1e-3), 2),
                     "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"]),

@@ -128,3 +128,11 @@ def max_over_ranks(x: float, device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def min_over_ranks(x: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())

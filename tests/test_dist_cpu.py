@@ -68,6 +68,70 @@ def test_broadcast_and_checksum_world2():
         assert moved == nbytes and t == 2.0
 
 
+def _tiny_flux(device=None):
+    from omgsr_amd.diffusers_api import FluxTransformer2DModel
+    kw = dict(num_layers=2, num_single_layers=3, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=64,
+              pooled_projection_dim=32, in_channels=64)
+    if device is None:
+        return FluxTransformer2DModel(**kw)
+    with torch.device(device):
+        return FluxTransformer2DModel(**kw)
+
+
+def _mixed_dtypes_(m):
+    """bf16 weights with fp32 norm tables and biases in between: every bucket boundary of the broadcast that falls on a dtype change."""
+    m.to(torch.bfloat16)
+    for name, p in m.named_parameters():
+        if "norm" in name or name.endswith(".bias"):
+            p.data = p.data.float()
+    return m
+
+
+def _worker8(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from omgsr_amd import dist as D
+    from omgsr_amd.testing import seeded_init_
+    r, _, w = D.init("gloo")
+    if r == 0:
+        m = _mixed_dtypes_(seeded_init_(_tiny_flux(), 11, rounded=False))
+    else:                                                      # peers never initialise weights: meta -> to_empty (uninitialised memory), as on the GPU node
+        m = _mixed_dtypes_(_tiny_flux("meta")).to_empty(device="cpu")
+    same_before = D.replicas_identical(m)
+    moved = D.broadcast_module_(m, src=0, bucket_bytes=1 << 20)          # ~25 MB of weights: dozens of buckets, several dtype boundaries
+    same_after = D.replicas_identical(m)
+    ref = _mixed_dtypes_(seeded_init_(_tiny_flux(), 11, rounded=False))
+    equal = all(a.dtype == b.dtype and torch.equal(a, b) for a, b in zip(m.state_dict().values(), ref.state_dict().values()))
+    lo, hi = D.shard_range(64, r, w)
+    ms = 100.0 + r
+    q.put((r, w, same_before, moved, same_after, equal, (lo, hi), D.min_over_ranks(ms, torch.device("cpu")), D.max_over_ranks(ms, torch.device("cpu")),
+           D.world_size_seen()))
+    D.shutdown()
+
+
+@pytest.mark.timeout(420)
+def test_world8_flux_shaped_broadcast_and_shards():
+    """BASELINE configs[4] on CPU: 8 gloo ranks, 64 images sharded 8 x 8, a FLUX-shaped module built on the meta device on
+    the peers (to_empty) and filled by the bucketed broadcast across fp32 / bf16 boundaries, bit-exact replica checksum, and the per-rank
+    min / max that bench.py prints next to the max-over-ranks time."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=400) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = _mixed_dtypes_(_tiny_flux())
+    nbytes = sum(p.numel() * p.element_size() for p in ref.parameters()) + sum(b.numel() * b.element_size() for b in ref.buffers())
+    assert len({p.dtype for p in ref.parameters()}) == 2
+    for r, w, same_before, moved, same_after, equal, shard, tmin, tmax, seen in res:
+        assert w == 8 and seen == 8 and not same_before and same_after and equal
+        assert moved == nbytes and shard == (8 * r, 8 * r + 8) and (tmin, tmax) == (100.0, 107.0)
+
+
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` outside a torchrun environment launches 2 ranks itself (child torchrun, parent never touches a
     GPU) and rank 0 reports n_gpus 2, dp2 and the bytes the weight broadcast moved. CPU rehearsal: gloo, reduced models."""
@@ -83,3 +147,6 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["world_size"] == 2 and j["config"]["parallelism"].startswith("dp2")
     assert j["config"]["broadcast_bytes"] > 1 << 20 and j["config"]["global_batch"] == 4 and j["scaling"] == "weak"
+    # per-rank step time next to the max over ranks the contract times: a SCALE run shows stragglers
+    pr = j["per_rank_ms_per_step"]
+    assert pr["min"] <= pr["max"] and abs(pr["max"] - j["ms_per_step"]) < 1e-6
