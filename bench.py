@@ -46,7 +46,8 @@ WORKLOADS = {
     "f1024": ("F", 1024, 8, 128, 64, 89.8),        # configs[3] (and the per-GPU share of configs[4]: 64 images over 8 GPUs)
 }
 DTYPES = {"fp32": "float32", "fp16": "float16", "bf16": "bfloat16"}
-IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel", 6: "igemm_halo_kernel<TAPS=4>", 7: "igemm_halo_multi_kernel", 8: "igemm_halo_multi_kernel<TAPS=4>", 9: "igemm_gmx_kernel"}
+IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel", 6: "igemm_halo_kernel<TAPS=4>", 7: "igemm_halo_multi_kernel", 8: "igemm_halo_multi_kernel<TAPS=4>", 9: "igemm_gmx_kernel",
+                  10: "igemm_halo_kernel<GN>", 11: "igemm_halo_multi_kernel<GN>"}
 
 
 def parse(argv=None):

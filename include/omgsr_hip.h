@@ -148,7 +148,28 @@ typedef struct omgsr_igemm_args {
                               check it once per call, at the sync the reference's forward() already has | NULL.
                               Bit 1 (value 2, diagnostic only): a value beyond +-448 was written into an OMGSR_EL_MX output - its fp8 correction
                               fields saturate (fixed scales), that element keeps single-rounding fp16 accuracy */
+    /* ---- ABI v15: GroupNorm apply (+ SiLU) as the conv's patch PRODUCER (SURVEY 2.3 K4 "apply fused into K1 prologue"; replaces the
+       pre_norm -> silu -> conv triplets of infer/vaehook.py:269-274, 384-413 / diffusers' ResnetBlock2D norm1 -> nonlinearity -> conv1) */
+    const float* gn_scale_shift; /* non-NULL: `in` is the STREAM tensor the GroupNorm reads (element kind `in_el`: the 16-bit compute type or fp32),
+                              [N,H,W,Cin] with Cin logical channels, and the kernel normalises while it builds its LDS patch:
+                              operand(n, y, x, c) = act(in * scale[n % gn_nimg][c] + shift[n % gn_nimg][c]) rounded once to the compute type,
+                              exact zeros outside the image (the conv pads the NORMALISED tensor). Table: f32 [gn_nimg][Cin][2] =
+                              (rstd gamma, beta - mean rstd gamma), omgsr_groupnorm_scale_shift(). Only for problems omgsr_igemm_gn_fusable()
+                              accepts (3x3 stride 1 pad 1 on the halo-tile kernel's spatial form, plain operand and weight, Cin <= 1024);
+                              anything else returns OMGSR_E_SHAPE | NULL */
+    int32_t gn_nimg;       /* rows n of `in` share the statistics of image n % gn_nimg (the tiled VAE's tile-major groups); N when every row has its own */
+    int32_t gn_act;        /* activation applied after the affine: OMGSR_ACT_SILU (the only one the fused form has: every conv-feeding GroupNorm of the path) */
+    int32_t in_el;         /* element kind of `in` when gn_scale_shift is set: OMGSR_EL_16 | OMGSR_EL_F32 */
+    int32_t reserved1;
 } omgsr_igemm_args;
+/* 1 when omgsr_igemm / omgsr_igemm_multi would run these arguments with the GroupNorm apply fused into the conv's patch producer (the
+ * fields above may still be unset: the answer depends on geometry, operand / weight form, compute type and `in_el` only; for a problem of a
+ * launch group call omgsr_igemm_multi_plan first). 0: run omgsr_groupnorm_apply and hand the conv its operand as before. */
+int32_t omgsr_igemm_gn_fusable(const omgsr_igemm_args* a);
+/* (scale, shift) table of a GroupNorm for the fused form: out[n][c] = (rstd[n][g] gamma[c], beta[c] - mean[n][g] rstd[n][g] gamma[c]), g = c / (C / G);
+ * mean / rstd f32 [nimg][G], gamma / beta f32 [C] | NULL, out f32 [nimg][C][2]. */
+int omgsr_groupnorm_scale_shift(const float* mean, const float* rstd, const float* gamma, const float* beta, float* out, int32_t nimg, int32_t C,
+                                int32_t G, void* stream);
 int omgsr_igemm(const omgsr_igemm_args* a, void* stream);
 /* The problems of ONE layer that differ only in tensors and spatial extents (the tiled VAE runs every layer once per tile-shape group:
  * corner / edge / interior tiles are separate dense tensors; infer/vaehook.py:537-829 walks them one tile at a time). Call

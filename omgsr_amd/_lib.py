@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class OmgsrError(RuntimeError):
@@ -39,6 +39,7 @@ class IgemmArgs(C.Structure):
         ("res_el", C.c_int32), ("in_split", C.c_int32), ("sample_rows", C.c_int64), ("out_lo_off", C.c_int32),
         ("in_ld", C.c_int32), ("w_split", C.c_int32), ("weight_ph", C.c_void_p), ("mx_chunks16", C.c_int32), ("mx_scale_w1", C.c_int32), ("mx_scale_a1", C.c_int32),
         ("mx_scale_w2", C.c_int32), ("mx_scale_a2", C.c_int32), ("out_mx", C.c_int32), ("group_tiles", C.c_int32), ("overflow_flag", C.c_void_p),
+        ("gn_scale_shift", C.c_void_p), ("gn_nimg", C.c_int32), ("gn_act", C.c_int32), ("in_el", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -83,6 +84,8 @@ SIGNATURES = {
     "omgsr_igemm_workspace_bytes": (C.c_int64, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_slots": (C.c_int32, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_entries": (C.c_int32, [C.POINTER(IgemmArgs)]),
+    "omgsr_igemm_gn_fusable": (C.c_int32, [C.POINTER(IgemmArgs)]),
+    "omgsr_groupnorm_scale_shift": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "omgsr_groupnorm_finalize": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, C.c_double, _F, _P]),
     "omgsr_groupnorm_partial": (C.c_int, [_P, _P, _I, _L, _I, _I, _I, _P]),
     "omgsr_groupnorm_finalize_merged": (C.c_int, [C.POINTER(GnMergeArgs), _P, _P, _P, _I, _I, _F, _P]),

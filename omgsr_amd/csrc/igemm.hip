@@ -36,6 +36,7 @@ int igemm_halo_tiles(const omgsr_igemm_args& a, bool phase = false);
 int igemm_halo_flat(const omgsr_igemm_args& a);      // pitch of the FLAT form the halo kernel would use for this problem (narrow maps), 0 = spatial tiles
 int igemm_halo_tiles_form(const omgsr_igemm_args& a, int flat);
 int igemm_halo_gn_slots(const omgsr_igemm_args& a, bool phase = false);
+bool igemm_halo_gn_geometry_ok(const omgsr_igemm_args& a);     // igemm_halo_gn.hip: what the normalising patch producer can run
 }
 
 namespace omgsr { static int g_batch_invariant = 0; }
@@ -370,6 +371,32 @@ void gn_plan(const omgsr_igemm_args& a, int* nslot, int* entries) {
 }
 }  // namespace
 
+namespace {
+// GroupNorm apply as the conv's patch producer (omgsr_igemm_args.gn_scale_shift): the problem must take the halo-tile kernel's spatial nine-tap
+// form on its own merits (tile count / launch-group policy included) - the fused form is an instantiation of THAT kernel, not a fall-back
+// path of its own. OMGSR_GN_FUSE=0 switches it off (A/B runs: every caller then runs the apply pass).
+bool gn_fusable(const omgsr_igemm_args& a_in) {
+    static const char* off = getenv("OMGSR_GN_FUSE");
+    if (off && off[0] == '0') return false;
+    omgsr_igemm_args a = a_in;
+    a.gn_scale_shift = nullptr;                                  // the decision never depends on whether the table is attached yet
+    if (!omgsr::igemm_halo_gn_geometry_ok(a) || a.out_layout != OMGSR_LAYOUT_NHWC || a.act == OMGSR_ACT_GEGLU) return false;
+    if ((int64_t)a.H * a.W * a.Cin >= (1ll << 31)) return false;
+    if (a.workspace && splitk_plan(a, (int64_t)a.N * a.Ho * a.Wo) > 1) return false;
+    if (!use_halo(a) || use_halo_phase(a)) return false;
+    if (omgsr::igemm_halo_flat(a) != 0) return false;            // (narrow maps take the FLAT form, which has no normalising instantiation)
+    // Policy (one-box A/B, profiles/r05_experiments.md): the producer's VALU work costs every workgroup tile ~+22 % of its time, whatever the
+    // layer; what it saves is the apply pass over the INPUT, which every 128-column output tile of a pixel block repeats. One column tile
+    // (Cout <= 128: the full-resolution levels, where the apply pass is largest): -0.17 ms per layer; two: break-even; four: a loss.
+    static const char* mc = getenv("OMGSR_GN_FUSE_MAX_COUT");   // A/B runs
+    static const int max_cout = mc ? atoi(mc) : 128;
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    return logical_cols <= max_cout;
+}
+}  // namespace
+
+extern "C" int32_t omgsr_igemm_gn_fusable(const omgsr_igemm_args* ap) { return (ap && gn_fusable(*ap)) ? 1 : 0; }
+
 extern "C" int32_t omgsr_igemm_gn_slots(const omgsr_igemm_args* ap) {
     if (!ap) return 0;
     int nslot, entries;
@@ -422,6 +449,7 @@ int validate_args(omgsr_igemm_args& a) {
     if (a.mx_chunks16 < 0 || (a.mx_chunks16 > 0 && !mx_geometry_ok(a) && !omgsr::igemm_gmx_ok(a))) return OMGSR_E_SHAPE;
     if (a.out_mx && (a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cout & 63) || a.out_lo_off || a.out_ld || a.gn_partial ||
                      omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
+    if (a.gn_scale_shift && (a.gn_nimg <= 0 || a.gn_act != OMGSR_ACT_SILU || !gn_fusable(a))) return OMGSR_E_SHAPE;      // (SiLU is the one activation the producer applies)
     if (a.gn_partial) {                            // must be exactly what omgsr_igemm_gn_slots / _gn_entries promised
         int nslot, entries;
         gn_plan(a, &nslot, &entries);
@@ -491,6 +519,7 @@ extern "C" int omgsr_igemm_multi(const omgsr_igemm_args* args, int32_t count, vo
             const int logical_cols = (grp[0].act == OMGSR_ACT_GEGLU) ? 2 * grp[0].Cout : grp[0].Cout;
             omgsr::TimingScope ts(OMGSR_TK_IGEMM, gf, gb, st, gm, logical_cols, (long long)grp[0].R * grp[0].S * grp[0].Cin);
             ts.rec.variant = ng == 1 ? (mode == 1 ? 6 : 3) : (mode == 1 ? 8 : 7);      // 7 / 8: igemm_halo_multi_kernel (gather / phase form)
+            if (grp[0].gn_scale_shift) ts.rec.variant = ng == 1 ? 10 : 11;              // 10 / 11: the GroupNorm-fused instantiations
             rc = ng == 1 ? omgsr::igemm_halo_launch(grp[0], geo[0], st, mode == 1) : omgsr::igemm_halo_launch_multi(grp, geo, ng, st, mode == 1);
         }
         ng = 0; gf = gb = 0.0; gm = 0;
@@ -506,7 +535,8 @@ extern "C" int omgsr_igemm_multi(const omgsr_igemm_args* args, int32_t count, vo
                           a.res_el == grp[0].res_el && (a.residual != nullptr) == (grp[0].residual != nullptr) &&
                           (a.gn_partial != nullptr) == (grp[0].gn_partial != nullptr) && a.gn_entries == grp[0].gn_entries && a.bias == grp[0].bias &&
                           a.gate == grp[0].gate && a.alpha == grp[0].alpha && a.upsample == grp[0].upsample && a.mx_chunks16 == grp[0].mx_chunks16 && a.out_mx == grp[0].out_mx &&
-                          ((a.Cout <= 32) == (grp[0].Cout <= 32)) && ((omgsr::igemm_halo_flat(a) != 0) == (omgsr::igemm_halo_flat(grp[0]) != 0));
+                          ((a.Cout <= 32) == (grp[0].Cout <= 32)) && ((omgsr::igemm_halo_flat(a) != 0) == (omgsr::igemm_halo_flat(grp[0]) != 0)) &&
+                          (a.gn_scale_shift != nullptr) == (grp[0].gn_scale_shift != nullptr) && a.gn_act == grp[0].gn_act;
         if (m < 0) {                     // not a halo problem: its own launch, in order
             rc = flush();
             if (rc == 0) rc = omgsr_igemm(&args[i], stream);
@@ -583,7 +613,8 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     }
     // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
     if (use_halo_phase(a)) { ts.rec.variant = 6; return omgsr::igemm_halo_launch(a, g, st, true); }
-    if (use_halo(a)) { ts.rec.variant = 3; return omgsr::igemm_halo_launch(a, g, st); }
+    if (use_halo(a)) { ts.rec.variant = a.gn_scale_shift ? 10 : 3; return omgsr::igemm_halo_launch(a, g, st); }
+    if (a.gn_scale_shift) return OMGSR_E_SHAPE;                  // (validate_args already refused it: never reached)
     {
         static const char* dbg = getenv("OMGSR_DEBUG_DISPATCH");      // one line per conv-shaped problem that did NOT take the halo kernel
         if (dbg && a.R == 3)

@@ -50,6 +50,9 @@ constexpr int BN = 128, B_BYTES = BN * 64, BPW = 2;       // BN / B_BYTES: the w
 constexpr int LDS_BYTES = HaloGeo<9>::LDS_BYTES > HaloGeo<4>::LDS_BYTES ? HaloGeo<9>::LDS_BYTES : HaloGeo<4>::LDS_BYTES;   // <= 72 KB: two workgroups per CU
 static_assert(HaloGeo<9>::APIECES == 22 && HaloGeo<9>::APW == 6 && HaloGeo<4>::APIECES == 19 && HaloGeo<4>::APW == 5, "piece counts");
 constexpr int LDS_BYTES_BIG = HaloGeo<9, true>::LDS_BYTES;
+// GNF instantiations: + the (scale, shift) table of one image, Cin <= 1024 channels x 2 floats (still two workgroups per CU)
+constexpr int GN_MAX_CIN = 1024, LDS_BYTES_GN = HaloGeo<9>::LDS_BYTES + GN_MAX_CIN * 8;
+static_assert(LDS_BYTES_GN <= 81920, "GNF: two workgroups per CU");
 static_assert(HaloGeo<9, true>::APW == 7 && LDS_BYTES_BIG == 81920, "big FLAT patch: two workgroups per CU");
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_h[4] = {0u, 0u, 0u, 0u};
@@ -73,8 +76,19 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 // NARROW: Cout <= 32 (the VAE's conv_out, 128 -> 3): the four waves split the 8 tile rows (2 each) over ONE 32-column
 // fragment instead of 2 x 2 waves over 128 columns. The im2col kernels gather every input pixel nine times out of L2
 // (3.2 GB for a 1.4 MPixel x 128-channel map: 350 us, L2-bound at 70 TFLOP/s); here the patch is read once.
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, int FLAT = 0>      // FLAT: 0 spatial tiles, 1 FLAT form, 2 FLAT form with the 27-piece patch
+// GNF (round 5): GroupNorm apply (+ SiLU) as the patch PRODUCER (omgsr_igemm_args.gn_scale_shift). 0 = `in` is a ready 16-bit operand.
+// 1 = `in` is the 16-bit STREAM tensor the GroupNorm reads: the patch of the next chunk is LDS-DMA'd exactly as before (raw values), and
+// between its arrival (the counted wait of tap 2 covers a wave's OWN pieces) and its first use one chunk later every wave normalises the
+// pieces it fetched IN PLACE: at the end of taps 2..7, behind the step's MFMAs when the fragment registers are dead, a lane reads back the 16
+// bytes it DMA'd (8 channels of one patch pixel), applies x * scale[c] + shift[c] (the (scale, shift) table of the tile's image sits in LDS
+// behind the weight ring), SiLU, rounds once and writes them back; pixels outside the image stay the exact zeros the zero page supplied
+// (the conv pads the NORMALISED map). No other wave touches those bytes before the next chunk's first barrier. The separate apply pass
+// (read stream, write operand) and the conv's read of that operand are gone: 4 of 6 bytes per element. Spatial nine-tap form, plain
+// 16-bit operand and weight only (no split / MX / wrap). An fp32 stream (the accurate tier's) would need its patch register-staged (a raw
+// fp32 chunk is 42 KB: no LDS room): loads held in VGPRs across K-steps next to inline-asm DMA traffic the compiler cannot count - not built.
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, int FLAT = 0, int GNF = 0>      // FLAT: 0 spatial tiles, 1 FLAT form, 2 FLAT form with the 27-piece patch
 OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const int tile, const int bidy) {      // tile: logical (XCD-remapped) tile index
+    static_assert(GNF == 0 || (TAPS == 9 && !MX && FLAT == 0 && ABL == 0 && !PRIO), "GNF: spatial nine-tap form only");
     constexpr int WTN = NARROW ? 32 : 64, FM = NARROW ? 2 : 4, FN = NARROW ? 1 : 2, BNK = NARROW ? 32 : 128;
     using HG = HaloGeo<TAPS, FLAT == 2>;
     constexpr int KS = HG::KS, PW = HG::PW, PROWS = HG::PROWS, APIECES = HG::APIECES, APW = HG::APW, A_BYTES = HG::A_BYTES;
@@ -115,6 +129,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
     // A patch pieces: piece j = wave*6 + i covers patch rows [16j, 16j+16); patch row -> (py, px)
     const unsigned char* a_ptr[APW];
     int a_inc[APW];
+    unsigned gn_ok = 0;
     const int ild = p.in_ld > 0 ? p.in_ld : p.Cin;      // physical channels per pixel row
     const int wrap_at = ild / 32;                       // chunk index at which the patch pointer returns to channel 0 (w_lo segment)
 #pragma unroll
@@ -136,6 +151,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         a_ptr[i] = ok ? reinterpret_cast<const unsigned char*>(in + pix * ild + kc * 8)
                       : reinterpret_cast<const unsigned char*>(g_zero_page_h);
         a_inc[i] = ok ? 64 : 0;
+        if constexpr (GNF != 0) gn_ok |= (ok ? 1u : 0u) << i;      // (a zero-page pixel must stay zero: silu(shift) is not)
     }
     const unsigned char* b_ptr[BPW];
 #pragma unroll
@@ -167,6 +183,34 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
             glds16(b_ptr[i], __builtin_amdgcn_readfirstlane(real ? dst + i * 1024 : lds_base + DUMMY_OFF));
             if (real) b_ptr[i] += b_step;
         }
+    };
+
+    // ---- GNF: normalise this wave's piece i of patch buffer `buf` (chunk `chunk`) in place -------------------------------------
+    // read (the lane's 16 raw bytes + its (scale, shift) octet) / math (~70 VALU instructions, SiLU is the only activation: omgsr_igemm
+    // refuses anything else) / write-back; the dummy pieces of the last wave normalise the dummy KiB (wave-uniform address select)
+    constexpr int GN_TAB_OFF = HG::LDS_BYTES;                   // (scale, shift) pairs of the tile's image, Cin x 2 floats, behind the weight ring
+    const int gn_lane16 = lane * 16, gn_kc64 = kc * 64;
+    auto gn_slot = [&](const int i, const int buf) -> u32x4_t* {
+        const int piece = wave * APW + i;                        // (wave-uniform)
+        const int off = piece < APIECES ? buf * A_BYTES + piece * 1024 : DUMMY_OFF + (piece - APIECES) * 1024;
+        return reinterpret_cast<u32x4_t*>(lds + off + gn_lane16);
+    };
+    auto gn_read = [&](const int i, const int buf, const int chunk, u32x4_t& raw, f32x4_t (&tb)[4]) {
+        raw = *gn_slot(i, buf);
+        const f32x4_t* tp = reinterpret_cast<const f32x4_t*>(lds + GN_TAB_OFF + chunk * 256 + gn_kc64);
+        tb[0] = tp[0]; tb[1] = tp[1]; tb[2] = tp[2]; tb[3] = tp[3];
+    };
+    auto gn_math = [&](const int i, const u32x4_t raw, const f32x4_t (&tb)[4]) -> u32x4_t {
+        float f[8];
+        unpack8<T>(raw, f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f[2 * q] = silu_f(f[2 * q] * tb[q][0] + tb[q][1]);
+            f[2 * q + 1] = silu_f(f[2 * q + 1] * tb[q][2] + tb[q][3]);
+        }
+        u32x4_t o = pack8<T>(f);
+        if (!((gn_ok >> i) & 1u)) o = (u32x4_t){0u, 0u, 0u, 0u};      // outside the image: the conv pads the NORMALISED map with zeros
+        return o;
     };
 
     f32x16_t acc[FM][FN];
@@ -207,6 +251,21 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         issue_a(0, 0);
         issue_b(0);
         issue_b(1);
+    }
+    if constexpr (GNF != 0) {
+        // the (scale, shift) table of the tile's image -> LDS (rows of a tile-major tensor share the statistics of image n % gn_nimg), then
+        // the first chunk's pieces, which nothing hides: ~0.7 us per tile, once (every later chunk is normalised behind the previous one's MFMAs)
+        const f32x4_t* tsrc = reinterpret_cast<const f32x4_t*>(p.gn_scale_shift + (int64_t)(img % p.gn_nimg) * ild * 2);
+        f32x4_t* tdst = reinterpret_cast<f32x4_t*>(lds + GN_TAB_OFF);
+        for (int q = t; q < ild / 2; q += 256) tdst[q] = tsrc[q];
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // this wave's patch pieces (older than the two weight slices) have landed
+        __syncthreads();                                         // the table is complete
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            u32x4_t raw; f32x4_t tb[4];
+            gn_read(i, 0, 0, raw, tb);
+            *gn_slot(i, 0) = gn_math(i, raw, tb);
+        }
     }
 
     // one K-step with compile-time tap and patch parity
@@ -317,6 +376,19 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
                 }
             }
         }
+        if constexpr (GNF != 0 && tap >= 2 && tap < 2 + APW) {
+            // GNF: the next chunk's patch was issued in tap 0 and this wave's OWN pieces are covered by the counted wait of tap 2: piece
+            // tap - 2 is normalised in place at the end of taps 2 .. 7, behind the step's MFMAs (the fragment registers are dead here).
+            // Interleaving the ~70 VALU instructions with the second half of the MFMAs instead (sched_group_barrier, 256 registers)
+            // measured the same: the step's cost is the VALU issue time itself, not its placement (profiles/r05_experiments.md)
+            if (cc + 1 < ncc) {
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4_t g_raw;
+                f32x4_t g_tb[4];
+                gn_read(tap - 2, par ^ 1, cc + 1, g_raw, g_tb);
+                *gn_slot(tap - 2, par ^ 1) = gn_math(tap - 2, g_raw, g_tb);
+            }
+        }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto chunk = [&](auto par_c, auto f8_c, const int cc) {
@@ -402,7 +474,7 @@ OMGSR_DEVINL bool phase_block_map(const int b, const int T, const int n8, const 
     return tile < T;
 }
 
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, int FLAT = 0>
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, int FLAT = 0, int GNF = 0>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     int tile, phase;
     // Phase form (TAPS = 4). The four phases of a tile read the SAME low-res patch and each its own phase-summed weights. Three block orders:
@@ -417,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     } else {
         tile = xcd_remap((int)blockIdx.x, g.ntm * g.ntn); phase = (int)blockIdx.y;
     }
-    halo_body<T, ABL, PRIO, NARROW, TAPS, MX, FLAT>(p, g, tile, phase);
+    halo_body<T, ABL, PRIO, NARROW, TAPS, MX, FLAT, GNF>(p, g, tile, phase);
 }
 
 // Several problems that share weights and epilogue options in ONE launch (the tiled VAE runs every layer once per tile-shape group:
@@ -431,7 +503,7 @@ struct HaloMulti {
     int start[HALO_MULTI_MAX + 1];
     int count;
 };
-template <typename T, bool NARROW, int TAPS, bool MX = false, int FLAT = 0>
+template <typename T, bool NARROW, int TAPS, bool MX = false, int FLAT = 0, int GNF = 0>
 __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMulti m) {
     int s = 0, tile, phase;
     if (TAPS == 4 && m.g[0].interleave) {      // x-only grid of 4 x the 8-aligned ranges; block order inside a problem's range: see igemm_halo_kernel
@@ -443,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMult
         if (bid >= m.g[s].ntm * m.g[s].ntn) return;                                 // filler block of the 8-aligned range
         tile = xcd_remap(bid, m.g[s].ntm * m.g[s].ntn); phase = (int)blockIdx.y;
     }
-    halo_body<T, 0, false, NARROW, TAPS, MX, FLAT>(m.p[s], m.g[s], tile, phase);
+    halo_body<T, 0, false, NARROW, TAPS, MX, FLAT, GNF>(m.p[s], m.g[s], tile, phase);
 }
 
 
@@ -456,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMult
 static inline int halo_flat_eligible(const omgsr_igemm_args& a) {
     static const char* off = getenv("OMGSR_HALO_FLAT");
     if (off && off[0] == '0') return 0;
+    if (a.gn_scale_shift) return 0;                 // the normalising patch producer exists in the spatial form only (omgsr_igemm_gn_fusable said so)
     static const char* mw = getenv("OMGSR_HALO_FLAT_MAXW");        // A/B runs: 45 = only the 22-piece patch
     static const int maxw = mw ? atoi(mw) : 80;                   // 256 + 2 (W + 2) + 2 <= 432 patch rows (27 pieces)
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;

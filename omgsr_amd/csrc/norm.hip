@@ -261,6 +261,17 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
     }
 }
 
+// (scale, shift) table of a GroupNorm for the conv kernels that normalise while they build their patch (omgsr_igemm_args.gn_scale_shift):
+// the same two expressions the apply kernels above evaluate per block
+__global__ void gn_scale_shift_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* __restrict__ out, int total, int C, int G) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int n = i / C, c = i - n * C, g = c / (C / G);
+    const float r = rstd[n * G + g], m = mean[n * G + g];
+    const float a = r * (gamma ? gamma[c] : 1.0f);
+    *reinterpret_cast<f32x2_t*>(out + 2 * (int64_t)i) = (f32x2_t){a, (beta ? beta[c] : 0.0f) - m * a};
+}
 // ---------------------------------------------------------------------------------------------
 OMGSR_DEVINL void load_affine8(const float* __restrict__ v, const int c, const float dflt, float (&o)[8]) {
     if (v) {
@@ -503,6 +514,14 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(T* __restrict__ x, co
 }
 
 }  // namespace
+
+extern "C" int omgsr_groupnorm_scale_shift(const float* mean, const float* rstd, const float* gamma, const float* beta, float* out, int32_t nimg,
+                                           int32_t C, int32_t G, void* stream) {
+    if (!mean || !rstd || !out || nimg <= 0 || C <= 0 || G <= 0 || (C % G)) return OMGSR_E_BADARG;
+    const int total = nimg * C;
+    hipLaunchKernelGGL(gn_scale_shift_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, rstd, gamma, beta, out, total, C, G);
+    return (int)hipGetLastError();
+}
 
 extern "C" int omgsr_groupnorm_nchunk(int64_t HW) { return (int)((HW + GN_PPC - 1) / GN_PPC); }
 

@@ -47,17 +47,20 @@ class ResnetBlock2D(nn.Module):
         """conv1_bias: conv1.bias + time_emb_proj(silu(temb)) folded by the UNet (constant at fixed t*).
         out_for: the ONLY consumer of the result is that conv / linear (an up / down-sampling conv): the result is written
         directly as its MFMA operand (no fp32 stream copy, no cast pass)."""
-        if self.conv_shortcut is not None:
-            # the 1x1 shortcut reads x itself: its operand copy is a second output of norm1's apply pass over x
+        # norm -> SiLU -> conv: the norm is handed to the conv (gn=): it runs as the conv's patch producer where the kernel can (a 16-bit
+        # stream tensor into a plain 3x3 conv on the halo-tile kernel: every resnet conv of the fast tiers), as the apply pass otherwise
+        if self.conv_shortcut is not None and x.dtype == torch.float32:
+            # accurate tier: the 1x1 shortcut reads x itself; its operand copy is a second output of norm1's apply pass over x
             h, xc = self.norm1.nhwc(x, ops.ACT_SILU, split=self.conv1.in_split(), also_cast=self.conv_shortcut.in_split())
-        else:
-            h, xc = self.norm1.nhwc(x, ops.ACT_SILU, split=self.conv1.in_split()), None
-        h = self.conv1.nhwc(h, bias_override=conv1_bias, gn_groups=self.norm2.num_groups)     # norm2's statistics ride the epilogue
-        h = self.norm2.nhwc(h, ops.ACT_SILU, split=self.conv2.in_split())
+            h = self.conv1.nhwc(h, bias_override=conv1_bias, gn_groups=self.norm2.num_groups)
+        else:                                                      # (a 16-bit stream tensor IS the shortcut's operand)
+            xc = x
+            h = self.conv1.nhwc(x, gn=self.norm1.spec(x, ops.ACT_SILU), bias_override=conv1_bias, gn_groups=self.norm2.num_groups)   # norm2's statistics ride the epilogue
+        g2 = self.norm2.spec(h, ops.ACT_SILU)
         sc = self.conv_shortcut.nhwc(xc, pad=0) if self.conv_shortcut is not None else x
         if out_for is not None:
-            return self.conv2.nhwc(h, residual=sc, out_dtype=ops.OUT_BF16, out_split=out_for.in_split())
-        return self.conv2.nhwc(h, residual=sc, gn_groups=self.norm1.num_groups)             # ... and the next block's norm1
+            return self.conv2.nhwc(h, gn=g2, residual=sc, out_dtype=ops.OUT_BF16, out_split=out_for.in_split())
+        return self.conv2.nhwc(h, gn=g2, residual=sc, gn_groups=self.norm1.num_groups)      # ... and the next block's norm1
 
     def forward(self, x, temb=None):  # NCHW (diffusers calling convention; the VAE variant has no temb)
         if temb is not None or self.time_emb_proj is not None:
@@ -241,8 +244,7 @@ class Encoder(nn.Module):
         for b in self.down_blocks:
             h = b.nhwc(h)
         h = self.mid_block.nhwc(h)
-        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU, split=self.conv_out.in_split())
-        return self.conv_out.nhwc(h)
+        return self.conv_out.nhwc(h, gn=self.conv_norm_out.spec(h, ops.ACT_SILU))
 
     def run_nhwc(self, x):
         """nhwc() or, when a tiled-VAE hook is installed (pipelines.vaehook.VAEHook), the hook."""
@@ -277,8 +279,7 @@ class Decoder(nn.Module):
         h = self.mid_block.nhwc(h)
         for b in self.up_blocks:
             h = b.nhwc(h)
-        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU, split=self.conv_out.in_split())
-        return self.conv_out.nhwc(h)
+        return self.conv_out.nhwc(h, gn=self.conv_norm_out.spec(h, ops.ACT_SILU))
 
     def run_nhwc(self, z):
         hook = getattr(self, "_tile_hook", None)

@@ -314,8 +314,7 @@ class UNet2DConditionModel(ModelMixin):
                     h = blk.attentions[j].nhwc(h, ehs, out_for=last)
             if blk.upsamplers is not None:
                 h = blk.upsamplers[0].nhwc(h)
-        h = self.conv_norm_out.nhwc(h, ops.ACT_SILU, split=self.conv_out.in_split())
-        return self.conv_out.nhwc(h)
+        return self.conv_out.nhwc(h, gn=self.conv_norm_out.spec(h, ops.ACT_SILU))
 
     # ---- diffusers API ---------------------------------------------------------------------
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, return_dict: bool = True):

@@ -111,9 +111,10 @@ class Conv2d(nn.Conv2d, _Packed, _Operand):
                             self.weight, self.bias, sp, wsp, ph)
 
     def nhwc(self, x, *, pad=None, upsample=False, act=ops.ACT_NONE, residual=None, bias_override=None, stride=None, gn_groups=0,
-             out_dtype=ops.OUT_STREAM, out_split=1):
+             out_dtype=ops.OUT_STREAM, out_split=1, gn=None):
         """x [N,H,W,Cin8] (operand, or a stream tensor that is cast / split here) -> [N,Ho,Wo,Cout8]; channels beyond
-        out_channels are exact zeros."""
+        out_channels are exact zeros. gn (ops.GnSpec): x is the stream tensor a GroupNorm reads; the norm runs as this conv's patch
+        producer where the kernel can, as the separate apply pass otherwise (ops.conv2d)."""
         pw = self.packed()
         if bias_override is not None:
             pw = dataclasses.replace(pw, bias=bias_override)
@@ -121,17 +122,17 @@ class Conv2d(nn.Conv2d, _Packed, _Operand):
         if out_dtype == ops.OUT_STREAM and self.out_inner16 and ops.precise():
             out_dtype = ops.OUT_BF16
         return ops.conv2d(x, pw, stride=stride or self.stride[0], pad=p, upsample=upsample, act=act, residual=residual,
-                          gn_groups=gn_groups, out_dtype=out_dtype, out_split=out_split)
+                          gn_groups=gn_groups, out_dtype=out_dtype, out_split=out_split, gn=gn)
 
     def nhwc_multi(self, xs, *, pad=None, upsample=False, act=ops.ACT_NONE, residuals=None, stride=None, gn_groups=0,
-                   out_dtype=ops.OUT_STREAM, out_split=1):
+                   out_dtype=ops.OUT_STREAM, out_split=1, gn=None):
         """nhwc() of several inputs (the tile-shape groups of a tiled-VAE layer) in one launch where the kernel allows (ops.conv2d_multi)."""
         pw = self.packed()
         p = self.padding[0] if pad is None else pad
         if out_dtype == ops.OUT_STREAM and self.out_inner16 and ops.precise():
             out_dtype = ops.OUT_BF16
         return ops.conv2d_multi(list(xs), pw, stride=stride or self.stride[0], pad=p, upsample=upsample, act=act, residuals=residuals,
-                                gn_groups=gn_groups, out_dtype=out_dtype, out_split=out_split)
+                                gn_groups=gn_groups, out_dtype=out_dtype, out_split=out_split, gn=gn)
 
     def forward(self, x):  # NCHW compat
         y = self.nhwc(ops.nchw_to_nhwc(x.contiguous(), ops._round_up(self.in_channels, 8)))
@@ -166,6 +167,16 @@ class GroupNorm(nn.GroupNorm, _Packed):
 
     def stats(self, x):
         return ops.group_norm_stats(x, self.num_groups, self.eps)
+
+    def spec(self, x, act=ops.ACT_NONE) -> "ops.GnSpec":
+        """This norm (statistics of x included) as something a conv can run as its patch producer: conv.nhwc(x, gn=norm.spec(x, SILU))."""
+        mean, rstd, _ = self.stats(x)
+        return self.spec_stats(mean, rstd, act)
+
+    def spec_stats(self, mean, rstd, act=ops.ACT_NONE) -> "ops.GnSpec":
+        """The same with externally supplied per-(image, group) statistics (tiled VAE)."""
+        g, b = self._affine()
+        return ops.GnSpec(mean, rstd, g, b, self.num_groups, act)
 
     def apply_stats(self, x, mean, rstd, act=ops.ACT_NONE, split=1, also_cast=0):
         """Normalise with externally supplied per-(n, group) statistics (tiled VAE)."""

@@ -527,34 +527,94 @@ def _conv_gn(a: IgemmArgs, gn_groups: int, out_split: int, device):
     return partial
 
 
+class GnSpec:
+    """A GroupNorm waiting for its consumer: statistics (mean / rstd [nimg, G]; rows n of the tensor use image n % nimg), affine, activation.
+    conv2d(..., gn=spec) runs it as the conv's patch producer when the library says the problem qualifies (omgsr_igemm_gn_fusable: the
+    halo-tile kernel's spatial 3x3 form over a 16-bit stream tensor, plain operand and weight) - the apply pass and the conv's read of its
+    output disappear - and as the separate apply pass in front of the conv otherwise. Same values either way up to the 16-bit rounding the
+    apply pass performs too (the fused form evaluates x * scale + shift from the same fp32 (scale, shift) table)."""
+
+    def __init__(self, mean: torch.Tensor, rstd: torch.Tensor, gamma, beta, groups: int, act: int = ACT_NONE):
+        self.mean, self.rstd, self.gamma, self.beta, self.groups, self.act = mean, rstd, gamma, beta, groups, act
+        self._table = None
+
+    def table(self, channels: int) -> torch.Tensor:
+        """f32 [nimg, C, 2] = (rstd gamma, beta - mean rstd gamma): one tiny launch per GroupNorm, shared by every tile-shape group."""
+        if self._table is None:
+            nimg = self.mean.shape[0]
+            t = torch.empty((nimg, channels, 2), device=self.mean.device, dtype=torch.float32)
+            check(_lib.load().omgsr_groupnorm_scale_shift(self.mean.data_ptr(), self.rstd.data_ptr(), _ptr(self.gamma), _ptr(self.beta),
+                                                          t.data_ptr(), nimg, channels, self.groups, _stream()), "omgsr_groupnorm_scale_shift")
+            self._table = t
+        return self._table
+
+    def apply(self, x: torch.Tensor, split: int = 1) -> torch.Tensor:
+        """The separate pass: stream tensor -> normalised operand in the form the consumer reads."""
+        if self.mean.shape[0] != x.shape[0]:
+            return group_norm_apply_shared(x, self.mean, self.rstd, self.gamma, self.beta, self.groups, self.act, split=split)
+        return group_norm_apply(x, self.mean, self.rstd, self.gamma, self.beta, self.groups, self.act, split=split)
+
+
+def _gn_candidate(x: torch.Tensor, pw: PackedWeight) -> bool:
+    """Host-side part of the fusable test (the library decides the rest from the geometry): a 16-bit stream tensor, plain operand / weight."""
+    return x.dtype == _ACT and pw.split == 1 and pw.w_split == 1 and pw.mx is None and pw.R == 3 and pw.S == 3
+
+
+def _gn_fusable(a: IgemmArgs, gn: "GnSpec") -> bool:
+    return gn.act == ACT_SILU and bool(_lib.load().omgsr_igemm_gn_fusable(C.byref(a)))
+
+
+def _attach_gn(a: IgemmArgs, gn: "GnSpec", channels: int) -> torch.Tensor:
+    t = gn.table(channels)
+    a.gn_scale_shift, a.gn_nimg, a.gn_act, a.in_el = t.data_ptr(), t.shape[0], gn.act, EL_16
+    return t
+
+
 def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, int, int] | int = 1,
            upsample: bool = False, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
            gate: Optional[torch.Tensor] = None, out_dtype: int = OUT_STREAM, alpha: float = 1.0,
-           out: Optional[torch.Tensor] = None, gn_groups: int = 0, out_split: int = 1, sample_rows: int = 0) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, gn_groups: int = 0, out_split: int = 1, sample_rows: int = 0,
+           gn: Optional["GnSpec"] = None) -> torch.Tensor:
     """x [N,H,W,Cin] operand (or a stream tensor: cast / split here) -> [N,Ho,Wo,Cout]. pad = (top, bottom, left, right) on
     the (virtual) input. out_dtype: OUT_STREAM (a stream tensor: default), OUT_BF16 (a 16-bit operand for the next GEMM,
     `out_split` 2 = written as the two-term split) or OUT_F32. residual: a stream tensor of the output's shape.
     gn_groups > 0: the caller will GroupNorm the result with that many groups; when the kernel can, it emits the
-    (sum, sum of squares) partials from its epilogue and group_norm_stats() skips its read pass over the tensor."""
+    (sum, sum of squares) partials from its epilogue and group_norm_stats() skips its read pass over the tensor.
+    gn: x is the stream tensor a GroupNorm (+ SiLU) reads and the conv consumes the normalised tensor (GnSpec): fused into the conv's
+    patch producer where the library can, the apply pass in front of the conv otherwise."""
     a = IgemmArgs()
+    if gn is not None and not _gn_candidate(x, pw):
+        x, gn = gn.apply(x, pw.split), None
     x, out = _conv_args(a, x, pw, stride, pad, upsample, act, residual, gate, out_dtype, alpha, out, out_split, sample_rows)
+    keep = None
+    if gn is not None:
+        a.in_el = EL_16
+        if _gn_fusable(a, gn):
+            keep = _attach_gn(a, gn, x.shape[-1])
+        else:
+            x = gn.apply(x, pw.split)
+            a.in_ = x.data_ptr()
     partial = _conv_gn(a, gn_groups, out_split, x.device)
     _igemm(a, x.device, "omgsr_igemm(conv2d)")
+    del keep
     if partial is not None:
         out._omgsr_gn = (partial, gn_groups, out.data_ptr(), out._version)      # consumed by group_norm_stats(out)
     return out
 
 
 def conv2d_multi(xs, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, int, int] | int = 1, upsample: bool = False,
-                 act: int = ACT_NONE, residuals=None, out_dtype: int = OUT_STREAM, gn_groups: int = 0, out_split: int = 1):
+                 act: int = ACT_NONE, residuals=None, out_dtype: int = OUT_STREAM, gn_groups: int = 0, out_split: int = 1,
+                 gn: Optional["GnSpec"] = None):
     """conv2d of several inputs with ONE weight (the tile-shape groups of a tiled-VAE layer: each x is its own dense [T*N, h, w, C]
     tensor) through omgsr_igemm_multi: the problems that take the halo-tile kernel run as one launch, with the kernel choice and the
     fused GroupNorm statistics planned for the group. Same results as a conv2d call per input. Returns the list of outputs."""
     n = len(xs)
     if n == 1:
         return [conv2d(xs[0], pw, stride=stride, pad=pad, upsample=upsample, act=act, residual=None if residuals is None else residuals[0],
-                       out_dtype=out_dtype, gn_groups=gn_groups, out_split=out_split)]
+                       out_dtype=out_dtype, gn_groups=gn_groups, out_split=out_split, gn=gn)]
     lib = _lib.load()
+    if gn is not None and not all(_gn_candidate(x, pw) for x in xs):
+        xs, gn = [gn.apply(x, pw.split) for x in xs], None
     arr = (IgemmArgs * n)()
     keep, outs = [], []
     for i in range(n):
@@ -562,7 +622,19 @@ def conv2d_multi(xs, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, 
                             None, out_split, 0)
         keep.append(x)
         outs.append(out)
+        if gn is not None:
+            arr[i].in_el = EL_16
     check(lib.omgsr_igemm_multi_plan(arr, n), "omgsr_igemm_multi_plan")
+    if gn is not None:
+        # one form per layer: every tile-shape group runs the normalising patch producer, or the apply pass runs for all of them
+        if all(_gn_fusable(arr[i], gn) for i in range(n)):
+            for i in range(n):
+                keep.append(_attach_gn(arr[i], gn, keep[i].shape[-1]))
+        else:
+            for i in range(n):
+                y = gn.apply(keep[i], pw.split)
+                keep.append(y)
+                arr[i].in_ = y.data_ptr()
     partials = []
     for i in range(n):
         partials.append(_conv_gn(arr[i], gn_groups, out_split, outs[i].device))

@@ -127,6 +127,7 @@ class VAEHook:
         """Layer-synchronous execution over shape groups. groups[shape] = [T_g*N, h, w, C] (tile-major)."""
         res: Dict[tuple, list] = {k: [] for k in groups}
         gi = 0
+        pending = None          # a GroupNorm handed to the conv that follows it (ops.GnSpec): the conv's patch producer where the kernel can
         for op in seq:
             kind = op[0]
             if kind == "gn":
@@ -143,6 +144,16 @@ class VAEHook:
                 if record is not None:
                     record.append((mean, var))
                 gi += 1
+                first = next(iter(groups.values()))
+                is_conv3 = getattr(op[3], "kernel_size", None) == (3, 3)
+                if is_conv3 and first.dtype != torch.float32:
+                    # a 16-bit stream tensor into a 3x3 conv: the conv takes the norm (fused into its patch producer, or applied in front of
+                    # it: ops.conv2d_multi decides for the whole layer); the 1x1 shortcut reads the un-normalised tensor, which IS its operand
+                    pending = norm.spec_stats(mean, rstd, act)
+                    if op[4] is not None:
+                        for k in groups:
+                            res[k].append(op[4].nhwc(groups[k], pad=0))
+                    continue
                 for k in groups:       # rows (tile, image) share the image's statistics
                     if op[4] is not None:
                         groups[k], xc = norm.apply_stats(groups[k], mean, rstd, act, split=op[3].in_split(), also_cast=op[4].in_split())
@@ -151,8 +162,9 @@ class VAEHook:
                         groups[k] = norm.apply_stats(groups[k], mean, rstd, act, split=op[3].in_split())
             elif kind == "conv":
                 keys = list(groups)
-                for k, y in zip(keys, op[1].nhwc_multi([groups[k] for k in keys], **op[2])):
+                for k, y in zip(keys, op[1].nhwc_multi([groups[k] for k in keys], gn=pending, **op[2])):
                     groups[k] = y
+                pending = None
             elif kind == "res_push":
                 for k in groups:
                     res[k].append(op[1](groups[k]) if op[1] is not None else groups[k])
@@ -160,9 +172,10 @@ class VAEHook:
                 keys = list(groups)
                 xs, rs = [groups[k] for k in keys], [res[k].pop() for k in keys]
                 if op[3] is not None:
-                    outs = op[1].nhwc_multi(xs, residuals=rs, out_dtype=ops.OUT_BF16, out_split=op[3].in_split())
+                    outs = op[1].nhwc_multi(xs, residuals=rs, out_dtype=ops.OUT_BF16, out_split=op[3].in_split(), gn=pending)
                 else:
-                    outs = op[1].nhwc_multi(xs, residuals=rs, gn_groups=op[2])
+                    outs = op[1].nhwc_multi(xs, residuals=rs, gn_groups=op[2], gn=pending)
+                pending = None
                 for k, y in zip(keys, outs):
                     groups[k] = y
             elif kind == "attn_res":

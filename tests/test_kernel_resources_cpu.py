@@ -59,11 +59,13 @@ def test_the_tight_kernels_are_where_design_says(tables):
     for k, b in built.items():
         if k.startswith(("igemm_halo", "igemm_dma", "igemm_p8", "igemm_gmx", "attn_kernel")):
             assert b["occupancy"] >= 2, (k, b)
-    # template arguments end with (TAPS, MX, FLAT): nine-tap MX instantiations, spatial and FLAT form
-    mx = [b for k, b in built.items() if k.startswith("igemm_halo") and (k.endswith(",9,1,0>") or k.endswith(",9,1,1>") or k.endswith(",9,1,2>"))]
+    # template arguments end with (TAPS, MX, FLAT, GNF): nine-tap MX instantiations, spatial and FLAT form
+    mx = [b for k, b in built.items() if k.startswith("igemm_halo") and (k.endswith(",9,1,0,0>") or k.endswith(",9,1,1,0>") or k.endswith(",9,1,2,0>"))]
     assert len(mx) == 6 and all(b["spill_vgpr"] <= 16 and b["scratch"] <= 64 for b in mx), mx
-    flat = [b for k, b in built.items() if k.startswith("igemm_halo") and (k.endswith(",1>") or k.endswith(",2>"))]    # the FLAT form (22- and 27-piece patch): 9 fragment-address registers instead of 36
+    flat = [b for k, b in built.items() if k.startswith("igemm_halo") and (k.endswith(",1,0>") or k.endswith(",2,0>"))]    # the FLAT form (22- and 27-piece patch): 9 fragment-address registers instead of 36
     assert len(flat) == 12 and all(b["spill_vgpr"] <= 4 for b in flat), flat
+    gn = [b for k, b in built.items() if k.startswith("igemm_halo") and k.endswith(",9,0,0,1>")]      # GroupNorm apply as the patch producer (round 5): no spills, two workgroups per CU
+    assert len(gn) == 8 and all(b["spill_vgpr"] == 0 and b["scratch"] == 0 for b in gn), gn
     for k, b in built.items():
-        if k.startswith("igemm_halo") and not k.endswith(",9,1,0>") and not k.endswith(",1>") and not k.endswith(",2>") and ",0,1,0,9,0,0>" not in k:      # (the s_setprio A/B instantiation spills 8)
+        if k.startswith("igemm_halo") and not k.endswith(",9,1,0,0>") and not k.endswith(",1,0>") and not k.endswith(",2,0>") and ",0,1,0,9,0,0,0>" not in k:      # (the s_setprio A/B instantiation spills 8)
             assert b["spill_vgpr"] == 0, (k, b)

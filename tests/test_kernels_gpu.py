@@ -784,3 +784,95 @@ def test_linear_attention_norm_bit_repeatability():
     check("groupnorm stats", lambda: ops.group_norm_stats(xg, 32, 1e-6), 30)
     xl = (torch.randn(1, 36864, 640, generator=g)).to(dt).to(DEV)
     check("layernorm", lambda: ops.layer_norm(xl, None, None, 1e-5), 30)
+
+
+# ---- GroupNorm apply (+ SiLU) as the conv's patch producer (round 5: omgsr_igemm_args.gn_scale_shift) ---------------
+# N rows, images (rows share the statistics of image n % nimg), C, Cout, H, W, act (1 = SiLU), residual, fusable expected
+GN_CONV_CASES = [
+    (12, 4, 128, 128, 64, 64, 1, True, True),       # (the halo-tile kernel wants >= 192 workgroup tiles: 16 per 64 x 64 image)
+    (12, 2, 128, 128, 43, 86, 1, False, True),      # tile-major rows sharing two images' statistics, ragged map
+    (8, 2, 256, 128, 64, 96, 1, True, True),
+    (4, 2, 512, 512, 48, 64, 1, False, False),      # four column tiles: the shipped policy keeps the apply pass (OMGSR_GN_FUSE_MAX_COUT)
+    (4, 2, 512, 128, 96, 64, 1, False, True),
+    (12, 1, 1024, 128, 64, 64, 1, False, True),     # the largest (scale, shift) table the kernel holds (8 KB)
+    (2, 2, 128, 3, 128, 192, 1, False, True),       # conv_out: the narrow shape
+    (12, 4, 128, 128, 64, 64, 0, False, False),     # no activation: SiLU is the one the producer applies -> apply pass
+    (4, 1, 64, 128, 96, 160, 1, True, True),        # two K chunks only: the first one is normalised in the prologue
+    (4, 2, 32, 128, 96, 160, 1, False, True),       # ONE chunk: prologue only
+    (1, 1, 128, 128, 16, 16, 1, False, False),      # too few tiles for the halo kernel: the apply pass runs in front of the conv
+    (30, 2, 128, 256, 38, 38, 1, True, False),      # narrow map: FLAT form, no normalising instantiation -> apply pass
+    (12, 1, 2048, 128, 64, 64, 1, False, False),    # table too large -> apply pass
+]
+
+
+def _gn_ref(x, mean, rstd, gamma, beta, G, act, nimg):
+    N, Cc = x.shape[0], x.shape[1]
+    idx = torch.arange(N) % nimg
+    m = mean[idx].repeat_interleave(Cc // G, 1)[:, :, None, None]
+    r = rstd[idx].repeat_interleave(Cc // G, 1)[:, :, None, None]
+    y = (x - m) * r * gamma[None, :, None, None] + beta[None, :, None, None]
+    return F.silu(y) if act else y
+
+
+@pytest.mark.parametrize("case", GN_CONV_CASES)
+def test_conv3x3_groupnorm_fused_into_the_patch_producer(case):
+    """conv2d(x, gn=spec) == conv2d(group_norm_apply(x)) (the same values: one fp32 (scale, shift) table, one 16-bit rounding of the
+    normalised operand) and == the fp32 torch reference within the 16-bit operand's rounding; zero padding applies to the NORMALISED map."""
+    ops = _ops()
+    from omgsr_amd import _lib
+    import ctypes as C
+    N, nimg, Cc, Cout, H, W, act, use_res, expect_fused = case
+    G = 32
+    x = rnd(N, Cc, H, W, seed=11) * 1.5 + 0.25
+    w = rnd(Cout, Cc, 3, 3, seed=12, scale=1.0 / math.sqrt(9 * Cc))
+    b = rnd(Cout, seed=13)
+    gamma, beta = 1.0 + 0.2 * rnd(Cc, seed=14), 0.3 * rnd(Cc, seed=15)
+    mean, rstd = 0.25 + 0.1 * rnd(nimg, G, seed=16), (1.0 / 1.5) * (1.0 + 0.1 * rnd(nimg, G, seed=17)).abs()
+    xn = _gn_ref(x, mean, rstd, gamma, beta, G, act, nimg)
+    ref = F.conv2d(F.pad(xn, (1, 1, 1, 1)), w, b)
+    res = None
+    if use_res:
+        res = rnd(*ref.shape, seed=18)
+        ref = ref + res
+    pw = ops.pack_conv_weight(w, b, device=DEV)
+    xd = nhwc(x)
+    spec = ops.GnSpec(mean.to(DEV), rstd.to(DEV), gamma.to(DEV), beta.to(DEV), G, ops.ACT_SILU if act else ops.ACT_NONE)
+    # what the library says about this problem
+    a = _lib.IgemmArgs()
+    ops._conv_args(a, xd, pw, 1, 1, False, ops.ACT_NONE, None, None, ops.OUT_STREAM, 1.0, None, 1, 0)
+    a.in_el = ops.EL_16
+    assert ops._gn_fusable(a, spec) == expect_fused
+    rd = None if res is None else nhwc(res)
+    y = ops.conv2d(xd, pw, pad=1, residual=rd, gn=spec, gn_groups=32 if Cout >= 96 else 0)
+    y_unfused = ops.conv2d(spec.apply(xd), pw, pad=1, residual=rd)
+    assert_close(to_nchw(y)[:, :Cout], ref, "gn-fused conv vs fp32 reference")
+    # against the two-pass form: identical operand bits are expected (same table, same expression); allow one 16-bit ulp of the OUTPUT
+    # for a contraction the compiler may have fused differently in the two kernels
+    d = (y.float() - y_unfused.float()).abs().max().item()
+    assert d <= 2 ** -7 * max(1.0, float(ref.abs().max())), f"fused vs apply + conv differ by {d}"
+    if Cout >= 96 and expect_fused:                  # the fused conv still leaves ITS output's GroupNorm statistics
+        m2, r2, _ = ops.group_norm_stats(y, 32, 1e-6)
+        yr = y.float().cpu().permute(0, 3, 1, 2)
+        mr = yr.reshape(N, 32, -1).mean(-1)
+        assert torch.allclose(m2.cpu(), mr, atol=2e-3, rtol=1e-3)
+
+
+def test_conv3x3_groupnorm_fused_multi_launch():
+    """The tile-shape groups of one tiled-VAE layer through conv2d_multi(gn=...): one launch, every group normalised with the statistics of
+    its rows' images (row r of a tile-major group belongs to image r % nimg)."""
+    ops = _ops()
+    Cc, Cout, G, nimg = 128, 128, 32, 2
+    w = rnd(Cout, Cc, 3, 3, seed=21, scale=1.0 / math.sqrt(9 * Cc))
+    b = rnd(Cout, seed=22)
+    gamma, beta = 1.0 + 0.2 * rnd(Cc, seed=23), 0.3 * rnd(Cc, seed=24)
+    mean, rstd = 0.1 * rnd(nimg, G, seed=25), (1.0 + 0.1 * rnd(nimg, G, seed=26)).abs()
+    shapes = [(8, 86, 86), (4, 86, 64), (4, 64, 86), (2, 64, 64)]
+    xs = [rnd(n, Cc, h, ww, seed=30 + i) for i, (n, h, ww) in enumerate(shapes)]
+    rs = [rnd(n, Cout, h, ww, seed=40 + i) for i, (n, h, ww) in enumerate(shapes)]
+    pw = ops.pack_conv_weight(w, b, device=DEV)
+    spec = ops.GnSpec(mean.to(DEV), rstd.to(DEV), gamma.to(DEV), beta.to(DEV), G, ops.ACT_SILU)
+    ys = ops.conv2d_multi([nhwc(x) for x in xs], pw, pad=1, residuals=[nhwc(r) for r in rs], gn=spec, gn_groups=32)
+    for x, r, y in zip(xs, rs, ys):
+        ref = F.conv2d(F.pad(_gn_ref(x, mean, rstd, gamma, beta, G, 1, nimg), (1, 1, 1, 1)), w, b) + r
+        assert_close(to_nchw(y), ref, "gn-fused multi conv")
+        assert getattr(y, "_omgsr_gn", None) is not None
