@@ -47,7 +47,7 @@ WORKLOADS = {
 }
 DTYPES = {"fp32": "float32", "fp16": "float16", "bf16": "bfloat16"}
 IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel", 6: "igemm_halo_kernel<TAPS=4>", 7: "igemm_halo_multi_kernel", 8: "igemm_halo_multi_kernel<TAPS=4>", 9: "igemm_gmx_kernel",
-                  10: "igemm_halo_kernel<GN>", 11: "igemm_halo_multi_kernel<GN>"}
+                  10: "igemm_halo_kernel<GN>", 11: "igemm_halo_multi_kernel<GN>", 12: "igemm_halo_multi_kernel(split-K)+splitk_reduce_kernel"}
 
 
 def parse(argv=None):
@@ -298,6 +298,8 @@ def main():
             for name in ("fp32", "fp16", "bf16"):
                 if name != args.weight_dtype:
                     others[name] = tier_leg(getattr(torch, DTYPES[name]), device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img)
+            # the tier a checkpoint with out-of-fp16-range activations would actually run (precision.RangeFallback, forced)
+            others["fp32_range_fallback"] = tier_leg(torch.float32, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img, range_fallback=True)
             extra["other_tiers"] = others
             ops.set_compute_dtype(wdtype)
 
@@ -398,9 +400,13 @@ def attach_traffic(roofline, per_kernel, fam, krows):
     mine = {k: v["launches"] for k, v in per_kernel.items()}
     sk = mine.get("igemm_dma_kernel(split-K)+splitk_reduce_kernel", 0)
     expect = {k: v for k, v in mine.items() if "(split-K)" not in k}
+    hsk = mine.get("igemm_halo_multi_kernel(split-K)+splitk_reduce_kernel", 0)      # (round 5: chunk ranges of the halo-tile kernel as one launch group)
     if sk:
         expect["igemm_dma_kernel"] = expect.get("igemm_dma_kernel", 0) + sk
-        expect["splitk_reduce_kernel"] = sk
+    if hsk:
+        expect["igemm_halo_multi_kernel"] = expect.get("igemm_halo_multi_kernel", 0) + hsk
+    if sk or hsk:
+        expect["splitk_reduce_kernel"] = sk + hsk
     ok_all, total_meas, total_n = True, 0.0, 0
     for name, n in expect.items():
         row = krows.get(name)
@@ -416,7 +422,7 @@ def attach_traffic(roofline, per_kernel, fam, krows):
         if tgt is not None:
             tgt["traffic_bytes_per_launch"] = round(row["hbm_bytes_per_launch"]) if ok else None
             tgt["traffic_launches_seen"] = seen
-            if ok and tgt["bytes_per_launch"] > 0 and "(split-K)" not in name and not (name == "igemm_dma_kernel" and sk):
+            if ok and tgt["bytes_per_launch"] > 0 and "(split-K)" not in name and not (name == "igemm_dma_kernel" and sk) and not (name == "igemm_halo_multi_kernel" and hsk):
                 tgt["traffic_over_algorithmic"] = round(row["hbm_bytes_per_launch"] / tgt["bytes_per_launch"], 3)
     n_igemm = sum(n for k, n in expect.items() if k.startswith(("igemm", "splitk")))
     if ok_all and total_n == n_igemm and roofline["launches"] > 0:
@@ -582,11 +588,13 @@ def cpu_leg_f(device, tiers, side, tile, overlap):
     del ov, of
     parity = {}
     for tier in tiers:
-        wdtype = getattr(torch, DTYPES[tier])
+        wdtype = getattr(torch, DTYPES["fp32" if tier.startswith("fp32") else tier])
         pv, pf = AutoencoderKL(**FLUX_VAE_CONFIG), FluxTransformer2DModel(**cfg)
         pv.load_state_dict(sdv); pf.load_state_dict(sdf)
         pf.round_timestep_to_weight_dtype = False          # the fp32 oracle conditions on the exact sigma(t*)
         pipe = OMGSR_F_Infer(None, None, device, wdtype, 244, 1.0, vae=pv, flux_transformer=pf)
+        if tier == "fp32_range_fallback":
+            pipe.range_fallback.enter()
         pipe.vae.posterior_noise = eps.to(device)
         with torch.no_grad():
             got, _ = pipe(x.to(device=device, dtype=wdtype), pe.to(device=device, dtype=wdtype), pooled.to(device=device, dtype=wdtype),
@@ -597,6 +605,8 @@ def cpu_leg_f(device, tiers, side, tile, overlap):
                               "the full FLUX VAE; the full-depth comparison is tests/test_flux_fullsize_gpu.py",
                         "rel_l2": round(e, 6), "psnr_db": round(p, 2), "north_star": "rel_l2 <= 1e-3 and psnr >= 60 dB",
                         "meets_north_star": bool(e <= 1e-3 and p >= 60.0)}
+        if tier == "fp32_range_fallback":
+            pipe.range_fallback.reset()
         del pipe, pv, pf
         torch.cuda.empty_cache()
     base = {"value": round(1.0 / secs, 5), "unit": "images/s (reduced-depth DiT: 20.3 of the full pipeline's 89.8 TFLOP)", "cores": cores, "kind": "port",
@@ -620,9 +630,16 @@ def f1024_record(args, device, _lib):
     pipe, _ = build_f(device, 0, 1, torch.float32)
     rec["setup_s"] = round(time.time() - t0, 1)
     nsteps = 3
-    for tier, B in (("fp32", 8), ("bf16", 8)):
+    # "fp32_range_fallback": the accurate tier as a real FLUX checkpoint would run it: FLUX activations leave the fp16 range
+    # (the reason the reference defaults to bf16, infer/infer_omgsr_f.py:137), the range guard fires on the first image and the pipeline
+    # stays on bf16 operands with every operand and weight split. Forced here (seeded weights never clip) with range_fallback.enter().
+    for key, B in (("fp32", 8), ("fp32_range_fallback", 8), ("bf16", 8)):
+        tier = "fp32" if key.startswith("fp32") else key
         wd = getattr(torch, DTYPES[tier])
+        if key == "fp32_range_fallback":
+            pipe.range_fallback.enter()
         if tier != "fp32":      # the same modules, cast in place to the reference's default dtype
+            pipe.range_fallback.reset()
             pipe = OMGSR_F_Infer(None, None, device, wd, 244, 1.0, vae=pipe.vae, flux_transformer=pipe.flux_transformer)
         inp = make_inputs(family, side, B, tile, 0, device, wd)
         pipe.vae.posterior_noise = inp["eps"].to(device)
@@ -636,14 +653,17 @@ def f1024_record(args, device, _lib):
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t1
         roofline, extra = (None, {}) if args.no_roofline else roofline_leg(_lib, step, args, tflop, B, 1, elapsed, False, wd, workload="f1024",
-                                                                           weight_dtype=tier, steps=nsteps)
-        rec[tier] = {"images_per_s": round(B * nsteps / elapsed, 3), "ms_per_step": round(elapsed / nsteps * 1e3, 3), "batch": B, "steps": nsteps,
-                     "warmup": 1, "roofline": roofline, **extra}
+                                                                           weight_dtype=key, steps=nsteps)
+        rec[key] = {"images_per_s": round(B * nsteps / elapsed, 3), "ms_per_step": round(elapsed / nsteps * 1e3, 3), "batch": B, "steps": nsteps,
+                    "warmup": 1, "roofline": roofline, **extra}
+        if key == "fp32_range_fallback":
+            rec[key]["mode"] = "fp32 stream, bf16 MFMA operands, every operand and weight split (3 K segments everywhere); sticky"
+            rec[key]["sticky"] = bool(pipe.range_fallback.sticky)
         del step, inp
     del pipe
     torch.cuda.empty_cache()
     if not args.no_cpu_baseline:
-        rec["cpu_baseline"], par = cpu_leg_f(device, ["fp32", "bf16"], side, tile, overlap)
+        rec["cpu_baseline"], par = cpu_leg_f(device, ["fp32", "fp32_range_fallback", "bf16"], side, tile, overlap)
         for tier, pr in par.items():
             rec[tier]["parity"] = pr
     return rec
@@ -697,11 +717,16 @@ def latency_b1_record(args, device, _lib):
     return rec
 
 
-def tier_leg(wdtype, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img):
-    """The same workload in another --weight_dtype tier: a short timed run + parity of image 0 against the same oracle output."""
+def tier_leg(wdtype, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img, range_fallback=False):
+    """The same workload in another --weight_dtype tier: a short timed run + parity of image 0 against the same oracle output.
+    range_fallback (accurate tier only): the mode a checkpoint whose activations leave the fp16 range runs in - forced
+    with pipe.range_fallback.enter(): bf16 operands (fp32's exponent range), EVERY operand and weight as a two-term split = three K
+    segments on every layer, sticky - instead of waiting for an fp16 operand to clip."""
     import torch
     from omgsr_amd.testing import psnr, rel_l2
     pipe, _ = build_s(device, 0, 1, wdtype)
+    if range_fallback:
+        pipe.range_fallback.enter()
     if tiled_vae:
         pipe._init_tiled_vae(encoder_tile_size=256, decoder_tile_size=64)
     pipe.vae.posterior_noise = inp["eps"].to(device)
@@ -719,6 +744,10 @@ def tier_leg(wdtype, device, family, side, B, tile, overlap, tiled_vae, inp, ora
     if oracle_img is not None:
         got = out[:1].float().cpu()
         leg.update(rel_l2=round(rel_l2(got, oracle_img), 6), psnr_db=round(psnr(got, oracle_img), 2))
+    if range_fallback:
+        leg["mode"] = "fp32 stream, bf16 MFMA operands, every operand and weight split (3 K segments everywhere); sticky"
+        leg["sticky"] = bool(pipe.range_fallback.sticky)
+        pipe.range_fallback.reset()
     del pipe
     torch.cuda.empty_cache()
     return leg

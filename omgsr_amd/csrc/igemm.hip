@@ -28,6 +28,7 @@ namespace omgsr {
 int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, bool phase = false);
 int igemm_halo_launch_multi(const omgsr_igemm_args* a, const IgemmGeo* g0, int count, hipStream_t st, bool phase);
+int igemm_halo_launch_splitk(const omgsr_igemm_args& a, const IgemmGeo& g0, int splits, hipStream_t st);     // igemm_halo_multi.hip
 bool igemm_p8_wanted(const omgsr_igemm_args& a, const IgemmGeo& g);
 int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 bool igemm_gmx_ok(const omgsr_igemm_args& a);
@@ -250,6 +251,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
     }
     const int64_t ldo = p.out_ld > 0 ? p.out_ld : p.Cout;
     float amax = 0.0f;          // fp16 range guard, as in the fused epilogues: largest magnitude written as a 16-bit value
+    if constexpr (std::is_same<T, f16_t>::value) {
+        if (p.out_mx) {         // the mixed-precision operand form of the next GEMM (Cout % 64 == 0: whole octets), as the fused epilogues write it
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = v[e];
+                if (p.gate) x *= p.gate[n + e];
+                if (p.residual) x += p.res_el == OMGSR_EL_F32 ? ((const float*)p.residual)[(int64_t)m * p.Cout + n + e]
+                                                               : (float)((const T*)p.residual)[(int64_t)m * p.Cout + n + e];
+                v[e] = x;
+                amax = fmaxf(amax, fabsf(x));
+            }
+            store8_mx<T>(p.out, (int64_t)m * 4 * p.Cout, p.Cout, n, v);
+            if (p.overflow_flag && amax > 65504.0f) atomicOr(p.overflow_flag, 1u);
+            if (p.overflow_flag && amax > 448.0f) atomicOr(p.overflow_flag, 2u);
+            return;
+        }
+    }
     for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
         float x = v[e];
         if (p.gate) x *= p.gate[n + e];
@@ -271,14 +289,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
 
 bool use_halo(const omgsr_igemm_args& a);
 bool use_halo_phase(const omgsr_igemm_args& a);
+int halo_splitk_plan(const omgsr_igemm_args& a);
+
+// Split-K for the halo-tile kernel (round 5: the reference's own operating point is ONE 128 -> 512 image per call, infer/infer_omgsr_s.py:92 - its 3x3
+// convs are 16 ... 64 workgroup tiles on 512 slots, 180 ... 1080 K-steps each). The contraction is cut into up to 8 ranges of 32-channel chunks; every range
+// runs as one member of a igemm_halo_multi_kernel launch group (same weights, its own chunk range in IgemmGeo.cc0 / cc1, an fp32 partial tile as
+// output) and splitk_reduce_kernel folds the partials into the real epilogue. A mixed-precision problem is cut on both sides of its fp16 / fp8 boundary
+// (equal K-step counts: the fp8 chunks cover twice the channels), never across it. `a` is the policy view. OMGSR_HALO_SPLITK=0 for A/B.
+int halo_splitk_plan(const omgsr_igemm_args& a) {
+    static const char* off = getenv("OMGSR_HALO_SPLITK");
+    if (off && off[0] == '0') return 1;
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    if (a.in_ld != 0 || a.gn_scale_shift || a.out_layout != OMGSR_LAYOUT_NHWC || a.act == OMGSR_ACT_GEGLU || logical_cols < 96 || a.upsample ||
+        a.group_tiles != 0 || a.batch != 1) return 1;
+    const int tiles = omgsr::igemm_halo_tiles(a);
+    static const char* mt = getenv("OMGSR_HALO_SPLITK_MAX_TILES");
+    static const int max_tiles = mt ? atoi(mt) : 128;                  // one quarter of the 512 workgroup slots
+    if (tiles <= 0 || tiles >= max_tiles) return 1;
+    const int nk = a.Cin / 32;
+    const bool mx = a.mx_chunks16 > 0;
+    static const char* tg = getenv("OMGSR_HALO_SPLITK_TARGET");
+    static const int target = tg ? atoi(tg) : 512;                     // aim at ~512 workgroups: two per CU (256 ... 768 measured within 1 %)
+    int splits = target / tiles;
+    if (splits > 8) splits = 8;
+    if (mx) {
+        splits &= ~1;
+        const int n16 = a.mx_chunks16, n8 = nk - n16;
+        while (splits >= 2 && (n16 / (splits / 2) < 2 || n8 / (splits / 2) < 2)) splits -= 2;
+    } else {
+        while (splits >= 2 && nk / splits < 2) --splits;
+    }
+    return splits < 2 ? 1 : splits;
+}
 
 // Split-K policy: small-M problems whose 256x128 tiles cannot fill the 256 CUs but whose contraction is long.
 int splitk_plan(const omgsr_igemm_args& a_real, int64_t M64) {
     const omgsr_igemm_args a = policy_view(a_real);
     if (omgsr::g_batch_invariant) M64 = (int64_t)a.N * a.Ho * a.Wo;
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
-    if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || (a.in_ld % 32) || logical_cols < 96 || a.mx_chunks16 > 0 || a.out_mx) return 1;      // (the reduce pass writes plain / split outputs only)
-    if (use_halo(a) || use_halo_phase(a)) return 1;   // the halo-tile kernel takes the problem (and owns the fused GroupNorm statistics)
+    if (use_halo_phase(a)) return 1;
+    if (use_halo(a)) return halo_splitk_plan(a);      // the halo-tile kernel takes the problem: whole (it then owns the fused GroupNorm statistics) or, when its tiles
+                                                      // cannot fill the chip, as up to 8 chunk ranges of the contraction (round 5)
+    if (a.batch != 1 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cin % 32) || (a.in_ld % 32) || logical_cols < 96 || a.mx_chunks16 > 0) return 1;
+    if (a.out_mx && a.act == OMGSR_ACT_GEGLU) return 1;               // (the reduce pass writes the MX form for plain columns only)
     const int nk = a.K_pad / 32;
     const int64_t tiles = ((M64 + 255) / 256) * ((logical_cols + 127) / 128);
     const int slots = 512;                                             // two 256 x 128 workgroups per CU
@@ -469,7 +522,7 @@ void work_of(const omgsr_igemm_args& a, double* flops, double* bytes) {
 }
 
 Geo geo_of(const omgsr_igemm_args& a) {
-    Geo g;
+    Geo g{};
     g.M = (int)((int64_t)a.N * a.Ho * a.Wo);
     g.HoWo = a.Ho * a.Wo;
     g.Hv = a.H << a.upsample;
@@ -563,7 +616,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     }
     const int64_t M64 = (int64_t)a.N * a.Ho * a.Wo;
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
-    Geo g;
+    Geo g{};
     g.M = (int)M64;
     g.HoWo = a.Ho * a.Wo;
     g.Hv = a.H << a.upsample;
@@ -588,9 +641,15 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         const int splits = splitk_plan(a, M64);
         if (splits > 1) {
             if (a.gn_partial) return OMGSR_E_BADARG;        // the reduce pass does not emit GroupNorm statistics (omgsr_igemm_gn_slots says so)
-            g.splits = splits;
-            ts.rec.variant = 4;
-            const int rc = omgsr::igemm_dma_launch(a, g, st);
+            int rc;
+            if (use_halo(a)) {                       // chunk ranges of the halo-tile kernel as one launch group
+                ts.rec.variant = 12;
+                rc = omgsr::igemm_halo_launch_splitk(a, g, splits, st);
+            } else {
+                g.splits = splits;
+                ts.rec.variant = 4;
+                rc = omgsr::igemm_dma_launch(a, g, st);
+            }
             if (rc != 0) return rc;
             const int ldw = ((logical_cols + 127) / 128) * 128;
             const int64_t items = M64 * ((a.Cout + 7) / 8);

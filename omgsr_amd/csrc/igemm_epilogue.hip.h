@@ -442,6 +442,8 @@ struct IgemmGeo {
                     // prologue / epilogue run at priority 0, so the co-resident workgroup's MFMA stream is not delayed by epilogue VALU / LDS traffic
     int flat;       // halo-tile kernel, FLAT form (narrow maps, W <= 45): pitch P = W + 2 of the flattened padded map a tile walks (256 consecutive
                     // positions per workgroup; the nine taps are the uniform shifts dy P + dx); 0 = the 8 x 32 spatial tile
+    int cc0, cc1;   // halo-tile kernel, split-K (round 5): this launch-group member runs the 32-channel chunks [cc0, cc1) of the contraction and writes
+                    // an fp32 partial tile (cc1 == 0: the whole contraction). A range never straddles the fp16 / fp8 boundary of an MX problem
     int interleave; // halo-tile kernel, phase form: 1 = the four output phases of a tile are consecutive logical blocks of ONE x-only grid
                     // (they share an XCD's L2: the low-res patch is fetched from HBM once, not four times); 0 = blockIdx.y = phase
 };

@@ -22,6 +22,7 @@
 #include "../../include/omgsr_hip.h"
 #include "igemm_epilogue.hip.h"
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 namespace {
@@ -137,8 +138,11 @@ __global__ __launch_bounds__(256, 2) void igemm_gmx_kernel(const omgsr_igemm_arg
         // only what the PREVIOUS step issued may still be in flight; lgkmcnt(0): this wave's fragment reads of the previous step have
         // returned before it passes the barrier that lets the others overwrite that stage (see igemm_halo_body.hip.h)
         if (kt + 1 < nk) {
+            static_assert(PIECES >= 3 && PIECES <= 6, "counted wait");
             if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            else if constexpr (PIECES == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            else if constexpr (PIECES == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void igemm_gmx_kernel(const omgsr_igemm_arg
                     // between the fp16 and the fp8 loop. Dependent MFMAs on one accumulator are 7 instructions of 16 passes apart.
                     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
                                  : "+v"(acc[i][j]) : "v"(b8[j]), "v"(a8[i]), "v"(sw), "v"(sa));   // transposed tile
-                if (i == FM / 2 - 1) {               // this step's LDS-DMA pieces behind the first half of its MFMAs
+                if (i == (FM > 1 ? FM / 2 - 1 : 0)) {               // this step's LDS-DMA pieces behind the first half of its MFMAs (one row block: behind all of them)
                     __builtin_amdgcn_sched_barrier(0);
                     if (kt + 2 < nk) issue(soff_next2);
                     __builtin_amdgcn_sched_barrier(0);
@@ -254,8 +258,15 @@ int igemm_gmx_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     const int64_t nt = (logical_cols + 127) / 128;
     const int64_t t256 = (int64_t)((g.M + 255) / 256) * nt, t192 = (int64_t)((g.M + 191) / 192) * nt;
     auto eff = [](int64_t tiles) { const int64_t rounds = (tiles + 511) / 512; return (double)tiles / (double)(rounds * 512); };
-    static const char* bm = getenv("OMGSR_GMX_BM");              // A/B runs: "256" | "192"
-    const bool force192 = bm && bm[0] == '1', force256 = bm && bm[0] == '2';
+    static const char* bm = getenv("OMGSR_GMX_BM");              // A/B runs: "256" | "192" | "128" | "64"
+    const bool force192 = bm && !strcmp(bm, "192"), force256 = bm && !strcmp(bm, "256");
+    // Small-M regime (round 5: one image per call, M = 64 ... 4096 token rows): a handful of 256-row tiles leaves most CUs idle AND makes every
+    // K-step of the few busy ones 16 MFMAs long on one wave per SIMD. 64- / 128-row tiles (one / two 32-row fragments per wave) shorten the
+    // step and quadruple the workgroups; everything is L2-resident at this size, so the extra weight reads cost nothing.
+    if (!force256 && !force192) {
+        if ((bm && !strcmp(bm, "64")) || (!bm && t256 < 64)) return launch_gmx<64>(a, g, st);
+        if ((bm && !strcmp(bm, "128")) || (!bm && t256 < 160)) return launch_gmx<128>(a, g, st);
+    }
     if (!force256 && (force192 || (eff(t256) < 0.78 && eff(t192) > eff(t256) + 0.1))) return launch_gmx<192>(a, g, st);
     return launch_gmx<256>(a, g, st);
 }

@@ -160,6 +160,15 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
                        ? reinterpret_cast<const unsigned char*>(wt + (int64_t)(n0 + 16 * (wave * BPW + i) + lrow) * 32 + kc * 8)
                        : reinterpret_cast<const unsigned char*>(g_zero_page_h);
     const int64_t b_step = (int64_t)p.Cout_pad * 64;       // bytes between consecutive (chunk, tap) slices
+    // split-K (IgemmGeo.cc0 / cc1): this workgroup's share of the contraction is the chunk range [cbeg, ncc); patch and weight streams start there
+    const int cbeg = g.cc1 > 0 ? g.cc0 : 0;
+    if (cbeg > 0) {
+#pragma unroll
+        for (int i = 0; i < APW; ++i) a_ptr[i] += (int64_t)a_inc[i] * cbeg;
+#pragma unroll
+        for (int i = 0; i < BPW; ++i)
+            if ((wave * BPW + i) * 16 < BNK) b_ptr[i] += b_step * TAPS * cbeg;
+    }
 
     auto issue_a = [&](int buf, const int chunk) {
         if (chunk == wrap_at) {
@@ -221,8 +230,8 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int ncc = g.nk;                  // 32-channel chunks
-    const int nsteps = ncc * TAPS;         // >= TAPS
+    const int ncc = g.cc1 > 0 ? g.cc1 : g.nk;      // (one past) the last 32-channel chunk this workgroup runs
+    const int nsteps = ncc * TAPS;         // K-step index s = chunk * TAPS + tap is absolute: only differences and comparisons with nsteps are used
 
     // The first versions of this loop were instruction-issue bound (profiles/r01_pmc_igemm.md §6: 5.3 VALU +
     // 4.4 SALU per MFMA, mostly LDS address arithmetic and tap bookkeeping). Everything is now static:
@@ -248,7 +257,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         }
 
     if constexpr (ABL != 2) {
-        issue_a(0, 0);
+        issue_a(0, cbeg);
         issue_b(0);
         issue_b(1);
     }
@@ -263,7 +272,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             u32x4_t raw; f32x4_t tb[4];
-            gn_read(i, 0, 0, raw, tb);
+            gn_read(i, 0, cbeg, raw, tb);
             *gn_slot(i, 0) = gn_math(i, raw, tb);
         }
     }
@@ -407,10 +416,11 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
     };
     if (g.main_prio == 1) __builtin_amdgcn_s_setprio(1);
     else if (g.main_prio == 2) __builtin_amdgcn_s_setprio(2);
-    int cc = 0;
-    for (; cc < n16; cc += 2) {
+    int cc = cbeg;
+    const int e16 = n16 < ncc ? n16 : ncc;          // (a split-K range lies on one side of the fp16 / fp8 boundary, so patch parity restarts at 0 on both)
+    for (; cc < e16; cc += 2) {
         chunk(std::integral_constant<int, 0>{}, std::false_type{}, cc);
-        if (cc + 1 < n16) chunk(std::integral_constant<int, 1>{}, std::false_type{}, cc + 1);
+        if (cc + 1 < e16) chunk(std::integral_constant<int, 1>{}, std::false_type{}, cc + 1);
     }
     if constexpr (MX && std::is_same<T, f16_t>::value && !NARROW && ABL == 0 && !PRIO) {
         // the fp8 segments of an MX problem (mx_chunks16 even, so the patch parity starts over at 0; n16 == ncc otherwise)

@@ -54,4 +54,37 @@ int igemm_halo_launch_multi(const omgsr_igemm_args* a, const IgemmGeo* g0, const
     return (int)hipGetLastError();
 }
 
+// Split-K (igemm.hip: halo_splitk_plan): `splits` chunk ranges of ONE problem as the members of a launch group. Each member is the problem itself with
+// its epilogue stripped (fp32 partial tile into its slice of the workspace, no bias / activation / gate / residual / statistics: splitk_reduce_kernel
+// applies them once to the sum) and its chunk range in the geometry block.
+int igemm_halo_launch_splitk(const omgsr_igemm_args& a, const IgemmGeo& g0, const int splits, hipStream_t st) {
+    if (splits < 2 || splits > HALO_MULTI_MAX || !a.workspace) return OMGSR_E_BADARG;
+    omgsr_igemm_args parts[HALO_MULTI_MAX];
+    IgemmGeo geos[HALO_MULTI_MAX];
+    const int nk = a.Cin / 32;
+    const bool mx = a.mx_chunks16 > 0;
+    const int n16 = mx ? a.mx_chunks16 : nk, n8 = nk - n16;
+    const int64_t M = (int64_t)a.N * a.Ho * a.Wo;
+    const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
+    const int ldw = ((logical_cols + 127) / 128) * 128;
+    for (int s = 0; s < splits; ++s) {
+        omgsr_igemm_args& q = parts[s];
+        q = a;
+        q.out = reinterpret_cast<float*>(a.workspace) + (int64_t)s * M * ldw;
+        q.out_dtype = OMGSR_OUT_F32; q.out_ld = ldw; q.out_lo_off = 0; q.out_mx = 0;
+        q.bias = nullptr; q.gate = nullptr; q.residual = nullptr; q.act = OMGSR_ACT_NONE; q.alpha = 1.0f;
+        q.gn_partial = nullptr; q.gn_groups = 0; q.gn_entries = 0; q.overflow_flag = nullptr; q.workspace = nullptr;
+        geos[s] = g0;
+        if (mx) {
+            const int h = splits / 2, t = s < h ? s : s - h;
+            geos[s].cc0 = s < h ? (n16 * t) / h : n16 + (n8 * t) / h;
+            geos[s].cc1 = s < h ? (n16 * (t + 1)) / h : n16 + (n8 * (t + 1)) / h;
+        } else {
+            geos[s].cc0 = (nk * s) / splits;
+            geos[s].cc1 = (nk * (s + 1)) / splits;
+        }
+    }
+    return igemm_halo_launch_multi(parts, geos, splits, st, false);
+}
+
 }  // namespace omgsr

@@ -88,6 +88,7 @@ class Attention(nn.Module):
             return ops.pack_linear_weight(torch.cat([self.to_q.weight, self.to_k.weight], dim=0), None, split=sp, w_split=wsp)
         k = _key(self.to_q.weight, self.to_k.weight, sp, wsp)
         if getattr(self, "_qk_key", None) != k:
+            bump_cache_epoch()
             self._qk, self._qk_key = build(), k
         return self._qk
 

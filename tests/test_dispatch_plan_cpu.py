@@ -55,3 +55,68 @@ def test_a_problem_on_its_own_decides_for_itself():
     # a 16 x 16 map gains nothing from either form (two tiles each way, half of every spatial tile padding): it leaves the halo kernel, and its
     # statistics come in the GEMM-shaped kernels' layout, one slot per 32 output rows
     assert lib.omgsr_igemm_gn_slots(C.byref(_args(64, 16, 16))) == 16 * 16 // 32
+
+
+# ---- round 5: the normalising patch producer (omgsr_igemm_gn_fusable) and the halo kernel's split-K plan (omgsr_igemm_workspace_bytes) --------
+
+def test_groupnorm_fusion_policy():
+    """GroupNorm apply as the conv's patch producer: only where the problem takes the halo-tile kernel's spatial nine-tap form with a plain
+    16-bit operand and weight, the (scale, shift) table fits (Cin <= 1024) and the output is ONE 128-column tile (the measured break-even:
+    profiles/r05_experiments.md). The answer never depends on whether the table is attached yet."""
+    lib = _lib.load()
+
+    def fus(n, h, w, cin, cout, **kw):
+        a = _args(n, h, w, cin, cout)
+        a.in_el = 0
+        for k, v in kw.items():
+            setattr(a, k, v)
+        first = lib.omgsr_igemm_gn_fusable(C.byref(a))
+        a.gn_scale_shift, a.gn_nimg, a.gn_act = 0x1000, 1, 1
+        assert lib.omgsr_igemm_gn_fusable(C.byref(a)) == first
+        return bool(first)
+    assert fus(4, 320, 320, 128, 128)                    # tiled-VAE decoder, last level
+    assert fus(4, 320, 320, 128, 8)                      # conv_out: the narrow shape
+    assert not fus(4, 320, 320, 128, 256)                # two column tiles: break-even -> the apply pass stays
+    assert not fus(4, 160, 160, 512, 512)
+    assert not fus(64, 40, 40, 128, 128)                 # FLAT form (narrow map): no normalising instantiation
+    assert not fus(1, 16, 16, 128, 128)                  # not a halo-kernel problem at all
+    assert not fus(4, 320, 320, 2048, 128)               # table beyond the 8 KB the kernel holds
+    assert not fus(4, 320, 320, 128, 128, in_el=1)       # fp32 stream (accurate tier): not built
+    assert not fus(4, 320, 320, 256, 128, in_ld=128, w_split=1)      # wrapped contraction (weight split)
+    assert not fus(4, 160, 160, 128, 128, upsample=1, Ho=320, Wo=320)
+
+
+def _mx_args(n, h, w, c, cout, **kw):
+    """3x3 conv over an OMGSR_EL_MX operand of c logical channels (Cin counts 16-bit slots)."""
+    lib = _lib.load()
+    lib.omgsr_set_compute_dtype(1)
+    a = _args(n, h, w, 2 * c, cout)
+    a.K_pad, a.mx_chunks16, a.sample_rows = 9 * 2 * c, c // 32, h * w
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_halo_split_k_plan():
+    """One image per call (the reference's own operating point): the accurate tier's mixed-precision 3x3 convs are 16 ... 64 workgroup tiles;
+    the halo-tile kernel then runs 2 ... 8 chunk ranges of the contraction as one launch group. The workspace the caller must hand over is
+    splits x rows x padded columns fp32; big problems, launch-group members and wrapped contractions never split."""
+    lib = _lib.load()
+    try:
+        def splits(a):
+            cols = -(-a.Cout // 128) * 128
+            b = lib.omgsr_igemm_workspace_bytes(C.byref(a))
+            assert b % (4 * a.N * a.Ho * a.Wo * cols) == 0
+            return b // (4 * a.N * a.Ho * a.Wo * cols)
+        assert splits(_mx_args(1, 64, 64, 512, 512)) == 8          # 64 tiles -> 512 / 64 = 8 ranges: 4 fp16 + 4 fp8 (16 chunks each side)
+        assert splits(_mx_args(1, 32, 32, 640, 640)) == 8          # 20 tiles: the cap
+        assert splits(_mx_args(1, 64, 64, 320, 320)) == 8          # 48 tiles
+        assert splits(_mx_args(1, 9, 33, 64, 128)) == 2            # two chunks per side: one fp16 range, one fp8 range
+        assert splits(_mx_args(8, 64, 64, 320, 320)) == 0          # batch 8: 384 tiles fill the chip, the one-pass epilogue keeps its fused statistics
+        assert splits(_mx_args(1, 64, 64, 512, 512, group_tiles=4096)) == 0     # a member of a tiled-VAE launch group
+        # batch-invariant mode decides from ONE sample: batch 8 then splits exactly like batch 1 (same summation order per element)
+        lib.omgsr_set_batch_invariant(1)
+        assert splits(_mx_args(8, 64, 64, 320, 320)) == 8
+    finally:
+        lib.omgsr_set_batch_invariant(0)
+        lib.omgsr_set_compute_dtype(0)

@@ -73,7 +73,9 @@ def _pipe(c, tier):
 
 
 # order matters: the bf16 legs cast the shared module in place, so both fp32 cases run first
-@pytest.mark.parametrize("tier,batch", [("fp32", 1), ("fp32", 8), ("bf16", 1), ("bf16", 8)])
+# order matters (pytest runs a file top to bottom): the bf16 legs at the end of the file cast the shared module in place, so the fp32
+# cases and the range-fallback case run first
+@pytest.mark.parametrize("tier,batch", [("fp32", 1), ("fp32", 8)])
 def test_omgsr_f_1024_full_depth_vs_oracle(f_case, tier, batch):
     """batch 1: the pipeline's image and the DiT's velocity alone against the oracle.
     batch 8 = the per-GPU share of BASELINE configs[4] (OMGSR-F 256->1024, batch 64 over 8 GPUs; VERDICT r3 'untested config'): the
@@ -134,3 +136,62 @@ def test_omgsr_f_1024_full_depth_vs_oracle(f_case, tier, batch):
         if b1 is not None:
             assert d <= 2 * tol
     assert rel_l2(got8[1:2], c["ref"]) > 10 * tol           # (the other images really are other images)
+
+
+def _scale_v_channels(flux, channels, s):
+    """Multiply a few VALUE channels of some blocks by 2^s and the matching input columns of the projection that reads the attention
+    output by 2^-s: attention is linear in V, powers of two are exact, so the fp32 function (and the oracle's image) is unchanged bit for
+    bit while V^T - a 16-bit MFMA operand - now carries outlier channels far beyond fp16's 65504 (what real FLUX activations do)."""
+    f = 2.0 ** s
+    with torch.no_grad():
+        for b in (flux.transformer_blocks[0], flux.transformer_blocks[9]):
+            for ch in channels:
+                b.attn.to_v.weight[ch].mul_(f); b.attn.to_v.bias[ch].mul_(f)
+                b.attn.add_v_proj.weight[ch].mul_(f); b.attn.add_v_proj.bias[ch].mul_(f)
+                b.attn.to_out[0].weight[:, ch].mul_(1.0 / f); b.attn.to_add_out.weight[:, ch].mul_(1.0 / f)
+        for b in (flux.single_transformer_blocks[3], flux.single_transformer_blocks[20]):
+            for ch in channels:
+                b.attn.to_v.weight[ch].mul_(f); b.attn.to_v.bias[ch].mul_(f)
+                b.proj_out.weight[:, ch].mul_(1.0 / f)          # proj_out reads [attn (D) | mlp]: attention channel ch is input column ch
+
+
+def test_omgsr_f_1024_full_depth_outlier_channels_take_the_range_fallback(f_case):
+    """the guard -> fallback -> result path at FULL depth (19 + 38 blocks at FLUX.1-dev width), not only at the toy scale
+    of test_precise_gpu. Three value channels of four blocks are scaled by 2^18 (function unchanged, see _scale_v_channels): the fp16
+    operand V^T clips, the range guard fires at forward()'s own synchronisation, the call is recomputed with bf16 operands and every
+    operand / weight split, the pipeline stays range-safe - and that result meets the north-star bar against the SAME oracle image."""
+    import warnings
+    from omgsr_amd import ops
+    from omgsr_amd.testing import psnr, rel_l2
+    c = f_case
+    chans, s = (5, 1033, 2777), 18
+    _scale_v_channels(c["flux"], chans, s)
+    try:
+        pipe, wd = _pipe(c, "fp32")
+        to = lambda t: t.to(device=DEV, dtype=wd)      # noqa: E731
+        pipe.vae.posterior_noise = c["eps"].to(DEV)
+        with torch.no_grad(), warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            got, _ = pipe(to(c["x"]), to(c["pe"]), to(c["pooled"]), to(c["tids"]), to(c["iids"]), 128, 64)
+        assert any("65504" in str(w.message) for w in wl)
+        assert pipe.range_fallback.count == 1 and pipe.range_fallback.sticky and ops.act_dtype() == torch.bfloat16 and ops.precise()
+        with torch.no_grad(), warnings.catch_warnings(record=True) as wl2:
+            warnings.simplefilter("always")
+            again, _ = pipe(to(c["x"]), to(c["pe"]), to(c["pooled"]), to(c["tids"]), to(c["iids"]), 128, 64)
+        assert not any("65504" in str(w.message) for w in wl2) and pipe.range_fallback.count == 1 and torch.equal(again, got)      # ONE range-safe pass
+        got = got.float().cpu()
+        e, p = rel_l2(got, c["ref"]), psnr(got, c["ref"])
+        print(f"OMGSR-F 256->1024, 19+38 blocks, accurate tier with 2^{s} outlier value channels -> range fallback: rel-L2 {e:.3e} PSNR {p:.1f} dB")
+        assert torch.isfinite(got).all() and e <= 1e-3 and p >= 60.0
+    finally:
+        try:
+            pipe.range_fallback.reset()
+        except NameError:
+            pass
+        _scale_v_channels(c["flux"], chans, -s)           # exact inverse: the module is shared with the cases below
+        ops.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("tier,batch", [("bf16", 1), ("bf16", 8)])
+def test_omgsr_f_1024_full_depth_vs_oracle_bf16(f_case, tier, batch):
+    test_omgsr_f_1024_full_depth_vs_oracle(f_case, tier, batch)

@@ -793,7 +793,7 @@ GN_CONV_CASES = [
     (12, 2, 128, 128, 43, 86, 1, False, True),      # tile-major rows sharing two images' statistics, ragged map
     (8, 2, 256, 128, 64, 96, 1, True, True),
     (4, 2, 512, 512, 48, 64, 1, False, False),      # four column tiles: the shipped policy keeps the apply pass (OMGSR_GN_FUSE_MAX_COUT)
-    (4, 2, 512, 128, 96, 64, 1, False, True),
+    (8, 2, 512, 128, 96, 64, 1, False, True),
     (12, 1, 1024, 128, 64, 64, 1, False, True),     # the largest (scale, shift) table the kernel holds (8 KB)
     (2, 2, 128, 3, 128, 192, 1, False, True),       # conv_out: the narrow shape
     (12, 4, 128, 128, 64, 64, 0, False, False),     # no activation: SiLU is the one the producer applies -> apply pass
@@ -828,7 +828,8 @@ def test_conv3x3_groupnorm_fused_into_the_patch_producer(case):
     b = rnd(Cout, seed=13)
     gamma, beta = 1.0 + 0.2 * rnd(Cc, seed=14), 0.3 * rnd(Cc, seed=15)
     mean, rstd = 0.25 + 0.1 * rnd(nimg, G, seed=16), (1.0 / 1.5) * (1.0 + 0.1 * rnd(nimg, G, seed=17)).abs()
-    xn = _gn_ref(x, mean, rstd, gamma, beta, G, act, nimg)
+    # the normalised tensor is an MFMA operand: rounded ONCE to the compute type (by the apply pass and by the fused producer alike)
+    xn = _gn_ref(x, mean, rstd, gamma, beta, G, act, nimg).to(ops.act_dtype()).float()
     ref = F.conv2d(F.pad(xn, (1, 1, 1, 1)), w, b)
     res = None
     if use_res:
@@ -845,7 +846,9 @@ def test_conv3x3_groupnorm_fused_into_the_patch_producer(case):
     rd = None if res is None else nhwc(res)
     y = ops.conv2d(xd, pw, pad=1, residual=rd, gn=spec, gn_groups=32 if Cout >= 96 else 0)
     y_unfused = ops.conv2d(spec.apply(xd), pw, pad=1, residual=rd)
-    assert_close(to_nchw(y)[:, :Cout], ref, "gn-fused conv vs fp32 reference")
+    # (looser than the plain conv tests: the GPU evaluates the affine as one fma from the fp32 table, the reference as (x - m) r g + b, so a few
+    # operand elements round to the neighbouring 16-bit value - each flip is one operand ulp in a sum of 9 C terms)
+    assert_close(to_nchw(y)[:, :Cout], ref, "gn-fused conv vs fp32 reference", rel_l2=6e-3, max_ulps=6.0)
     # against the two-pass form: identical operand bits are expected (same table, same expression); allow one 16-bit ulp of the OUTPUT
     # for a contraction the compiler may have fused differently in the two kernels
     d = (y.float() - y_unfused.float()).abs().max().item()
@@ -873,6 +876,6 @@ def test_conv3x3_groupnorm_fused_multi_launch():
     spec = ops.GnSpec(mean.to(DEV), rstd.to(DEV), gamma.to(DEV), beta.to(DEV), G, ops.ACT_SILU)
     ys = ops.conv2d_multi([nhwc(x) for x in xs], pw, pad=1, residuals=[nhwc(r) for r in rs], gn=spec, gn_groups=32)
     for x, r, y in zip(xs, rs, ys):
-        ref = F.conv2d(F.pad(_gn_ref(x, mean, rstd, gamma, beta, G, 1, nimg), (1, 1, 1, 1)), w, b) + r
-        assert_close(to_nchw(y), ref, "gn-fused multi conv")
+        ref = F.conv2d(F.pad(_gn_ref(x, mean, rstd, gamma, beta, G, 1, nimg).to(ops.act_dtype()).float(), (1, 1, 1, 1)), w, b) + r
+        assert_close(to_nchw(y), ref, "gn-fused multi conv", rel_l2=6e-3, max_ulps=6.0)
         assert getattr(y, "_omgsr_gn", None) is not None

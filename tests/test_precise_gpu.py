@@ -206,6 +206,49 @@ def test_conv_mx(N, H, W, C, Cout):
     assert torch.allclose(mean.double().cpu(), r.mean(dim=(1, 3)), atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("N,H,W,C,Cout,act,res,osplit", [(1, 64, 64, 512, 512, 0, True, 1), (1, 32, 32, 640, 640, 1, False, 1), (1, 64, 64, 320, 320, 0, True, 2),
+                                                        (1, 64, 64, 960, 320, 0, False, 1), (1, 9, 33, 64, 128, 1, True, 1), (3, 24, 40, 192, 136, 0, True, 1),
+                                                        (1, 32, 32, 640, 640, 0, True, 3)])
+def test_conv_mx_split_k_small_m(N, H, W, C, Cout, act, res, osplit):
+    """Round 5: the reference's operating point is ONE image per call - its 3x3 convs are 16 ... 64 workgroup tiles on 512 slots. The halo-tile
+    kernel then runs the contraction as up to 8 chunk ranges (one launch group: igemm_halo_multi_kernel, fp32 partial tiles) and
+    splitk_reduce_kernel applies bias / activation / residual / output form once: same values as the one-pass epilogue up to fp32 summation
+    order. Ragged chunk counts (C = 192: 6 + 6 chunks over 4 ranges), one-chunk halves (C = 64) and the two-term split output included."""
+    import ctypes as C_
+    from omgsr_amd import _lib, ops
+    x = torch.randn(N, H, W, C, generator=_g(41))
+    w = torch.randn(Cout, C, 3, 3, generator=_g(42)) * (9 * C) ** -0.5
+    b = 0.1 * torch.randn(Cout, generator=_g(43))
+    r = torch.randn(N, H, W, Cout, generator=_g(44)) if res else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    if act:
+        ref = F.silu(ref)
+    if r is not None:
+        ref = ref + r.double()
+    pw = ops.pack_conv_weight(w, b, device=DEV, cout_multiple=8, split=3)
+    xd = ops.to_operand(x.to(DEV), 3)
+    a = _lib.IgemmArgs()
+    ops._conv_args(a, xd, pw, 1, 1, False, ops.ACT_SILU if act else ops.ACT_NONE, None, None, ops.OUT_STREAM, 1.0, None, 1, 0)
+    assert _lib.load().omgsr_igemm_workspace_bytes(C_.byref(a)) > 0, "this shape was meant to take the split-K form"
+    if osplit == 2:
+        y = ops.conv2d(xd, pw, pad=1, act=ops.ACT_SILU if act else ops.ACT_NONE, residual=None if r is None else r.to(DEV), out_dtype=ops.OUT_BF16, out_split=2)
+        Cp = y.shape[-1] // 2
+        y = y[..., :Cp].double() + y[..., Cp:].double()
+        assert _rel(y[..., :Cout], ref) < 2e-5
+        return
+    if osplit == 3:            # the reduce pass writes the mixed-precision operand of the next GEMM (a ResnetBlock feeding an upsampler / proj_out)
+        y = ops.conv2d(xd, pw, pad=1, residual=None if r is None else r.to(DEV), out_dtype=ops.OUT_BF16, out_split=3)
+        hi, lo, hi8 = _mx_decode(y, Cout)
+        assert _rel(hi.double() + lo.double(), ref) < 2e-4 and _rel(hi8, ref) < 5e-2      # hi + lo' 2^-11: ~2^-15; the fp8 copy: 3 mantissa bits
+        return
+    y = ops.conv2d(xd, pw, pad=1, act=ops.ACT_SILU if act else ops.ACT_NONE, residual=None if r is None else r.to(DEV), gn_groups=8)
+    assert y.dtype == torch.float32 and _rel(y[..., :Cout], ref) < 2e-5
+    mean, _, _ = ops.group_norm_stats(y, 8, 1e-6)                  # no fused statistics from a split-K launch: the stand-alone pass runs
+    assert torch.allclose(mean.double().cpu(), y.double().cpu().reshape(N, H * W, 8, -1).mean(dim=(1, 3)), atol=1e-5, rtol=1e-5)
+    again = ops.conv2d(xd, pw, pad=1, act=ops.ACT_SILU if act else ops.ACT_NONE, residual=None if r is None else r.to(DEV))
+    assert torch.equal(again, y)                                   # fixed summation order: bit-repeatable
+
+
 def test_conv_mx_upsample_phase_form_and_epilogue_output():
     """The producer / consumer pair of a decoder upsampler in the mixed-precision form: a GEMM epilogue writes the OMGSR_EL_MX operand
     (out_split 3) and the phase-decomposed upsampling conv consumes it (fp16 + block-scaled fp8 chunks of the phase-summed kernels)."""
