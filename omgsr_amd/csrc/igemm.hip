@@ -235,10 +235,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-        for (int sidx = 0; sidx < splits; ++sidx) {
-            const float* r = ws + ((int64_t)sidx * M + m) * ldw + n;
+        for (int sidx = 0; sidx < splits; ++sidx) {          // (ldw % 128 == 0, n % 8 == 0: two aligned 16-byte loads per partial row)
+            const f32x4_t* r = reinterpret_cast<const f32x4_t*>(ws + ((int64_t)sidx * M + m) * ldw + n);
+            const f32x4_t r0 = r[0], r1 = r[1];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r[e];
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -267,6 +268,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
             if (p.overflow_flag && amax > 448.0f) atomicOr(p.overflow_flag, 2u);
             return;
         }
+    }
+    if ((p.Cout & 7) == 0 && (ldo & 7) == 0 && (p.out_lo_off & 7) == 0) {      // whole octets: 16-byte residual loads and stores (round 5: 80 launches per one-image call)
+        if (p.gate) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.gate[n + e];
+        }
+        if (p.residual) {
+            float rf[8];
+            if (p.res_el == OMGSR_EL_F32) load8<T, true>(p.residual, (int64_t)m * p.Cout + n, rf);
+            else load8<T, false>(p.residual, (int64_t)m * p.Cout + n, rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rf[e];
+        }
+        const int64_t o = (int64_t)m * ldo + n;
+        if (p.out_dtype == OMGSR_OUT_BF16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+            if (p.out_lo_off > 0) store8<T, 2>(p.out, o, p.out_lo_off, v);
+            else store8<T, 0>(p.out, o, 0, v);
+            if constexpr (std::is_same<T, f16_t>::value) {
+                if (p.overflow_flag && amax > 65504.0f) atomicOr(p.overflow_flag, 1u);
+            }
+        } else store8<T, 1>(p.out, o, 0, v);
+        return;
     }
     for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
         float x = v[e];
@@ -682,7 +707,12 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
                     omgsr::igemm_halo_tiles(a));
     }
     const bool dma_ok = logical_cols >= 96 && (a.Cin % 32) == 0 && (a.in_ld % 32) == 0;   // the DMA kernel's K-steps never straddle taps (or the wrap point)
-    if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && tiles256 >= 192))) {
+    // ... and (round 5) GEMM-shaped problems too small to fill the chip with 256-row tiles: the LDS-DMA kernel's 64 / 128-row instantiations
+    // (the register-staged kernel's 64 x 64 tile spends ~0.6 us per 32-channel K-step on them). OMGSR_DMA_SMALL=0 for A/B.
+    static const char* dsm = getenv("OMGSR_DMA_SMALL");
+    const bool gemm_shaped = a.R == 1 && a.S == 1 && a.stride == 1 && a.pad_top == 0 && a.pad_left == 0 && !a.upsample && a.Ho == a.H && a.Wo == a.W;
+    const bool dma_small = !(dsm && dsm[0] == '0') && gemm_shaped && a.batch == 1 && a.K_pad >= 256 && a.out_layout == OMGSR_LAYOUT_NHWC && Mp >= 64;
+    if (dma_ok && ((mode && !strcmp(mode, "dma")) || (!(mode && !strcmp(mode, "reg")) && (tiles256 >= 192 || dma_small)))) {
         static const char* p8 = getenv("OMGSR_P8");               // A/B runs: "0" = never use the ping-pong GEMM kernel
         if (!(p8 && p8[0] == '0') && !omgsr::g_batch_invariant && omgsr::igemm_p8_wanted(a, g)) {
             ts.rec.variant = 5;

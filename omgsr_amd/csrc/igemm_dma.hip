@@ -264,6 +264,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void igemm_dma_kernel(const omgs
         q.out = (float*)p.workspace + (int64_t)blockIdx.y * g.M * ldw;
         q.out_dtype = OMGSR_OUT_F32; q.out_layout = OMGSR_LAYOUT_NHWC; q.out_ld = ldw; q.Cout = ldw;
         q.bias = nullptr; q.gate = nullptr; q.residual = nullptr; q.act = OMGSR_ACT_NONE; q.alpha = 1.0f; q.gn_partial = nullptr; q.out_lo_off = 0;
+        q.out_mx = 0; q.overflow_flag = nullptr;           // (round 5: the reduce pass writes the MX form; a partial is plain fp32)
         igemm_epilogue_linear<T, WTN, FM, FN>(q, g.M, acc, epi, lane, m0 + wm * WTM, n0 + wn * WTN, 0);
         return;
     }
@@ -334,6 +335,14 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
     {
         const int64_t nt = (logical_cols + 127) / 128;
         const int64_t t256b = (int64_t)((g.M + 255) / 256) * nt * a.batch, t192 = (int64_t)((g.M + 191) / 192) * nt * a.batch;
+        // Small-M regime (round 5: one image per call - GEMM-shaped problems of 64 ... 4096 rows that used to fall to the register-staged kernel): a few
+        // 256-row tiles would leave most CUs idle and make every K-step 16 MFMAs long on one wave per SIMD; 64 / 128-row tiles give 4x / 2x the
+        // workgroups and 4 / 8 MFMAs per step (igemm.hip sends such problems here only when they are GEMM-shaped)
+        static const char* bms = getenv("OMGSR_DMA_BM");
+        if (!bms) {
+            if (t256b < 64) return launch_dma<2, 2, 0, 64>(a, g, st);
+            if (t256b < 160) return launch_dma<2, 2, 0, 128>(a, g, st);
+        }
         auto eff = [](int64_t tiles) { const int64_t rounds = (tiles + 511) / 512; return (double)tiles / (double)(rounds * 512); };
         static const char* bm = getenv("OMGSR_DMA_BM");              // A/B runs: "256" | "192"
         const bool force192 = bm && bm[0] == '1', force256 = bm && bm[0] == '2';

@@ -9,13 +9,17 @@
 namespace {
 
 constexpr int GN_PPC = 256;   // pixels per statistics chunk (1024 measured 30 % slower: too few blocks in flight)
+// ... on big maps. One image per call (round 5) makes the maps 256 ... 4096 pixels: 1 ... 16 chunks of 256 are 1 ... 16 workgroups walking their
+// pixels in ~11 dependent load batches (20 us per launch, 76 launches per 128 -> 512 image). Smaller chunks there: a function of HW alone, so the
+// partial order - and with it batch invariance - is unchanged for a given image size.
+static inline int gn_ppc(const int64_t HW) { return HW >= 32768 ? GN_PPC : (HW >= 8192 ? 128 : (HW >= 2048 ? 32 : 16)); }
 
 // ---------------------------------------------------------------------------------------------
 // GroupNorm statistics, pass 1: per (image, pixel-chunk) partial (sum, sumsq) per group.
 // x [N][HW][C] bf16.  grid = (nchunk, N), 256 threads.  LDS: 2*C floats.
 template <typename T, bool XF32>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const void* __restrict__ x, float* __restrict__ partial,
-                                                          int64_t HW, int C, int G, int nchunk) {
+                                                          int64_t HW, int C, int G, int nchunk, int ppc) {
     // LDS: csum[P][C], csq[P][C] — one slot per (pixel lane, channel), reduced in a FIXED order
     // afterwards (no atomics: results are bitwise reproducible and independent of the batch size)
     extern __shared__ __attribute__((aligned(16))) float gn_lds[];
@@ -26,8 +30,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const void* __restrict_
     const int P = 256 / TP;                      // pixels in flight
     float* csum = gn_lds;
     float* csq = gn_lds + P * C;
-    const int64_t p0 = (int64_t)chunk * GN_PPC;
-    const int npx = (int)((HW - p0) < GN_PPC ? (HW - p0) : GN_PPC);
+    const int64_t p0 = (int64_t)chunk * ppc;
+    const int npx = (int)((HW - p0) < ppc ? (HW - p0) : ppc);
     if (t < TP * P) {
         const int pl = t / TP;
         const int64_t base = ((int64_t)n * HW + p0) * C;
@@ -523,7 +527,7 @@ extern "C" int omgsr_groupnorm_scale_shift(const float* mean, const float* rstd,
     return (int)hipGetLastError();
 }
 
-extern "C" int omgsr_groupnorm_nchunk(int64_t HW) { return (int)((HW + GN_PPC - 1) / GN_PPC); }
+extern "C" int omgsr_groupnorm_nchunk(int64_t HW) { const int ppc = gn_ppc(HW); return (int)((HW + ppc - 1) / ppc); }
 
 extern "C" int omgsr_groupnorm_stats(const void* x, float* partial, float* mean, float* rstd, float* var_out,
                                      int32_t N, int64_t HW, int32_t C, int32_t G, float eps, int32_t x_el, void* stream) {
@@ -534,8 +538,8 @@ extern "C" int omgsr_groupnorm_stats(const void* x, float* partial, float* mean,
     omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, (x_el == OMGSR_EL_F32 ? 4.0 : 2.0) * N * (double)HW * C, st);
     const int tp = (C >> 3) < 256 ? (C >> 3) : 256;
     const size_t lds = 2 * (size_t)(256 / tp) * C * sizeof(float);      // <= 20 KB
-    if (x_el == OMGSR_EL_F32) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, true>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk));
-    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, false>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk));
+    if (x_el == OMGSR_EL_F32) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, true>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk, gn_ppc(HW)));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, false>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk, gn_ppc(HW)));
     const int tot = N * G;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(tot), dim3(64), 0, st, partial, mean, rstd, var_out,
                        N, G, nchunk, (double)HW * (C / G), eps, G);
@@ -608,8 +612,8 @@ extern "C" int omgsr_groupnorm_partial(const void* x, float* partial, int32_t N,
     omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, (x_el == OMGSR_EL_F32 ? 4.0 : 2.0) * N * (double)HW * C, st);
     const int tp = (C >> 3) < 256 ? (C >> 3) : 256;
     const size_t lds = 2 * (size_t)(256 / tp) * C * sizeof(float);
-    if (x_el == OMGSR_EL_F32) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, true>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk));
-    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, false>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk));
+    if (x_el == OMGSR_EL_F32) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, true>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk, gn_ppc(HW)));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_partial_kernel<T, false>), dim3(nchunk, N), dim3(256), lds, st, x, partial, HW, C, G, nchunk, gn_ppc(HW)));
     return (int)hipGetLastError();
 }
 
@@ -653,6 +657,11 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
     static const int64_t belems = ppe ? atol(ppe) : 16384;
     int64_t ppb = (belems + C - 1) / C;      // ~32 KB of activations per block (5.6 TB/s; 64 KB 5.4, 128 KB 4.9, 256 KB 30 % slower)
     if (ppb < 1) ppb = 1;
+    // small maps (one image per call): at least ~512 blocks, down to 8 pixels each, instead of 10 ... 80 blocks on 256 CUs
+    if (((HW + ppb - 1) / ppb) * N < 512) {
+        ppb = (HW * N + 511) / 512;
+        if (ppb < 8) ppb = 8;
+    }
     const int nblk = (int)((HW + ppb - 1) / ppb);
     omgsr::TimingScope ts(OMGSR_TK_GN, 0.0, ((x_el == OMGSR_EL_F32 ? 4.0 : 2.0) + (y_el == OMGSR_EL_16 ? 2.0 : 4.0) +
                                              (y2 ? (y2_el == OMGSR_EL_16 ? 2.0 : 4.0) : 0.0)) * N * (double)HW * C, st);

@@ -197,7 +197,9 @@ def test_conv_multi_launch(case):
             assert torch.allclose(var.cpu(), r.var(dim=(1, 3), unbiased=False), atol=2e-3, rtol=5e-3)
 
 
-@pytest.mark.parametrize("M,K,Nout", [(64, 320, 320), (4096, 320, 960), (1000, 1280, 1280), (77, 1024, 640), (300, 64, 3072)])
+@pytest.mark.parametrize("M,K,Nout", [(64, 320, 320), (4096, 320, 960), (1000, 1280, 1280), (77, 1024, 640), (300, 64, 3072),
+                                      # round 5, small-M regime (one image per call): the LDS-DMA kernel's 64- / 128-row tiles
+                                      (128, 1280, 1280), (512, 640, 640), (65, 256, 10240), (2048, 320, 320), (33, 1280, 320)])
 def test_linear(M, K, Nout):
     ops = _ops()
     x = rnd(2, M, K, seed=5)

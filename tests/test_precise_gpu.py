@@ -249,6 +249,25 @@ def test_conv_mx_split_k_small_m(N, H, W, C, Cout, act, res, osplit):
     assert torch.equal(again, y)                                   # fixed summation order: bit-repeatable
 
 
+@pytest.mark.parametrize("M,K,Nn", [(256, 5120, 1280), (64, 11520, 1280), (1024, 2560, 640)])
+def test_linear_split_k_writes_the_mx_operand(M, K, Nn):
+    """Round 5: a small-M / long-K GEMM whose result is the mixed-precision operand of the next GEMM (the UNet's feed-forward output in front of
+    proj_out at the 16 x 16 level, one image per call) takes the LDS-DMA kernel's split-K; its reduce pass writes [hi fp16 | lo' fp8 | hi' fp8]."""
+    import ctypes as C_
+    from omgsr_amd import _lib, ops
+    x = torch.randn(1, M, K, generator=_g(51)).to(torch.float16).float()
+    w = (torch.randn(Nn, K, generator=_g(52)) * K ** -0.5).to(torch.float16).float()
+    b = 0.1 * torch.randn(Nn, generator=_g(53))
+    r = torch.randn(1, M, Nn, generator=_g(54))
+    ref = torch.addmm(b.double(), x[0].double(), w.double().t())[None] + r.double()
+    pw = ops.pack_linear_weight(w, b, device=DEV)
+    y = ops.linear(ops.to_operand(x.to(DEV)), pw, residual=r.to(DEV), out_dtype=ops.OUT_BF16, out_split=3)
+    hi, lo, hi8 = _mx_decode(y, Nn)
+    assert _rel(hi.double() + lo.double(), ref) < 2e-4 and _rel(hi8, ref) < 5e-2
+    y32 = ops.linear(ops.to_operand(x.to(DEV)), pw, residual=r.to(DEV))
+    assert _rel(y32, ref) < 3e-6
+
+
 def test_conv_mx_upsample_phase_form_and_epilogue_output():
     """The producer / consumer pair of a decoder upsampler in the mixed-precision form: a GEMM epilogue writes the OMGSR_EL_MX operand
     (out_split 3) and the phase-decomposed upsampling conv consumes it (fp16 + block-scaled fp8 chunks of the phase-summed kernels)."""
