@@ -327,6 +327,9 @@ int halo_splitk_plan(const omgsr_igemm_args& a) {
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;
     if (a.in_ld != 0 || a.gn_scale_shift || a.out_layout != OMGSR_LAYOUT_NHWC || a.act == OMGSR_ACT_GEGLU || logical_cols < 96 || a.upsample ||
         a.group_tiles != 0 || a.batch != 1) return 1;
+    // the mixed-precision problems on the spatial form: the only convs the halo kernel takes whatever their tile count (a plain conv with too few
+    // tiles goes to the LDS-DMA kernel, which has its own split-K); one extra instantiation instead of a run-time range in every one of them
+    if (a.mx_chunks16 <= 0 || omgsr::igemm_halo_flat(a) != 0) return 1;
     const int tiles = omgsr::igemm_halo_tiles(a);
     static const char* mt = getenv("OMGSR_HALO_SPLITK_MAX_TILES");
     static const int max_tiles = mt ? atoi(mt) : 128;                  // one quarter of the 512 workgroup slots

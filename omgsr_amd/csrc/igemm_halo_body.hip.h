@@ -86,7 +86,9 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 // (read stream, write operand) and the conv's read of that operand are gone: 4 of 6 bytes per element. Spatial nine-tap form, plain
 // 16-bit operand and weight only (no split / MX / wrap). An fp32 stream (the accurate tier's) would need its patch register-staged (a raw
 // fp32 chunk is 42 KB: no LDS room): loads held in VGPRs across K-steps next to inline-asm DMA traffic the compiler cannot count - not built.
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, int FLAT = 0, int GNF = 0>      // FLAT: 0 spatial tiles, 1 FLAT form, 2 FLAT form with the 27-piece patch
+// SPLITK (round 5): the workgroup runs the chunk range IgemmGeo.cc0 .. cc1 of the contraction (split-K launch groups). A template flag, not a run-time
+// test: with the two extra loop bounds live the FLAT instantiations - already at 256 registers - went from 3 to 38 spilled VGPRs.
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, int FLAT = 0, int GNF = 0, bool SPLITK = false>      // FLAT: 0 spatial tiles, 1 FLAT form, 2 FLAT form with the 27-piece patch
 OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const int tile, const int bidy) {      // tile: logical (XCD-remapped) tile index
     static_assert(GNF == 0 || (TAPS == 9 && !MX && FLAT == 0 && ABL == 0 && !PRIO), "GNF: spatial nine-tap form only");
     constexpr int WTN = NARROW ? 32 : 64, FM = NARROW ? 2 : 4, FN = NARROW ? 1 : 2, BNK = NARROW ? 32 : 128;
@@ -161,7 +163,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
                        : reinterpret_cast<const unsigned char*>(g_zero_page_h);
     const int64_t b_step = (int64_t)p.Cout_pad * 64;       // bytes between consecutive (chunk, tap) slices
     // split-K (IgemmGeo.cc0 / cc1): this workgroup's share of the contraction is the chunk range [cbeg, ncc); patch and weight streams start there
-    const int cbeg = g.cc1 > 0 ? g.cc0 : 0;
+    const int cbeg = (SPLITK && g.cc1 > 0) ? g.cc0 : 0;
     if (cbeg > 0) {
 #pragma unroll
         for (int i = 0; i < APW; ++i) a_ptr[i] += (int64_t)a_inc[i] * cbeg;
@@ -230,7 +232,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int ncc = g.cc1 > 0 ? g.cc1 : g.nk;      // (one past) the last 32-channel chunk this workgroup runs
+    const int ncc = (SPLITK && g.cc1 > 0) ? g.cc1 : g.nk;      // (one past) the last 32-channel chunk this workgroup runs
     const int nsteps = ncc * TAPS;         // K-step index s = chunk * TAPS + tap is absolute: only differences and comparisons with nsteps are used
 
     // The first versions of this loop were instruction-issue bound (profiles/r01_pmc_igemm.md §6: 5.3 VALU +
@@ -417,7 +419,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
     if (g.main_prio == 1) __builtin_amdgcn_s_setprio(1);
     else if (g.main_prio == 2) __builtin_amdgcn_s_setprio(2);
     int cc = cbeg;
-    const int e16 = n16 < ncc ? n16 : ncc;          // (a split-K range lies on one side of the fp16 / fp8 boundary, so patch parity restarts at 0 on both)
+    const int e16 = (SPLITK && n16 > ncc) ? ncc : n16;      // (a split-K range lies on one side of the fp16 / fp8 boundary, so patch parity restarts at 0 on both)
     for (; cc < e16; cc += 2) {
         chunk(std::integral_constant<int, 0>{}, std::false_type{}, cc);
         if (cc + 1 < e16) chunk(std::integral_constant<int, 1>{}, std::false_type{}, cc + 1);
@@ -513,7 +515,7 @@ struct HaloMulti {
     int start[HALO_MULTI_MAX + 1];
     int count;
 };
-template <typename T, bool NARROW, int TAPS, bool MX = false, int FLAT = 0, int GNF = 0>
+template <typename T, bool NARROW, int TAPS, bool MX = false, int FLAT = 0, int GNF = 0, bool SPLITK = false>
 __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMulti m) {
     int s = 0, tile, phase;
     if (TAPS == 4 && m.g[0].interleave) {      // x-only grid of 4 x the 8-aligned ranges; block order inside a problem's range: see igemm_halo_kernel
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMult
         if (bid >= m.g[s].ntm * m.g[s].ntn) return;                                 // filler block of the 8-aligned range
         tile = xcd_remap(bid, m.g[s].ntm * m.g[s].ntn); phase = (int)blockIdx.y;
     }
-    halo_body<T, 0, false, NARROW, TAPS, MX, FLAT, GNF>(m.p[s], m.g[s], tile, phase);
+    halo_body<T, 0, false, NARROW, TAPS, MX, FLAT, GNF, SPLITK>(m.p[s], m.g[s], tile, phase);
 }
 
 

@@ -9,8 +9,9 @@ static int mx_attrs() {
         const void* fns[] = {reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, false, 9, true>),
                              reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 9, true>),
                              reinterpret_cast<const void*>(igemm_halo_kernel<f16_t, 0, false, false, 4, true>),
-                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 4, true>)};
-        const int rc = halo_set_lds_attr(fns, 4);
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 4, true>),
+                             reinterpret_cast<const void*>(igemm_halo_multi_kernel<f16_t, false, 9, true, 0, 0, true>)};      // split-K launch groups
+        const int rc = halo_set_lds_attr(fns, 5);
         if (rc != 0) return rc;
         attr_set = true;
     }
@@ -21,6 +22,7 @@ int igemm_halo_launch_multi_mx(const void* halo_multi, unsigned blocks, hipStrea
     const int rc = mx_attrs();
     if (rc != 0) return rc;
     if (m.p[0].upsample) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 4, true>), m.g[0].interleave ? dim3(4 * blocks) : dim3(blocks, 4), dim3(256), LDS_BYTES, st, m);
+    else if (m.g[0].cc1 > 0) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, true, 0, 0, true>), dim3(blocks), dim3(256), LDS_BYTES, st, m);      // chunk ranges of one problem
     else hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, true>), dim3(blocks), dim3(256), LDS_BYTES, st, m);
     return (int)hipGetLastError();
 }

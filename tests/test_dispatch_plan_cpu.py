@@ -111,7 +111,8 @@ def test_halo_split_k_plan():
         assert splits(_mx_args(1, 64, 64, 512, 512)) == 8          # 64 tiles -> 512 / 64 = 8 ranges: 4 fp16 + 4 fp8 (16 chunks each side)
         assert splits(_mx_args(1, 32, 32, 640, 640)) == 8          # 20 tiles: the cap
         assert splits(_mx_args(1, 64, 64, 320, 320)) == 8          # 48 tiles
-        assert splits(_mx_args(1, 9, 33, 64, 128)) == 2            # two chunks per side: one fp16 range, one fp8 range
+        assert splits(_mx_args(1, 8, 64, 64, 128)) == 2            # two chunks per side: one fp16 range, one fp8 range
+        assert splits(_mx_args(1, 9, 33, 64, 128)) == 0            # narrow map: the FLAT form, which has no chunk-range instantiation
         assert splits(_mx_args(8, 64, 64, 320, 320)) == 0          # batch 8: 384 tiles fill the chip, the one-pass epilogue keeps its fused statistics
         assert splits(_mx_args(1, 64, 64, 512, 512, group_tiles=4096)) == 0     # a member of a tiled-VAE launch group
         # batch-invariant mode decides from ONE sample: batch 8 then splits exactly like batch 1 (same summation order per element)

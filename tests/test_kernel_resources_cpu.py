@@ -59,13 +59,22 @@ def test_the_tight_kernels_are_where_design_says(tables):
     for k, b in built.items():
         if k.startswith(("igemm_halo", "igemm_dma", "igemm_p8", "igemm_gmx", "attn_kernel")):
             assert b["occupancy"] >= 2, (k, b)
-    # template arguments end with (TAPS, MX, FLAT, GNF): nine-tap MX instantiations, spatial and FLAT form
-    mx = [b for k, b in built.items() if k.startswith("igemm_halo") and (k.endswith(",9,1,0,0>") or k.endswith(",9,1,1,0>") or k.endswith(",9,1,2,0>"))]
+    def targs(k):
+        """{TAPS, MX, FLAT, GNF, SPLITK, PRIO} of a halo instantiation: igemm_halo_kernel<T, ABL, PRIO, NARROW, TAPS, MX, FLAT, GNF>,
+        igemm_halo_multi_kernel<T, NARROW, TAPS, MX, FLAT, GNF, SPLITK>."""
+        a = k[k.index("<") + 1:-1].split(",")
+        if k.startswith("igemm_halo_multi_kernel"):
+            return dict(taps=a[2], mx=a[3], flat=a[4], gnf=a[5], splitk=a[6], prio="0", abl="0")
+        return dict(taps=a[4], mx=a[5], flat=a[6], gnf=a[7], splitk="0", prio=a[2], abl=a[1])
+    halo = {k: (b, targs(k)) for k, b in built.items() if k.startswith("igemm_halo")}
+    mx = [b for b, t in halo.values() if t["taps"] == "9" and t["mx"] == "1" and t["splitk"] == "0"]      # nine-tap MX instantiations, spatial and FLAT form
     assert len(mx) == 6 and all(b["spill_vgpr"] <= 16 and b["scratch"] <= 64 for b in mx), mx
-    flat = [b for k, b in built.items() if k.startswith("igemm_halo") and (k.endswith(",1,0>") or k.endswith(",2,0>"))]    # the FLAT form (22- and 27-piece patch): 9 fragment-address registers instead of 36
+    flat = [b for b, t in halo.values() if t["flat"] in ("1", "2")]      # the FLAT form (22- and 27-piece patch): 9 fragment-address registers instead of 36
     assert len(flat) == 12 and all(b["spill_vgpr"] <= 4 for b in flat), flat
-    gn = [b for k, b in built.items() if k.startswith("igemm_halo") and k.endswith(",9,0,0,1>")]      # GroupNorm apply as the patch producer (round 5): no spills, two workgroups per CU
+    sk = [b for b, t in halo.values() if t["splitk"] == "1"]             # the split-K (chunk range) instantiation: spatial MX form only, small-M regime
+    assert len(sk) == 1 and sk[0]["spill_vgpr"] <= 24 and sk[0]["occupancy"] >= 2, sk
+    gn = [b for b, t in halo.values() if t["gnf"] == "1"]                # GroupNorm apply as the patch producer (round 5): no spills, two workgroups per CU
     assert len(gn) == 8 and all(b["spill_vgpr"] == 0 and b["scratch"] == 0 for b in gn), gn
-    for k, b in built.items():
-        if k.startswith("igemm_halo") and not k.endswith(",9,1,0,0>") and not k.endswith(",1,0>") and not k.endswith(",2,0>") and ",0,1,0,9,0,0,0>" not in k:      # (the s_setprio A/B instantiation spills 8)
+    for k, (b, t) in halo.items():
+        if not (t["taps"] == "9" and t["mx"] == "1" and t["flat"] == "0") and t["flat"] == "0" and t["prio"] == "0":      # (the s_setprio A/B instantiation spills a few)
             assert b["spill_vgpr"] == 0, (k, b)
