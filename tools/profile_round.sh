@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-tiers --no-f1024 --no-latency $*"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
+OMGSR_KERNEL_TABLE=$OUT/ktable.md rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
 DB=$(find $OUT/trace -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB $OUT/kernel_stats.md > /dev/null
 # three pipeline passes: the first also runs the one-time constant folding; tools/traffic_summary.py keeps the last two (steady state)
