@@ -39,6 +39,26 @@ for M, C, N in [(147456, 320, 320), (36864, 640, 2560), (9216, 1280, 1280)]:
     xm = ops.to_operand((torch.randn(1, M, C, generator=g) * 0.5).to(dev), 3)
     pm = ops.pack_linear_weight(torch.randn(N, C, generator=g) * C ** -0.5, torch.randn(N, generator=g), device=dev, split=3)
     total += soak(f"[accurate] MX linear {M}x{C}->{N} (gmx | p8-MX)", lambda: ops.linear(xm, pm), reps)
+# round 5: the small-M forms of the same kernels (64 / 128-row tiles) and the split-K launch group of the halo-tile kernel (one image per call)
+for M, C, N in [(1024, 640, 640), (256, 1280, 1280), (4096, 320, 320)]:
+    xm = ops.to_operand((torch.randn(1, M, C, generator=g) * 0.5).to(dev), 3)
+    pm = ops.pack_linear_weight(torch.randn(N, C, generator=g) * C ** -0.5, torch.randn(N, generator=g), device=dev, split=3)
+    total += soak(f"[accurate] MX linear {M}x{C}->{N} (gmx, small tiles)", lambda: ops.linear(xm, pm), reps)
+for N_, C, Co, H_, W_ in [(1, 512, 512, 64, 64), (1, 640, 640, 32, 32), (1, 320, 320, 64, 64)]:
+    xc = ops.to_operand((torch.randn(N_, H_, W_, C, generator=g) * 0.5).to(dev), 3)
+    pc = ops.pack_conv_weight(torch.randn(Co, C, 3, 3, generator=g) * (9 * C) ** -0.5, torch.zeros(Co), device=dev, split=3)
+    rr = torch.randn(N_, H_, W_, Co, generator=g).to(dev)
+    total += soak(f"[accurate] MX halo conv, split-K {N_}x{H_}x{W_} {C}->{Co}", lambda: ops.conv2d(xc, pc, pad=1, residual=rr), reps)
+# ... and GroupNorm apply + SiLU as the conv's patch producer (fast tiers: a wave normalises its own LDS-DMA'd pieces in place)
+for tier in (torch.bfloat16, torch.float16):
+    ops.set_compute_dtype(tier)
+    dt = ops.act_dtype()
+    for N_, C, Co, H_, W_ in [(4, 128, 128, 256, 256), (12, 512, 128, 64, 64), (2, 128, 8, 256, 256)]:
+        xs = (torch.randn(N_, H_, W_, C, generator=g) * 1.5).to(dt).to(dev)
+        pc = ops.pack_conv_weight(torch.randn(Co, C, 3, 3, generator=g) * (9 * C) ** -0.5, torch.zeros(Co), device=dev, cout_multiple=8)
+        spec = ops.GnSpec(torch.randn(N_, 32, generator=g).to(dev) * 0.1, (1.0 + 0.1 * torch.randn(N_, 32, generator=g)).abs().to(dev),
+                          (1.0 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev), 32, ops.ACT_SILU)
+        total += soak(f"[{dt}] GN-fused halo conv {N_}x{H_}x{W_} {C}->{Co}", lambda: ops.conv2d(xs, pc, pad=1, gn=spec), reps)
 ops.set_compute_dtype(torch.bfloat16)
 print("TOTAL differing:", total)
 sys.exit(1 if total else 0)
