@@ -377,6 +377,7 @@ class RangeFallback:
         # every forward() re-asserts what its own pipeline needs - after pipeline A went sticky (fp32 stream, bf16 operands) a second
         # accurate pipeline B would otherwise run its fp16-only policy (MX layers, q / k splits) under bf16 operands and fail every call
         self.weight_dtype = weight_dtype
+        self.mx_saturation_count = 0    # calls in which a mixed-precision operand carried a value beyond +-448 (its fp8 correction fields saturated)
         self.count = 0
         self.sticky = False
         self._saved = None
@@ -428,7 +429,17 @@ class RangeFallback:
         self.reassert()
         out = run()
         torch.cuda.synchronize()
-        if not self.sticky and ops.precise() and ops.overflow_seen():
+        overflowed = (not self.sticky) and ops.precise() and ops.overflow_seen()          # (reads the guard word: also latches the MX diagnostic bit)
+        if ops.precise() and ops.mx_saturation_seen():
+            # not an error - the fp16 main term of that element is exact, its two correction terms were clamped, so it carried
+            # single-rounding accuracy. Seeded weights never get here; a checkpoint whose feed-forward / attention outputs reach the hundreds
+            # does, and then the accuracy evidence of this tier (all from O(1) activations) does not cover it: say so once.
+            self.mx_saturation_count += 1
+            if self.mx_saturation_count == 1:
+                warnings.warn(f"{what} accurate tier: a mixed-precision (fp16 + fp8 correction) operand held values beyond +-448; their correction "
+                              f"terms saturated (single-rounding accuracy for those elements). OMGSR_MX_LINEAR=0 / OMGSR_MX=0 run those layers "
+                              f"with fp16 correction segments instead")
+        if overflowed:
             self.count += 1
             warnings.warn(f"{what} accurate tier: an fp16 MFMA operand exceeded 65504; this call is recomputed with bf16 operands and "
                           f"the pipeline stays range-safe (pipe.range_fallback.reset() returns to fp16 operands)")

@@ -38,6 +38,7 @@ def test_range_fallback_state_machine_without_gpu(monkeypatch):
     monkeypatch.setattr(ops, "precise", lambda: state["precise"])
     monkeypatch.setattr(ops, "act_dtype", lambda: state["act"])
     monkeypatch.setattr(ops, "overflow_seen", lambda reset=True: state["ovf"].pop(0))
+    monkeypatch.setattr(ops, "mx_saturation_seen", lambda reset=True: False)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     rf = precision.RangeFallback(net)
     calls = []
@@ -66,6 +67,8 @@ def test_two_pipelines_one_sticky_reassert_their_own_mode(monkeypatch):
     monkeypatch.setattr(ops, "precise", lambda: state["precise"])
     monkeypatch.setattr(ops, "act_dtype", lambda: state["act"])
     monkeypatch.setattr(ops, "overflow_seen", lambda reset=True: False)
+    sat = [True, True, False, False]
+    monkeypatch.setattr(ops, "mx_saturation_seen", lambda reset=True: sat.pop(0) if sat else False)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     a = precision.RangeFallback(torch.nn.Sequential(Conv2d(32, 32, 3)), weight_dtype=torch.float32)
     b = precision.RangeFallback(torch.nn.Sequential(Conv2d(32, 32, 3)), weight_dtype=torch.float32)
@@ -79,6 +82,8 @@ def test_two_pipelines_one_sticky_reassert_their_own_mode(monkeypatch):
     b.run(lambda: seen.append((state["act"], state["precise"])), "B")
     assert seen == [(torch.float16, True), (torch.bfloat16, False), (torch.bfloat16, True), (torch.float16, True)]
     assert a.sticky and not b.sticky and not c.sticky
+    # the MX saturation diagnostic is counted per pipeline in the accurate tier (B saw it once, A once), never raised as an overflow
+    assert b.mx_saturation_count == 1 and a.mx_saturation_count == 1 and c.mx_saturation_count == 0 and b.count == 0
 
 
 def test_graph_cache_drops_entries_captured_under_an_older_cache_epoch():
