@@ -338,14 +338,20 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
         // Small-M regime (round 5: one image per call - GEMM-shaped problems of 64 ... 4096 rows that used to fall to the register-staged kernel): a few
         // 256-row tiles would leave most CUs idle and make every K-step 16 MFMAs long on one wave per SIMD; 64 / 128-row tiles give 4x / 2x the
         // workgroups and 4 / 8 MFMAs per step (igemm.hip sends such problems here only when they are GEMM-shaped)
-        static const char* bms = getenv("OMGSR_DMA_BM");
+        static const char* bms = getenv("OMGSR_DMA_BM");             // A/B runs: "256" | "192" | "128" | "64" (the last two: GEMM-shaped problems only)
+        const bool gemm_shaped = a.R == 1 && a.S == 1 && a.stride == 1 && !a.upsample;
         if (!bms) {
             if (t256b < 64) return launch_dma<2, 2, 0, 64>(a, g, st);
             if (t256b < 160) return launch_dma<2, 2, 0, 128>(a, g, st);
+        } else if (gemm_shaped) {
+            static const char* mk = getenv("OMGSR_DMA_BM_MAXK");      // ... with K_pad <= this (default: any)
+            static const int maxk = mk ? atoi(mk) : (1 << 30);
+            if (!strcmp(bms, "64") && a.K_pad <= maxk) return launch_dma<2, 2, 0, 64>(a, g, st);
+            if (!strcmp(bms, "128") && a.K_pad <= maxk) return launch_dma<2, 2, 0, 128>(a, g, st);
         }
         auto eff = [](int64_t tiles) { const int64_t rounds = (tiles + 511) / 512; return (double)tiles / (double)(rounds * 512); };
-        static const char* bm = getenv("OMGSR_DMA_BM");              // A/B runs: "256" | "192"
-        const bool force192 = bm && bm[0] == '1', force256 = bm && bm[0] == '2';
+        const char* bm = bms;
+        const bool force192 = bm && !strcmp(bm, "192"), force256 = bm && !strcmp(bm, "256");
         if (!force256 && (g.M % 192) == 0 && (force192 || (eff(t256b) < 0.78 && eff(t192) > eff(t256b) + 0.1)))
             return launch_dma<2, 2, 0, 192>(a, g, st);
     }
