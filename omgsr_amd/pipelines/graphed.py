@@ -40,7 +40,7 @@ class WeightsStamp:
         v = a = 0
         for _, _, p in own:
             v += p._version
-            a ^= p.data_ptr()
+            a = (a * 1000003 + p.data_ptr()) & 0xFFFFFFFFFFFFFFFF      # order-dependent: two parameters swapping storage do not cancel
         return (len(own), v, a)
 
 
@@ -94,6 +94,8 @@ class GraphCache:
             return static_out.clone()
         if full in self._eager_only:
             return fn(*dynamic)
+        if len(self._eager_only) > 256:      # (bounded like _seen: a service must not grow a set per failed key forever)
+            self._eager_only.clear()
         n = self._seen.get(full, 0)
         if len(self._seen) > 4096:       # keys are cheap (ints / shapes), but a service that sees ever-new prompts must not grow without bound
             self._seen.clear()
