@@ -317,6 +317,12 @@ int omgsr_vae_sample(const void* moments, const float* eps, void* z, int64_t row
  * (mirrors the reference's eager bf16 arithmetic, infer/omgsr_s_infer_model.py:80-84). */
 int omgsr_axpby(const void* x, const void* y, void* out, int64_t n, float a, float b, float c, float d,
                 int32_t bf16_steps, int32_t el, void* stream);
+/* ABI v16: y f32[rows][N] = act(x f32[rows][K]) . w f32[N][K]^T + b f32[N] (b may be NULL; act = SiLU when `silu_in`), fp32 FMAs in a fixed
+ * order (one wave per output element). The load-time constant folds: diffusers TimestepEmbedding / CombinedTimestep(Guidance)TextProjEmbeddings,
+ * AdaLayerNormZero(.Single) / AdaLayerNormContinuous `linear(silu(temb))`, ResnetBlock2D `time_emb_proj(silu(temb))` - all functions of
+ * (t*, guidance, prompt) only (infer/omgsr_s_infer_model.py:107-110, infer/omgsr_f_infer_model.py:83-88). */
+int omgsr_linear_f32(const float* x, const float* w, const float* b, float* y, int32_t rows, int32_t K, int32_t N,
+                     int32_t silu_in, void* stream);
 /* acc[n,y0+y,x0+x,c] += tile[n,y,x,c] * w[y,x] (f32 acc, bf16 tile NHWC ld=tile_ld), and the matching
  * normaliser; infer/omgsr_s_infer_model.py:137-161. */
 int omgsr_tile_accumulate(const void* tile, const float* w, float* acc, int32_t N, int32_t C,

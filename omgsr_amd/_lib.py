@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class OmgsrError(RuntimeError):
@@ -106,6 +106,7 @@ SIGNATURES = {
     "omgsr_copy_channels": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "omgsr_vae_sample": (C.c_int, [_P, _P, _P, _L, _I, _I, _F, _F, _I, _P]),
     "omgsr_axpby": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _F, _I, _I, _P]),
+    "omgsr_linear_f32": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "omgsr_tile_accumulate": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "omgsr_tile_normalise": (C.c_int, [_P, _P, _P, _I, _L, _I, _I, _I, _P]),
     "omgsr_crop_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

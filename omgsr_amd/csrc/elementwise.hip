@@ -196,7 +196,7 @@ inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)((tot
 
 }  // namespace
 
-extern "C" int omgsr_abi_version(void) { return 15; }
+extern "C" int omgsr_abi_version(void) { return 16; }
 
 extern "C" int omgsr_set_compute_dtype(int dtype) {
     if (dtype != OMGSR_DT_BF16 && dtype != OMGSR_DT_F16) return OMGSR_E_BADARG;
@@ -294,6 +294,38 @@ extern "C" int omgsr_axpby(const void* x, const void* y, void* out, int64_t n, f
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 6.0 * n, st);
     if (el == OMGSR_EL_F32) hipLaunchKernelGGL(axpby_kernel<float>, grid1d(n), dim3(256), 0, st, (const float*)x, (const float*)y, (float*)out, n, a, b, c, d, 0);
     else OMGSR_DISPATCH_T(hipLaunchKernelGGL(axpby_kernel<T>, grid1d(n), dim3(256), 0, st, (const T*)x, (const T*)y, (T*)out, n, a, b, c, d, bf16_steps));
+    return (int)hipGetLastError();
+}
+
+namespace {
+// y[r][n] = sum_k act(x[r][k]) * w[n][k] + b[n] in fp32, one wave per output element, FIXED summation order (lane-strided partials, then the
+// xor butterfly): the constant folds a model runs once per (timestep, prompt) - time embeddings, adaLN modulation vectors, time_emb_proj -
+// so that no vendor BLAS kernel runs in the product process. HBM-bound on w (read once, 256-byte coalesced rows).
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                         float* __restrict__ y, int rows, int K, int N, int silu_in) {
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= (int64_t)rows * N) return;
+    const int r = (int)(o / N), n = (int)(o % N), lane = threadIdx.x & 63;
+    const float* xr = x + (int64_t)r * K;
+    const float* wn = w + (int64_t)n * K;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float xv = xr[k];
+        if (silu_in) xv = xv / (1.0f + expf(-xv));
+        s = fmaf(xv, wn[k], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) y[o] = s + (b ? b[n] : 0.f);
+}
+}  // namespace
+
+extern "C" int omgsr_linear_f32(const float* x, const float* w, const float* b, float* y, int32_t rows, int32_t K, int32_t N,
+                                int32_t silu_in, void* stream) {
+    if (!x || !w || !y || rows <= 0 || K <= 0 || N <= 0) return OMGSR_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 2.0 * rows * K * N, 4.0 * ((double)N * K + (double)rows * (K + N)), st);
+    const int64_t outs = (int64_t)rows * N;
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, st, x, w, b, y, rows, K, N, silu_in);
     return (int)hipGetLastError();
 }
 

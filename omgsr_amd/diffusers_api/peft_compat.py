@@ -13,6 +13,8 @@ import os
 import torch
 import torch.nn as nn
 
+from .. import ops
+
 
 class PeftModel(nn.Module):
     def __init__(self, base: nn.Module, adapter_sd: dict, r: int, lora_alpha: float):
@@ -59,10 +61,9 @@ class PeftModel(nn.Module):
             tgt = mods[self._target_name(key)]
             w = tgt.weight
             A32, B32 = A.to(w.device, torch.float32), Bm.to(w.device, torch.float32)
-            if A32.dim() == 4:   # conv: B is [out, r, 1, 1], A is [r, in, k, k]
-                delta = torch.einsum("or,rikl->oikl", B32[:, :, 0, 0], A32)
-            else:
-                delta = B32 @ A32
+            # linear: B [out, r] @ A [r, in]; conv: B [out, r, 1, 1], A [r, in, k, k] - one rank-r product either way, in the library's
+            # fixed-order fp32 kernel when the weights already live on the GPU (no vendor BLAS in the product process)
+            delta = ops.linear_f32(B32.reshape(B32.shape[0], -1), A32.reshape(A32.shape[0], -1).t()).reshape(w.shape)
             w.add_((scale * delta).to(w.dtype))
         self._merged = True
         return self.base_model

@@ -27,7 +27,6 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..nn import InputCache, LayerNorm, Linear, RMSNormWeight, _key, bump_cache_epoch
@@ -98,9 +97,9 @@ class AdaLayerNormZero(nn.Module):
         self.norm = LayerNorm(dim, elementwise_affine=False, eps=1e-6)
 
     @torch.no_grad()
-    def fold(self, act32: torch.Tensor):
-        """silu(temb) [dim] fp32 -> `chunks` fp32 vectors (constant folding, once per (t*, guidance, prompt))."""
-        m = F.linear(act32, self.linear.weight.float(), self.linear.bias.float())
+    def fold(self, temb32: torch.Tensor):
+        """temb [dim] fp32 -> `chunks` fp32 vectors linear(silu(temb)) (constant folding, once per (t*, guidance, prompt))."""
+        m = ops.linear_f32(temb32, self.linear.weight, self.linear.bias, silu_in=True)
         return [c.contiguous() for c in m.chunk(self.chunks)]
 
 
@@ -115,9 +114,9 @@ class FluxTransformerBlock(nn.Module):
         self.norm2_context = LayerNorm(dim, elementwise_affine=False, eps=1e-6)
         self.ff_context = FluxFeedForward(dim)
 
-    def fold(self, act32):
+    def fold(self, temb32):
         def six(norm):
-            shift_a, scale_a, gate_a, shift_m, scale_m, gate_m = norm.fold(act32)
+            shift_a, scale_a, gate_a, shift_m, scale_m, gate_m = norm.fold(temb32)
             return dict(a1=(1 + scale_a).contiguous(), b1=shift_a, g1=gate_a, a2=(1 + scale_m).contiguous(), b2=shift_m, g2=gate_m)
         return dict(img=six(self.norm1), ctx=six(self.norm1_context))
 
@@ -157,8 +156,8 @@ class FluxSingleTransformerBlock(nn.Module):
         self.attn = FluxAttention(dim, heads, head_dim, joint=False, pre_only=True)
         self.attn._shares_input_with = (self.proj_mlp,)        # precision.check_policy: one LayerNorm'd operand feeds all four
 
-    def fold(self, act32):
-        shift, scale, gate = self.norm.fold(act32)
+    def fold(self, temb32):
+        shift, scale, gate = self.norm.fold(temb32)
         return dict(a=(1 + scale).contiguous(), b=shift, g=gate)
 
     def run(self, x, mod, rope, ws):
@@ -187,8 +186,8 @@ class _TextProj(nn.Module):
         self.linear_2 = Linear(dim, dim)
 
     def fp32(self, x):
-        h = F.linear(x, self.linear_1.weight.float(), self.linear_1.bias.float())
-        return F.linear(F.silu(h), self.linear_2.weight.float(), self.linear_2.bias.float())
+        h = ops.linear_f32(x, self.linear_1.weight, self.linear_1.bias)
+        return ops.linear_f32(h, self.linear_2.weight, self.linear_2.bias, silu_in=True)
 
 
 class _TimeTextEmbed(nn.Module):
@@ -300,10 +299,9 @@ class FluxTransformer2DModel(ModelMixin, _Cached):
             tt = torch.tensor([t], dtype=torch.float32, device=dev)
             gg = None if g is None else torch.tensor([g], dtype=torch.float32, device=dev)
             temb = self.time_text_embed.fp32(tt, gg, pooled.to(dev)[:1])[0]
-            act = F.silu(temb)
-            double = [b.fold(act) for b in self.transformer_blocks]
-            single = [b.fold(act) for b in self.single_transformer_blocks]
-            scale, shift = F.linear(act, self.norm_out.linear.weight.float(), self.norm_out.linear.bias.float()).chunk(2)   # scale FIRST
+            double = [b.fold(temb) for b in self.transformer_blocks]
+            single = [b.fold(temb) for b in self.single_transformer_blocks]
+            scale, shift = ops.linear_f32(temb, self.norm_out.linear.weight, self.norm_out.linear.bias, silu_in=True).chunk(2)   # scale FIRST
             out = dict(a=(1 + scale).contiguous(), b=shift.contiguous())
             return dict(double=double, single=single, out=out)
         return self._mod_cache.get((pooled,), wkey, build)

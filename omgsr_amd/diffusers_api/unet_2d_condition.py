@@ -24,7 +24,6 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..nn import Conv2d, GroupNorm, InputCache, LayerNorm, Linear, _key, bump_cache_epoch
@@ -57,9 +56,9 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = Linear(dim, dim)
 
     def fp32(self, x: torch.Tensor) -> torch.Tensor:
-        """Constant-folding path (fp32 torch math, once per timestep — not on the per-image path)."""
-        h = F.linear(x, self.linear_1.weight.float(), self.linear_1.bias.float())
-        return F.linear(F.silu(h), self.linear_2.weight.float(), self.linear_2.bias.float())
+        """Constant-folding path (fp32, the library's fixed-order kernel; once per timestep - not on the per-image path)."""
+        h = ops.linear_f32(x, self.linear_1.weight, self.linear_1.bias)
+        return ops.linear_f32(h, self.linear_2.weight, self.linear_2.bias, silu_in=True)
 
 
 class Attention(nn.Module):
@@ -277,10 +276,9 @@ class UNet2DConditionModel(ModelMixin):
                 tt = torch.tensor([t], dtype=torch.int64, device=dev)
                 emb = self.time_embedding.fp32(timestep_sinusoid(tt, self.config.block_out_channels[0],
                                                                  self.config.flip_sin_to_cos, self.config.freq_shift))
-                act = F.silu(emb)
                 out = {}
                 for r in self._resnets():
-                    v = F.linear(act, r.time_emb_proj.weight.float(), r.time_emb_proj.bias.float())[0]
+                    v = ops.linear_f32(emb, r.time_emb_proj.weight, r.time_emb_proj.bias, silu_in=True)[0]
                     out[id(r)] = (r.conv1.bias.float() + v).contiguous()
             self._temb_cache = {key: out}
         return self._temb_cache[key]

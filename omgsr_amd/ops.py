@@ -1140,6 +1140,27 @@ def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float, c: flo
     return out
 
 
+def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, silu_in: bool = False) -> torch.Tensor:
+    """fp32 constant folding: y = act(x) @ weight.T + bias with x [..., K], weight [N, K] (any float dtype; widened to fp32 first), in the
+    library's own fixed-order kernel (omgsr_linear_f32) - the time / guidance / pooled-text embeddings and the modulation vectors a model
+    derives once per (t*, guidance, prompt), so no vendor BLAS runs in the product process. Device tensors only: weights still on the host
+    (CPU-side tooling and the `not gpu` tests, where no kernel of this library can run either) take torch's fp32 math instead."""
+    w32 = weight.detach().float().contiguous()
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    x32 = x.detach().float().contiguous()
+    if not w32.is_cuda:
+        xin = torch.nn.functional.silu(x32) if silu_in else x32
+        return torch.nn.functional.linear(xin, w32, b32)
+    N, K = w32.shape
+    if x32.shape[-1] != K:
+        raise ValueError(f"linear_f32: x[..., {x32.shape[-1]}] against weight [{N}, {K}]")
+    rows = x32.numel() // K
+    y = torch.empty(x32.shape[:-1] + (N,), dtype=torch.float32, device=w32.device)
+    check(_lib.load().omgsr_linear_f32(x32.data_ptr(), w32.data_ptr(), _ptr(b32), y.data_ptr(), rows, K, N, int(silu_in), _stream()),
+          "omgsr_linear_f32")
+    return y
+
+
 def tile_accumulate(tile: Optional[torch.Tensor], w: torch.Tensor, acc: torch.Tensor, y0: int, x0: int,
                     channels: Optional[int] = None) -> None:
     """acc [N,H,W,C] f32 += tile[..., :C] * w[th,tw]; tile None accumulates the weights alone (acc [1,H,W,1])."""

@@ -881,3 +881,29 @@ def test_conv3x3_groupnorm_fused_multi_launch():
         ref = F.conv2d(F.pad(_gn_ref(x, mean, rstd, gamma, beta, G, 1, nimg).to(ops.act_dtype()).float(), (1, 1, 1, 1)), w, b) + r
         assert_close(to_nchw(y), ref, "gn-fused multi conv", rel_l2=6e-3, max_ulps=6.0)
         assert getattr(y, "_omgsr_gn", None) is not None
+
+
+# ---- round 5: the load-time constant folds in the library's own fp32 kernel (no vendor BLAS in the product process) ---------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K,N,silu,bias", [(1, 320, 1280, False, True), (1, 1280, 1280, True, True), (1, 3072, 18432, True, True),
+                                                (1, 768, 3072, False, True), (3, 257, 129, True, False), (3072, 16, 3072, False, False)])
+def test_linear_f32_constant_fold(rows, K, N, silu, bias):
+    """omgsr_linear_f32 against fp64 math: time / guidance / text embeddings, adaLN modulation, time_emb_proj and the LoRA merge's rank-r
+    product (rows = out, K = r). fp32 FMAs in a fixed order: repeat launches give the same bits."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows * 7 + K)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) if bias else None
+    ref = F.linear(F.silu(x.double()) if silu else x.double(), w.double(), None if b is None else b.double())
+    xd, wd, bd = x.cuda(), w.cuda(), None if b is None else b.cuda()
+    got = ops.linear_f32(xd, wd, bd, silu_in=silu)
+    assert got.dtype == torch.float32 and got.shape == (rows, N)
+    err = (got.double().cpu() - ref).abs().max().item()
+    assert err < 2e-6 * max(1.0, ref.abs().max().item()) * max(1.0, (K / 64) ** 0.5), err
+    assert torch.equal(got, ops.linear_f32(xd, wd, bd, silu_in=silu))
+    # 16-bit checkpoints: the weights widen to fp32 first, exactly like the reference's `.float()` folds
+    got16 = ops.linear_f32(xd, wd.bfloat16(), bd, silu_in=silu)
+    ref16 = F.linear(F.silu(x.double()) if silu else x.double(), w.bfloat16().double(), None if b is None else b.double())
+    assert (got16.double().cpu() - ref16).abs().max().item() < 2e-6 * max(1.0, ref16.abs().max().item()) * max(1.0, (K / 64) ** 0.5)
