@@ -39,7 +39,7 @@ class IgemmArgs(C.Structure):
         ("res_el", C.c_int32), ("in_split", C.c_int32), ("sample_rows", C.c_int64), ("out_lo_off", C.c_int32),
         ("in_ld", C.c_int32), ("w_split", C.c_int32), ("weight_ph", C.c_void_p), ("mx_chunks16", C.c_int32), ("mx_scale_w1", C.c_int32), ("mx_scale_a1", C.c_int32),
         ("mx_scale_w2", C.c_int32), ("mx_scale_a2", C.c_int32), ("out_mx", C.c_int32), ("group_tiles", C.c_int32), ("overflow_flag", C.c_void_p),
-        ("gn_scale_shift", C.c_void_p), ("gn_nimg", C.c_int32), ("gn_act", C.c_int32), ("in_el", C.c_int32), ("reserved1", C.c_int32),
+        ("gn_scale_shift", C.c_void_p), ("gn_nimg", C.c_int32), ("gn_act", C.c_int32), ("in_el", C.c_int32), ("mx_fmt", C.c_int32),
     ]
 
 

@@ -152,6 +152,77 @@ template <typename T> OMGSR_DEVINL void store8_mx(void* base, const int64_t row_
     *reinterpret_cast<u32x2_t*>(row + 3 * C + c) = hi8;
 }
 
+// ---- the fp6 operand form (OMGSR_EL_MX6, round 5; include/omgsr_hip.h): the same 4C-byte row whose two correction thirds hold e2m3 codes with
+// one E8M0 scale byte per 32-channel block. A 64-byte group of a third = 64 channels = two blocks; block h owns bytes [16h, 16h + 16) and
+// [32 + 16h, 40 + 16h) (its 192-bit code string, channel i at bits [6i, 6i + 6)), byte 40 + 16h (scale) and 7 zero bytes - exactly what lane-half h of
+// the halo-tile kernel's fragment reads fetches. No 2^11 on the low part: the block scale carries every magnitude.
+template <int CTRL> OMGSR_DEVINL unsigned quad_perm(const unsigned v) {          // DPP quad_perm: 0xB1 = lanes ^ 1, 0x4E = lanes ^ 2
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+OMGSR_DEVINL float quad_max(float m) {
+    m = fmaxf(m, __uint_as_float(quad_perm<0xB1>(__float_as_uint(m))));
+    return fmaxf(m, __uint_as_float(quad_perm<0x4E>(__float_as_uint(m))));
+}
+// E8M0 byte of a block whose largest magnitude is m: the largest scaled value lands in e2m3's top binade [4, 8) (7.5 < x < 8 saturates)
+OMGSR_DEVINL unsigned mx6_scale_byte(const float m) {
+    const int eb = (int)(__float_as_uint(m) >> 23) - 2;
+    return (unsigned)(eb < 0 ? 0 : eb);
+}
+// e2m3 code (sign | 2 exponent bits | 3 mantissa bits) of s = value / block scale, round to nearest even, saturating at +-7.5:
+// the grid is k/8 below 2, k/4 below 4, k/2 up to 7.5, so code = rint(|s| / step) + 8 * (binade index above [1, 2))
+OMGSR_DEVINL unsigned e2m3_code(const float s) {
+    const float a = fminf(fabsf(s), 7.5f);
+    unsigned eb = __float_as_uint(a) >> 23;
+    eb = eb < 127u ? 127u : eb;
+    const float inv_step = __uint_as_float((257u - eb) << 23);          // 8, 4, 2 for |s| in [0, 2), [2, 4), [4, 7.5]
+    const unsigned q = (unsigned)(int)__builtin_rintf(a * inv_step);
+    return (q + ((eb - 127u) << 3)) | ((__float_as_uint(s) >> 26) & 32u);
+}
+// eight values -> 48 bits (w0: 32, w1: 16)
+OMGSR_DEVINL void e2m3_pack8(const float (&v)[8], const float inv_scale, unsigned& w0, unsigned& w1) {
+    unsigned c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = e2m3_code(v[e] * inv_scale);
+    w0 = c[0] | (c[1] << 6) | (c[2] << 12) | (c[3] << 18) | (c[4] << 24) | (c[5] << 30);
+    w1 = (c[5] >> 2) | (c[6] << 4) | (c[7] << 10);
+}
+// 8 channels c .. c + 7 of a row. COOPERATIVE: lanes 4k .. 4k + 3 of the wave must hold the four octets (c & 31) = 0, 8, 16, 24 of ONE block of ONE
+// row, all of them active (the thread-per-octet kernels - cast, GroupNorm apply - map consecutive lanes to consecutive octets and C % 64 == 0).
+template <typename T> OMGSR_DEVINL void store8_mx6(void* base, const int64_t row_byte0, const int C, const int c, const float (&f)[8]) {
+    unsigned char* row = reinterpret_cast<unsigned char*>(base) + row_byte0;
+    u32x4_t hi;
+    float ah[8], al[8], mh = 0.0f, ml = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned int h2 = pack2<T>(f[2 * q], f[2 * q + 1]);
+        hi[q] = h2;
+        ah[2 * q] = lo_of<T>(h2, 0); ah[2 * q + 1] = lo_of<T>(h2, 1);
+        al[2 * q] = f[2 * q] - ah[2 * q]; al[2 * q + 1] = f[2 * q + 1] - ah[2 * q + 1];
+        mh = fmaxf(mh, fmaxf(fabsf(ah[2 * q]), fabsf(ah[2 * q + 1])));
+        ml = fmaxf(ml, fmaxf(fabsf(al[2 * q]), fabsf(al[2 * q + 1])));
+    }
+    *reinterpret_cast<u32x4_t*>(row + 2 * c) = hi;
+    const unsigned sl = mx6_scale_byte(quad_max(ml)), sh = mx6_scale_byte(quad_max(mh));
+    const int oct = (c >> 3) & 3;
+    unsigned char* grp = row + 2 * C + (c >> 6) * 64 + ((c >> 5) & 1) * 16;        // the block's first 16 bytes in the a_lo' third; + C: a_hi'
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+        const unsigned sb = seg ? sh : sl;
+        unsigned w0, w1;
+        e2m3_pack8(seg ? ah : al, __uint_as_float((254u - sb) << 23), w0, w1);
+        const unsigned o0 = quad_perm<0xB1>(w0), o1 = quad_perm<0xB1>(w1);       // the odd octet's bits reach its even partner
+        const unsigned d0 = w0, d1 = w1 | (o0 << 16), d2 = (o0 >> 16) | (o1 << 16);
+        unsigned char* g = grp + seg * C;
+        if (oct == 0) {
+            *reinterpret_cast<u32x2_t*>(g) = u32x2_t{d0, d1};
+            *reinterpret_cast<unsigned*>(g + 8) = d2;
+        } else if (oct == 2) {
+            *reinterpret_cast<unsigned*>(g + 12) = d0;
+            *reinterpret_cast<u32x4_t*>(g + 32) = u32x4_t{d1, d2, sb, 0u};
+        }
+    }
+}
+
 // store: EL 0 = 16-bit at base[idx]; 1 = fp32 at base[idx]; 2 = split, hi at base[idx], lo at base[idx + lo_off]
 template <typename T, int EL> OMGSR_DEVINL void store8(void* base, const int64_t idx, const int64_t lo_off, const float (&f)[8]) {
     if constexpr (EL == 1) {

@@ -74,6 +74,7 @@ __global__ void to_operand_kernel(const float* __restrict__ x, void* __restrict_
         float f[8];
         load8<T, true>(x, r * C + g * 8, f);
         if constexpr (YEL == 3) store8_mx<T>(y, r * 4 * C, C, g * 8, f);
+        else if constexpr (YEL == 4) store8_mx6<T>(y, r * 4 * C, C, g * 8, f);        // (lanes 4k .. 4k + 3 = the four octets of one block: ng % 8 == 0)
         else store8<T, YEL>(y, r * (YEL == 2 ? 2 * C : C) + g * 8, C, f);
         if constexpr (std::is_same<T, f16_t>::value) {
 #pragma unroll
@@ -265,13 +266,14 @@ extern "C" int omgsr_copy_channels(const void* src, void* dst, int64_t rows, int
 }
 
 extern "C" int omgsr_to_operand(const float* x, void* y, int64_t rows, int32_t C, int32_t y_el, uint32_t* overflow_flag, void* stream) {
-    if (!x || !y || rows <= 0 || C <= 0 || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT && y_el != OMGSR_EL_MX)) return OMGSR_E_BADARG;
+    if (!x || !y || rows <= 0 || C <= 0 || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT && y_el != OMGSR_EL_MX && y_el != OMGSR_EL_MX6)) return OMGSR_E_BADARG;
     if (C & 7) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, (y_el == OMGSR_EL_16 ? 6.0 : 8.0) * rows * C, st);
-    if (y_el == OMGSR_EL_MX) {        // fp16 compute type, whole 64-channel fp8 chunks
+    if (y_el == OMGSR_EL_MX || y_el == OMGSR_EL_MX6) {        // fp16 compute type, whole 64-channel correction chunks
         if ((C & 63) || omgsr::compute_dtype() != 1) return OMGSR_E_SHAPE;
-        hipLaunchKernelGGL((to_operand_kernel<f16_t, 3>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C, overflow_flag);
+        if (y_el == OMGSR_EL_MX6) hipLaunchKernelGGL((to_operand_kernel<f16_t, 4>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C, overflow_flag);
+        else hipLaunchKernelGGL((to_operand_kernel<f16_t, 3>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C, overflow_flag);
     } else if (y_el == OMGSR_EL_SPLIT) OMGSR_DISPATCH_T(hipLaunchKernelGGL((to_operand_kernel<T, 2>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C, overflow_flag));
     else OMGSR_DISPATCH_T(hipLaunchKernelGGL((to_operand_kernel<T, 0>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C, overflow_flag));
     return (int)hipGetLastError();

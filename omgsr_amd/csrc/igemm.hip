@@ -528,6 +528,8 @@ int validate_args(omgsr_igemm_args& a) {
     if (a.Cin % (8 * ksegs)) return OMGSR_E_SHAPE;
     // an MX operand is understood by the halo-tile kernel (3x3 convs, mx_geometry_ok) and by the MX GEMM kernel (1x1: igemm_gmx.hip)
     if (a.mx_chunks16 < 0 || (a.mx_chunks16 > 0 && !mx_geometry_ok(a) && !omgsr::igemm_gmx_ok(a))) return OMGSR_E_SHAPE;
+    // ... the fp6 form (OMGSR_EL_MX6) by the halo-tile kernel's nine-tap forms only
+    if (a.mx_chunks16 > 0 && a.mx_fmt != 0 && a.mx_fmt != 8 && (a.mx_fmt != 6 || a.upsample || !mx_geometry_ok(a))) return OMGSR_E_SHAPE;
     if (a.out_mx && (a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cout & 63) || a.out_lo_off || a.out_ld || a.gn_partial ||
                      omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
     if (a.gn_scale_shift && (a.gn_nimg <= 0 || a.gn_act != OMGSR_ACT_SILU || !gn_fusable(a))) return OMGSR_E_SHAPE;      // (SiLU is the one activation the producer applies)
@@ -615,7 +617,7 @@ extern "C" int omgsr_igemm_multi(const omgsr_igemm_args* args, int32_t count, vo
                           a.act == grp[0].act && a.out_dtype == grp[0].out_dtype && a.out_lo_off == grp[0].out_lo_off && a.out_ld == grp[0].out_ld &&
                           a.res_el == grp[0].res_el && (a.residual != nullptr) == (grp[0].residual != nullptr) &&
                           (a.gn_partial != nullptr) == (grp[0].gn_partial != nullptr) && a.gn_entries == grp[0].gn_entries && a.bias == grp[0].bias &&
-                          a.gate == grp[0].gate && a.alpha == grp[0].alpha && a.upsample == grp[0].upsample && a.mx_chunks16 == grp[0].mx_chunks16 && a.out_mx == grp[0].out_mx &&
+                          a.gate == grp[0].gate && a.alpha == grp[0].alpha && a.upsample == grp[0].upsample && a.mx_chunks16 == grp[0].mx_chunks16 && a.mx_fmt == grp[0].mx_fmt && a.out_mx == grp[0].out_mx &&
                           ((a.Cout <= 32) == (grp[0].Cout <= 32)) && ((omgsr::igemm_halo_flat(a) != 0) == (omgsr::igemm_halo_flat(grp[0]) != 0)) &&
                           (a.gn_scale_shift != nullptr) == (grp[0].gn_scale_shift != nullptr) && a.gn_act == grp[0].gn_act;
         if (m < 0) {                     // not a halo problem: its own launch, in order

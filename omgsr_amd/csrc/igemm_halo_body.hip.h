@@ -88,7 +88,7 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 // fp32 chunk is 42 KB: no LDS room): loads held in VGPRs across K-steps next to inline-asm DMA traffic the compiler cannot count - not built.
 // SPLITK (round 5): the workgroup runs the chunk range IgemmGeo.cc0 .. cc1 of the contraction (split-K launch groups). A template flag, not a run-time
 // test: with the two extra loop bounds live the FLAT instantiations - already at 256 registers - went from 3 to 38 spilled VGPRs.
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, int FLAT = 0, int GNF = 0, bool SPLITK = false>      // FLAT: 0 spatial tiles, 1 FLAT form, 2 FLAT form with the 27-piece patch
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, int MX = 0, int FLAT = 0, int GNF = 0, bool SPLITK = false>      // MX: 0 plain, 1 fp8 correction chunks, 6 fp6 ones; FLAT: 0 spatial tiles, 1 FLAT form, 2 FLAT form with the 27-piece patch
 OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const int tile, const int bidy) {      // tile: logical (XCD-remapped) tile index
     static_assert(GNF == 0 || (TAPS == 9 && !MX && FLAT == 0 && ABL == 0 && !PRIO), "GNF: spatial nine-tap form only");
     constexpr int WTN = NARROW ? 32 : 64, FM = NARROW ? 2 : 4, FN = NARROW ? 1 : 2, BNK = NARROW ? 32 : 128;
@@ -288,7 +288,8 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
     const int seg2_at = n16 + (g.nk - n16) / 2;          // first chunk of the a_hi' x w_lo' segment
     auto step = [&](auto tap_c, auto par_c, auto f8_c, const int cc, const int s) {
         constexpr int tap = decltype(tap_c)::value, par = decltype(par_c)::value;
-        constexpr bool F8 = decltype(f8_c)::value;
+        constexpr int FMT = (int)decltype(f8_c)::value;          // 0: fp16 / bf16 chunk; 1: fp8 (e4m3) correction chunk; 2: fp6 (e2m3) correction chunk
+        constexpr bool F8 = FMT != 0;
         // wait for slice s: only what the PREVIOUS step issued may still be in flight. lgkmcnt(0): every fragment read of the
         // previous step has RETURNED before this wave passes the barrier that lets the others overwrite that stage - hipcc
         // is free to sink MFMAs (and the lgkmcnt wait in front of them) below the barrier, and a ds_read still queued
@@ -331,9 +332,51 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
             typedef int i32x4_t __attribute__((ext_vector_type(4)));
             // the scale operands are VGPRs written by VALU moves: set them up in front of the fragment reads (the asm MFMAs that read them
             // are invisible to the compiler's hazard padding; the LDS reads and their wait put >> the 2 required wait states in between)
+            if constexpr (MX == 6) {
+                // MX == 6 (OMGSR_EL_MX6, round 5): the same 64-byte rows and fragment addresses; of a lane's 32 bytes the first 24 are ITS 32-channel
+                // block (e2m3 codes: 6 registers), byte 24 is the block's E8M0 scale. The 8-pass fp6 form of the instruction (cbsz / blgp = 2) takes
+                // the six registers and, per lane, the scale bytes of both fragments. A template value, not a run-time branch: both forms in one
+                // kernel cost 100+ spilled registers (the allocator loses track of the tied accumulators); 24 data bytes + 1 scale byte per read
+                // instead of the whole 32: two registers less per fragment (24 spilled registers with 8-register fragments).
+                typedef int i32x2_t __attribute__((ext_vector_type(2)));
+                typedef int i32x6_t __attribute__((ext_vector_type(6)));
+                i32x6_t a6[FM], b6[FN];
+                int sa6[FM], sb6[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const unsigned char* q = As + i * AIMM + aoff[tap][FLAT ? 0 : i];
+                    const unsigned char* q2 = As + i * AIMM + (aoff[tap][FLAT ? 0 : i] ^ 32);
+                    const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(q);
+                    const i32x2_t hi = *reinterpret_cast<const i32x2_t*>(q2);
+                    a6[i] = i32x6_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1]};
+                    sa6[i] = q2[8];
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(Bs + j * 32 * 64 + boff0);
+                    const i32x2_t hi = *reinterpret_cast<const i32x2_t*>(Bs + j * 32 * 64 + boff1);
+                    b6[j] = i32x6_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1]};
+                    sb6[j] = Bs[j * 32 * 64 + boff1 + 8];
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
+                                     : "+v"(acc[i][j]) : "v"(b6[j]), "v"(a6[i]), "v"(sb6[j]), "v"(sa6[i]));   // transposed tile
+                    if constexpr (LATE) {
+                        if (i == FM / 2 - 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_dma();
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                return;
+            }
+            i32x8_t a8[FM], b8[FN];
             int sw = cc < seg2_at ? p.mx_scale_w1 : p.mx_scale_w2, sa = cc < seg2_at ? p.mx_scale_a1 : p.mx_scale_a2;
             asm volatile("" : "+v"(sw), "+v"(sa));
-            i32x8_t a8[FM], b8[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i)
                 a8[i] = __builtin_shufflevector(*reinterpret_cast<const i32x4_t*>(As + i * AIMM + aoff[tap][FLAT ? 0 : i]),
@@ -421,15 +464,15 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
     int cc = cbeg;
     const int e16 = (SPLITK && n16 > ncc) ? ncc : n16;      // (a split-K range lies on one side of the fp16 / fp8 boundary, so patch parity restarts at 0 on both)
     for (; cc < e16; cc += 2) {
-        chunk(std::integral_constant<int, 0>{}, std::false_type{}, cc);
-        if (cc + 1 < e16) chunk(std::integral_constant<int, 1>{}, std::false_type{}, cc + 1);
+        chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, cc);
+        if (cc + 1 < e16) chunk(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, cc + 1);
     }
     if constexpr (MX && std::is_same<T, f16_t>::value && !NARROW && ABL == 0 && !PRIO) {
         // the fp8 segments of an MX problem (mx_chunks16 even, so the patch parity starts over at 0; n16 == ncc otherwise)
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");        // (the asm MFMAs below are invisible to the compiler's hazard padding)
         for (; cc < ncc; cc += 2) {
-            chunk(std::integral_constant<int, 0>{}, std::true_type{}, cc);
-            if (cc + 1 < ncc) chunk(std::integral_constant<int, 1>{}, std::true_type{}, cc + 1);
+            chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, cc);
+            if (cc + 1 < ncc) chunk(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, cc + 1);
         }
         // the last asm MFMAs (16 passes each) must have written the accumulators before the epilogue's VALU reads them
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -486,7 +529,7 @@ OMGSR_DEVINL bool phase_block_map(const int b, const int T, const int n8, const 
     return tile < T;
 }
 
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, bool MX = false, int FLAT = 0, int GNF = 0>
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, int MX = 0, int FLAT = 0, int GNF = 0>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     int tile, phase;
     // Phase form (TAPS = 4). The four phases of a tile read the SAME low-res patch and each its own phase-summed weights. Three block orders:
@@ -515,7 +558,7 @@ struct HaloMulti {
     int start[HALO_MULTI_MAX + 1];
     int count;
 };
-template <typename T, bool NARROW, int TAPS, bool MX = false, int FLAT = 0, int GNF = 0, bool SPLITK = false>
+template <typename T, bool NARROW, int TAPS, int MX = 0, int FLAT = 0, int GNF = 0, bool SPLITK = false>
 __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMulti m) {
     int s = 0, tile, phase;
     if (TAPS == 4 && m.g[0].interleave) {      // x-only grid of 4 x the 8-aligned ranges; block order inside a problem's range: see igemm_halo_kernel

@@ -28,8 +28,11 @@ static int flat_attrs() {
     }
     return 0;
 }
+int igemm_halo_flat_launch_mx6(const omgsr_igemm_args& a, const IgemmGeo& g, hipStream_t st);        // igemm_halo_mx6_flat.hip
+int igemm_halo_flat_launch_multi_mx6(const void* halo_multi, unsigned blocks, bool big, hipStream_t st);
 // one problem per grid; g comes from halo_geo (g.flat != 0)
 int igemm_halo_flat_launch(const omgsr_igemm_args& a, const IgemmGeo& g, hipStream_t st) {
+    if (a.mx_chunks16 > 0 && a.mx_fmt == 6) return igemm_halo_flat_launch_mx6(a, g, st);
     const int rc = flat_attrs();
     if (rc != 0) return rc;
     const dim3 grid(g.ntm * g.ntn);
@@ -51,6 +54,7 @@ int igemm_halo_flat_launch_multi(const void* halo_multi, unsigned blocks, hipStr
     if (rc != 0) return rc;
     bool big = false;
     for (int i = 0; i < m.count; ++i) big = big || m.g[i].flat > 47;         // one kernel per launch: the 27-piece patch serves the narrower problems too
+    if (m.p[0].mx_chunks16 > 0 && m.p[0].mx_fmt == 6) return igemm_halo_flat_launch_multi_mx6(halo_multi, blocks, big, st);
     if (big) {
         if (m.p[0].mx_chunks16 > 0) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, true, 2>), dim3(blocks), dim3(256), LDS_BYTES_BIG, st, m);
         else if (omgsr::compute_dtype() == 1) hipLaunchKernelGGL((igemm_halo_multi_kernel<f16_t, false, 9, false, 2>), dim3(blocks), dim3(256), LDS_BYTES_BIG, st, m);

@@ -223,6 +223,8 @@ __global__ __launch_bounds__(256) void gn_apply_any_kernel(const void* __restric
     // YEL 3 = OMGSR_EL_MX: [hi fp16 | lo' fp8 | hi' fp8], 4C bytes per pixel (common.hip.h store8_mx)
     auto put = [&](const int64_t pix, const int cc8, const float (&v)[8]) {
         if constexpr (YEL == 3) store8_mx<T>(y, pix * 4 * C, C, cc8 * 8, v);
+        else if constexpr (YEL == 4) store8_mx6<T>(y, pix * 4 * C, C, cc8 * 8, v);     // OMGSR_EL_MX6; cooperative over lane quads: consecutive lanes hold
+                                                                                       // consecutive octets of one pixel and C % 64 == 0 (every loop below keeps quads together)
         else store8<T, YEL>(y, pix * ldy + cc8 * 8, C, v);
     };
     // second output: x itself as an operand - plain, two-term split, or (Y2EL 3, round 4) the mixed-precision form of a 1x1 shortcut
@@ -645,8 +647,8 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
                     const float* beta, int32_t N, int64_t HW, int32_t C, int32_t G, int32_t act, int32_t stat_rows, int32_t x_el,
                     int32_t y_el, void* y2, int32_t y2_el, uint32_t* ovf, void* stream) {
     if (!x || !y || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0) return OMGSR_E_BADARG;
-    if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT && y_el != OMGSR_EL_MX)) return OMGSR_E_BADARG;
-    if (y_el == OMGSR_EL_MX && ((C & 63) || omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;        // fp16 compute type, whole 64-channel fp8 chunks
+    if ((x_el != OMGSR_EL_16 && x_el != OMGSR_EL_F32) || (y_el != OMGSR_EL_16 && y_el != OMGSR_EL_SPLIT && y_el != OMGSR_EL_MX && y_el != OMGSR_EL_MX6)) return OMGSR_E_BADARG;
+    if ((y_el == OMGSR_EL_MX || y_el == OMGSR_EL_MX6) && ((C & 63) || omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;        // fp16 compute type, whole 64-channel correction chunks
     if (y2 && (x_el != OMGSR_EL_F32 || (y2_el != OMGSR_EL_16 && y2_el != OMGSR_EL_SPLIT && y2_el != OMGSR_EL_MX))) return OMGSR_E_BADARG;
     if (y2 && y2_el == OMGSR_EL_MX && ((C & 63) || omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
     if ((C & 7) || (C % G) || C > 8192) return OMGSR_E_SHAPE;
@@ -669,7 +671,16 @@ int gn_apply_launch(const void* x, void* y, const float* mean, const float* rstd
     const dim3 grid(nblk, N);
 #define OMGSR_GN_ANY2(YE, Y2) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, true, YE, Y2>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf))
 #define OMGSR_GN_ANY(XF, YE) OMGSR_DISPATCH_T(hipLaunchKernelGGL((gn_apply_any_kernel<T, XF, YE>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows))
-    if (y2 && y2_el == OMGSR_EL_MX) {        // the shortcut's operand in the mixed-precision form (fp16 compute type)
+    if (y_el == OMGSR_EL_MX6) {              // fp6 correction thirds for a 3x3 conv of the halo-tile kernel (round 5); the twin keeps its own form
+        using T = f16_t;
+#define OMGSR_GN_6(XF, Y2) hipLaunchKernelGGL((gn_apply_any_kernel<T, XF, 4, Y2>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf)
+        if (y2 && y2_el == OMGSR_EL_MX) OMGSR_GN_6(true, 3);
+        else if (y2 && y2_el == OMGSR_EL_SPLIT) OMGSR_GN_6(true, 2);
+        else if (y2) OMGSR_GN_6(true, 0);
+        else if (x_el == OMGSR_EL_F32) hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 4>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, nullptr, nullptr);
+        else hipLaunchKernelGGL((gn_apply_any_kernel<T, false, 4>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, nullptr, nullptr);
+#undef OMGSR_GN_6
+    } else if (y2 && y2_el == OMGSR_EL_MX) {        // the shortcut's operand in the mixed-precision form (fp16 compute type)
         using T = f16_t;
         if (y_el == OMGSR_EL_MX) hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 3, 3>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf);
         else if (y_el == OMGSR_EL_SPLIT) hipLaunchKernelGGL((gn_apply_any_kernel<T, true, 2, 3>), grid, dim3(256), lds, st, x, y, mean, rstd, gamma, beta, HW, C, G, act, ppb, stat_rows, y2, ovf);

@@ -26,14 +26,14 @@ from ._lib import AttnArgs, IgemmArgs, check
 ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_GEGLU = 0, 1, 2, 3
 OUT_STREAM, OUT_BF16, OUT_F32 = -1, 0, 1      # conv / linear outputs: stream tensor (default) | 16-bit operand | fp32
 LAYOUT_NHWC, LAYOUT_T = 0, 1
-EL_16, EL_F32, EL_SPLIT, EL_MX = 0, 1, 2, 3
+EL_16, EL_F32, EL_SPLIT, EL_MX, EL_MX6 = 0, 1, 2, 3, 4
 MX_LO_SHIFT = 11          # OMGSR_MX_LO_SHIFT (csrc/common.hip.h): a_lo' = (a - a_hi) * 2^11 as fp8
 
 
 def _el_of_split(split: int) -> int:
     """Operand form of a `split` code: 1 plain, 2 two-term split [hi | lo] (both fp16), 3 the mixed-precision form
     [hi fp16 | lo' fp8 | hi' fp8] (OMGSR_EL_MX: same row width as 2, its correction segments run as block-scaled fp8 MFMAs)."""
-    return {1: EL_16, 2: EL_SPLIT, 3: EL_MX}[split]
+    return {1: EL_16, 2: EL_SPLIT, 3: EL_MX, 4: EL_MX6}[split]
 
 
 _ACT = torch.bfloat16
@@ -252,6 +252,7 @@ class PackedWeight:
     split: int = 1     # 2: the input is a two-term split operand [hi | lo]: every input channel packed twice ([w | w]);
                        # 3: the mixed-precision form (OMGSR_EL_MX operand; fp16 [w_hi] + fp8 [w_hi' | w_lo'] per tap, `mx`)
     mx: Optional[tuple] = None      # split 3: (fp16 chunks per tap, E8M0 scale of w_hi', of a_lo', of w_lo', of a_hi')
+    mx_fmt: int = 0                 # 6: split 4, the fp6 form (OMGSR_EL_MX6: e2m3 codes + per-block scale bytes in the data; `mx` scales unused)
     w_split: int = 1   # 2: the weight itself is carried as w_hi + w_lo: one more K segment [w_lo] that re-reads the operand's
                        # first (hi) half - the contraction WRAPS (omgsr_igemm_args.in_ld); `cin` counts every segment
     in_ld: int = 0     # physical channels of the operand row this weight expects (split * padded Cin); 0 = cin
@@ -290,6 +291,42 @@ def _mx_rows(w: torch.Tensor, s1: int, s2: int) -> torch.Tensor:
     return torch.cat([w_hi.contiguous().view(torch.uint8).reshape(*w.shape[:-1], 2 * w.shape[-1]), hi8, lo8], dim=-1)
 
 
+def _e2m3_blocks(v: torch.Tensor) -> torch.Tensor:
+    """[..., C] fp32 (C % 64 == 0) -> [..., C] uint8: one correction third of an OMGSR_EL_MX6 row (include/omgsr_hip.h). Every 64-byte group covers
+    64 channels = two 32-channel blocks; block h owns bytes [16h, 16h + 16) and [32 + 16h, 40 + 16h) (its 192-bit string of e2m3 codes, channel i
+    at bits [6i, 6i + 6)), byte 40 + 16h (E8M0 scale = max(0, biased exponent of the block's largest magnitude - 2)) and 7 zero bytes. Codes round
+    to nearest even and saturate at +-7.5. The SAME integer arithmetic as the device producers (csrc/common.hip.h store8_mx6): tests compare bytes."""
+    lead, Cc = v.shape[:-1], v.shape[-1]
+    b = v.reshape(-1, Cc // 32, 32).float()
+    m = b.abs().amax(-1)
+    sb = ((m.view(torch.int32) >> 23) - 2).clamp(min=0)                                    # [R, nb] scale bytes
+    inv = ((254 - sb) << 23).to(torch.int32).view(torch.float32).unsqueeze(-1)
+    s_ = b * inv
+    a = s_.abs().clamp(max=7.5)
+    eb = (a.view(torch.int32) >> 23).clamp(min=127)
+    q = torch.round(a * ((257 - eb) << 23).to(torch.int32).view(torch.float32)).to(torch.int64)      # torch.round: half to even, like v_rndne
+    code = (q + ((eb.to(torch.int64) - 127) << 3)) | (((s_.view(torch.int32).to(torch.int64) >> 26) & 32))
+    # four codes = 24 bits = three bytes: code i sits at bits [6i, 6i + 6) of the block's little-endian 192-bit string
+    c4 = code.reshape(*code.shape[:-1], 8, 4)
+    v24 = c4[..., 0] | (c4[..., 1] << 6) | (c4[..., 2] << 12) | (c4[..., 3] << 18)
+    string = torch.stack([v24 & 0xFF, (v24 >> 8) & 0xFF, (v24 >> 16) & 0xFF], dim=-1).to(torch.uint8).reshape(*code.shape[:-1], 24)
+    R, nb = string.shape[0], string.shape[1]
+    out = torch.zeros((R, nb // 2, 64), dtype=torch.uint8, device=v.device)
+    st = string.reshape(R, nb // 2, 2, 24)
+    sbv = sb.reshape(R, nb // 2, 2).to(torch.uint8)
+    for h in (0, 1):
+        out[..., 16 * h:16 * h + 16] = st[..., h, :16]
+        out[..., 32 + 16 * h:40 + 16 * h] = st[..., h, 16:]
+        out[..., 40 + 16 * h] = sbv[..., h]
+    return out.reshape(*lead, Cc)
+
+
+def _mx6_rows(w: torch.Tensor) -> torch.Tensor:
+    """[..., C] fp32 -> [..., 4C] uint8: [w_hi fp16 | e2m3 blocks of w_hi | e2m3 blocks of w - w_hi] (meets an OMGSR_EL_MX6 operand's [a_hi | a_lo' | a_hi'])."""
+    w_hi = w.to(torch.float16)
+    return torch.cat([w_hi.contiguous().view(torch.uint8).reshape(*w.shape[:-1], 2 * w.shape[-1]), _e2m3_blocks(w_hi.float()), _e2m3_blocks(w - w_hi.float())], dim=-1)
+
+
 def _mx_shift(t: torch.Tensor) -> int:
     """s with max |t| 2^s in [128, 256): e4m3 tops out at 448, its 17 binades below cover values 5 orders of magnitude under the largest."""
     import math
@@ -297,11 +334,16 @@ def _mx_shift(t: torch.Tensor) -> int:
     return max(-100, min(100, 7 - math.floor(math.log2(m)))) if m > 0 else 0
 
 
-def _pack_mx(w: torch.Tensor, bias, cout: int, cin: int, R: int, S: int, dev, upsample_phases: bool = False) -> "PackedWeight":
+def _pack_mx(w: torch.Tensor, bias, cout: int, cin: int, R: int, S: int, dev, upsample_phases: bool = False, fmt: int = 8) -> "PackedWeight":
     """[Cout, R, S, C] fp32 -> the mixed-precision weight of an OMGSR_EL_MX operand: per tap 4C bytes = 2C 16-bit slots,
     [w_hi fp16 (2C B) | w_hi' fp8 (C B) | w_lo' fp8 (C B)] with w_hi = fp16(w), w_hi' = fp8(w_hi 2^s1), w_lo' = fp8((w - w_hi) 2^s2): the
     first C / 32 chunks meet a_hi in fp16 MFMAs, then C / 64 fp8 chunks meet a_lo' (w_hi') and C / 64 meet a_hi' (w_lo') in block-scaled
-    fp8 MFMAs whose E8M0 scale operands undo s1 / s2 and the operand's 2^11."""
+    fp8 MFMAs whose E8M0 scale operands undo s1 / s2 and the operand's 2^11.
+    fmt 6 (split 4, OMGSR_EL_MX6; 3x3 convs of the halo-tile kernel only): the two correction thirds hold fp6 (e2m3) codes with a scale byte per
+    32-channel block inside the data (_e2m3_blocks) - the MFMA runs them in half the passes of fp8."""
+    if fmt == 6 and ((R, S) != (3, 3) or upsample_phases):
+        raise ValueError("the fp6 form (split 4) serves 3x3 stride-1 convolutions of the halo-tile kernel's nine-tap form")
+    rows = (lambda t: _mx6_rows(t)) if fmt == 6 else (lambda t: _mx_rows(t, s1, s2))
     if (R, S) not in ((3, 3), (1, 1)) or cin % 64 or act_dtype() != torch.float16:
         raise ValueError("the mixed-precision (MX) form serves 3x3 and 1x1 convolutions (linears) with Cin % 64 == 0 in the fp16 compute type")
     ph = _phase_kernels(w) if upsample_phases else None       # [4, Cout, 2, 2, C]: one set of scales for the taps AND the phase sums
@@ -311,15 +353,17 @@ def _pack_mx(w: torch.Tensor, bias, cout: int, cin: int, R: int, S: int, dev, up
     kslots = 2 * cin                                           # 16-bit slots per tap
     cout_pad = _round_up(cout, 256 if cout >= 256 else 128)
     out = torch.zeros((cout_pad, R * S * kslots), device=dev, dtype=torch.float16)
-    out[:cout] = _mx_rows(w, s1, s2).reshape(cout, R * S * 4 * cin).contiguous().view(torch.float16)
+    out[:cout] = rows(w).reshape(cout, R * S * 4 * cin).contiguous().view(torch.float16)
     # 3x3: slice-major copy for the halo-tile kernel; 1x1 (a Linear): `out` itself is what igemm_gmx_kernel streams, row by row
     w_cm = out.view(cout_pad, 9, kslots // 32, 32).permute(2, 1, 0, 3).contiguous() if R == 3 else None
     w_ph = None
     if ph is not None:
         full = torch.zeros((4, cout_pad, 4 * kslots), device=dev, dtype=torch.float16)
-        full[:, :cout] = _mx_rows(ph, s1, s2).reshape(4, cout, 4 * 4 * cin).contiguous().view(torch.float16)
+        full[:, :cout] = rows(ph).reshape(4, cout, 4 * 4 * cin).contiguous().view(torch.float16)
         w_ph = full.view(4, cout_pad, 4, kslots // 32, 32).permute(0, 3, 2, 1, 4).contiguous()         # [phase][chunk][tap][Cout_pad][32]
     b = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if fmt == 6:
+        return PackedWeight(out, b, cout, kslots, R, S, w_cm=w_cm, split=4, w_split=1, in_ld=kslots, w_ph=None, mx=(cin // 32, 127, 127, 127, 127), mx_fmt=6)
     return PackedWeight(out, b, cout, kslots, R, S, w_cm=w_cm, split=3, w_split=1, in_ld=kslots, w_ph=w_ph,
                         mx=(cin // 32, 127 - s1, 127 - MX_LO_SHIFT, 127 - s2, 127))
 
@@ -365,10 +409,10 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
     w = _note_weight_range(weight.detach().to(device=dev, dtype=torch.float32)).permute(0, 2, 3, 1)  # [Cout,R,S,Cin]
     if cin8 != cin:
         w = torch.nn.functional.pad(w, (0, cin8 - cin))
-    if split == 3:
+    if split in (3, 4):
         if cin8 != cin:
             raise ValueError("the mixed-precision (MX) form needs Cin % 64 == 0")
-        return _pack_mx(w, bias if bias is None else bias.detach().to(dev), cout, cin, R, S, dev, upsample_phases)
+        return _pack_mx(w, bias if bias is None else bias.detach().to(dev), cout, cin, R, S, dev, upsample_phases, fmt=6 if split == 4 else 8)
     if split not in (1, 2) or w_split not in (1, 2):
         raise ValueError("split / w_split must be 1 or 2")
     if w_split == 2 and bool(torch.equal(w.to(act_dtype()).float(), w)):
@@ -460,12 +504,15 @@ def _fill_k(a: IgemmArgs, pw: PackedWeight) -> None:
     a.w_split = int(pw.w_split == 2)
     if pw.mx is not None:
         a.mx_chunks16, a.mx_scale_w1, a.mx_scale_a1, a.mx_scale_w2, a.mx_scale_a2 = pw.mx
+        a.mx_fmt = pw.mx_fmt
 
 
 def _fill_out(a: IgemmArgs, out: torch.Tensor, out_split: int, residual: Optional[torch.Tensor], cout: int) -> None:
     a.out = out.data_ptr()
     a.out_dtype = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
     a.out_lo_off = cout if out_split == 2 else 0
+    if out_split == 4:
+        raise ValueError("no GEMM epilogue writes the fp6 operand form (OMGSR_EL_MX6): its producers are the GroupNorm apply and cast kernels")
     a.out_mx = int(out_split == 3)
     if residual is not None:
         a.residual = residual.data_ptr()
@@ -933,8 +980,8 @@ def group_norm_stats_merged(tensors, tiles, N: int, groups: int, eps: float):
 
 
 def _operand_like(x: torch.Tensor, split: int) -> torch.Tensor:
-    if split not in (1, 2, 3):
-        raise ValueError("split must be 1, 2 or 3 (MX)")
+    if split not in (1, 2, 3, 4):
+        raise ValueError("split must be 1, 2, 3 (MX) or 4 (MX6)")
     return torch.empty((*x.shape[:-1], x.shape[-1] * min(split, 2)), device=x.device, dtype=_ACT)
 
 

@@ -825,3 +825,135 @@ def test_vae_attention_qk_split_path():
     print(f"VAE attention: logits q / k single {e1:.2e} -> split {e2:.2e}; branch output {e_plain:.2e} -> {e_sharp:.2e}")
     assert e2 < 3e-6 and e1 > 30 * e2, (e1, e2)
     assert not torch.equal(plain, sharp) and e_sharp <= 1.05 * e_plain and e_sharp < 4e-4, (e_plain, e_sharp)
+
+
+# ---- round 5: fp6 (e2m3) correction segments with per-block scales (OMGSR_EL_MX6, split 4; VERDICT r4 item 4) -----------------------------------
+
+_E2M3 = torch.tensor([0, .125, .25, .375, .5, .625, .75, .875, 1, 1.125, 1.25, 1.375, 1.5, 1.625, 1.75, 1.875,
+                      2, 2.25, 2.5, 2.75, 3, 3.25, 3.5, 3.75, 4, 4.5, 5, 5.5, 6, 6.5, 7, 7.5], dtype=torch.float64)
+
+
+def _mx6_third(raw):
+    """[..., C] uint8 (one correction third of an OMGSR_EL_MX6 row) -> [..., C] float64, decoded straight from the format's definition
+    (include/omgsr_hip.h): per 64-byte group two blocks; block h = bytes [16h, 16h + 16) + [32 + 16h, 40 + 16h), scale byte 40 + 16h."""
+    lead, C = raw.shape[:-1], raw.shape[-1]
+    g = raw.reshape(-1, C // 64, 64).to(torch.int64)
+    out = torch.zeros(g.shape[0], C // 64, 2, 32, dtype=torch.float64)
+    for h in (0, 1):
+        st = torch.cat([g[..., 16 * h:16 * h + 16], g[..., 32 + 16 * h:40 + 16 * h]], -1)
+        sc = 2.0 ** (g[..., 40 + 16 * h].double() - 127)
+        for i in range(32):
+            by, sh = (6 * i) // 8, (6 * i) % 8
+            code = ((st[..., by] | (st[..., min(by + 1, 23)] << 8)) >> sh) & 63
+            out[..., h, i] = torch.where((code & 32) != 0, -1.0, 1.0) * _E2M3[code & 31] * sc
+    return out.reshape(*lead, C)
+
+
+def test_to_operand_mx6_is_the_documented_byte_format():
+    """The cast kernel's OMGSR_EL_MX6 row against the host packer (ops._e2m3_blocks: the same integer arithmetic, so BYTES are compared) and
+    against the format's definition (decode: a_hi + a_lo' reproduces a to 2^-4 of the block's largest residual)."""
+    from omgsr_amd import ops
+    x = torch.randn(3, 50, 2, 256, generator=_g(70)) * torch.exp(torch.randn(256, generator=_g(71)))
+    x[0, 0, 0, :32] = 0.0                                      # an all-zero block: scale byte 0, codes 0
+    x[1, 3, 1, 64:96] *= 1e-30                                 # a block below the E8M0 range of interest
+    y = ops.to_operand(x.to(DEV), 4)
+    assert y.dtype == torch.float16 and y.shape[-1] == 2 * 256
+    raw = y.cpu().view(torch.uint8).reshape(3, 50, 2, 4 * 256)
+    hi = x.to(torch.float16)
+    want = torch.cat([hi.contiguous().view(torch.uint8).reshape(3, 50, 2, 512), ops._e2m3_blocks(x - hi.float()), ops._e2m3_blocks(hi.float())], -1)
+    assert torch.equal(raw, want)
+    lo = _mx6_third(raw[..., 512:768])
+    resid = (x - hi.float()).double()
+    bmax = resid.reshape(3, 50, 2, 8, 32).abs().amax(-1, keepdim=True).expand(3, 50, 2, 8, 32).reshape(resid.shape)
+    assert ((lo - resid).abs() <= bmax * (0.25 / 3.75) + 1e-300).all()
+    assert _rel(hi.double() + lo, x) < 3e-5
+
+
+@pytest.mark.parametrize("C,G,HW,twin", [(128, 32, 4096, 0), (320, 32, 1000, 3), (512, 32, 300, 2), (256, 32, 77, 1)])
+def test_group_norm_mx6_operand(C, G, HW, twin):
+    """GroupNorm apply (+ SiLU) writing the fp6 form: the fp16 third is bit-equal to the other forms', the fp6 thirds decode to the residual and to
+    a_hi within the format's step; the shortcut twin (plain / split / MX) is untouched by the first output's form. Ragged pixel counts: the lane
+    quads that share a block stay together in the kernel's tail loop."""
+    from omgsr_amd import ops
+    if C % 64:
+        pytest.skip("whole 64-channel chunks")
+    x = torch.randn(2, HW, 1, C, generator=_g(2)) * 3 + 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=_g(3)), 0.1 * torch.randn(C, generator=_g(4))
+    xd = x.to(DEV)
+    mean, rstd, _ = ops.group_norm_stats(xd, G, 1e-6)
+    out = ops.group_norm_apply(xd, mean, rstd, gamma.to(DEV), beta.to(DEV), G, ops.ACT_SILU, split=4, also_cast=twin)
+    y, y2 = out if twin else (out, None)
+    ref2 = ops.group_norm_apply(xd, mean, rstd, gamma.to(DEV), beta.to(DEV), G, ops.ACT_SILU, split=2, also_cast=twin)
+    s2, t2 = ref2 if twin else (ref2, None)
+    if twin:
+        assert torch.equal(y2, t2)
+    raw = y.cpu().view(torch.uint8).reshape(2, HW, 1, 4 * C)
+    hi = raw[..., :2 * C].contiguous().view(torch.float16)
+    assert torch.equal(hi, s2[..., :C].cpu())
+    lo_ref = s2[..., C:].double().cpu()                         # the two-term split's low half: the residual to 2^-11 of itself
+    lo, hi6 = _mx6_third(raw[..., 2 * C:3 * C]), _mx6_third(raw[..., 3 * C:])
+    nb = C // 32
+    bm = lambda t: t.reshape(2, HW, 1, nb, 32).abs().amax(-1, keepdim=True).expand(2, HW, 1, nb, 32).reshape(t.shape)     # noqa: E731
+    assert ((lo - lo_ref).abs() <= bm(lo_ref) * 0.07).all()
+    assert ((hi6 - hi.double()).abs() <= bm(hi.double()) * 0.07).all()
+    ref = F.silu(F.group_norm(x.permute(0, 3, 1, 2).double(), G, gamma.double(), beta.double(), 1e-6)).permute(0, 2, 3, 1)
+    assert _rel(hi.double() + lo, ref) < 3e-5
+
+
+_MX6_CASES = [(2, 64, 64, 128, 128), (1, 64, 96, 320, 320), (2, 16, 16, 1280, 640), (1, 40, 43, 512, 512), (1, 9, 33, 64, 128), (4, 38, 38, 256, 256), (4, 75, 75, 256, 512),
+              (1, 128, 128, 128, 136)]
+
+
+@pytest.mark.parametrize("N,H,W,C,Cout", _MX6_CASES)
+def test_conv_mx6(N, H, W, C, Cout):
+    """a w = a_hi w_hi (fp16 MFMAs) + a_lo w_hi + a_hi w_lo with the correction terms as fp6 (e2m3) codes and per-32-channel E8M0 scales from the
+    data, in the f8f6f4 MFMA's 8-pass form (igemm_halo_mx6.hip: spatial and FLAT forms, ragged maps). Same 3 mantissa bits as the fp8 form: the
+    corrections are carried to ~2^-4 of their block's largest, i.e. the result to ~1e-5, against ~3e-4 for one fp16 rounding of both sides."""
+    from omgsr_amd import ops
+    x = torch.randn(N, H, W, C, generator=_g(8)) * torch.exp(0.7 * torch.randn(C, generator=_g(12)))      # channel gains: blocks with a dominant channel
+    w = torch.randn(Cout, C, 3, 3, generator=_g(9)) * (9 * C) ** -0.5
+    b = 0.1 * torch.randn(Cout, generator=_g(10))
+    res = torch.randn(N, H, W, Cout, generator=_g(11))
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+    pw = ops.pack_conv_weight(w, b, device=DEV, cout_multiple=8, split=4)
+    assert pw.mx_fmt == 6 and pw.split == 4 and pw.row_channels == 2 * C
+    y = ops.conv2d(x.to(DEV), pw, pad=1, residual=res.to(DEV), gn_groups=8)
+    e = _rel(y[..., :Cout], ref)
+    pw8 = ops.pack_conv_weight(w, b, device=DEV, cout_multiple=8, split=3)
+    e8 = _rel(ops.conv2d(x.to(DEV), pw8, pad=1, residual=res.to(DEV))[..., :Cout], ref)
+    pw1 = ops.pack_conv_weight(w, b, device=DEV, cout_multiple=8)
+    e1 = _rel(ops.conv2d(x.to(DEV), pw1, pad=1, residual=res.to(DEV))[..., :Cout], ref)
+    print(f"conv MX6 {N, H, W, C, Cout}: rel {e:.2e} (fp8 form {e8:.2e}, single fp16 rounding of both sides {e1:.2e})")
+    assert e < 3e-5 and e1 > 8 * e and e < 2.5 * e8
+    mean, _, _ = ops.group_norm_stats(y, 8, 1e-6)                  # statistics left by the halo epilogue
+    assert torch.allclose(mean.double().cpu(), y.double().cpu().reshape(N, H * W, 8, -1).mean(dim=(1, 3)), atol=1e-5, rtol=1e-5)
+    assert torch.equal(ops.conv2d(x.to(DEV), pw, pad=1, residual=res.to(DEV)), y)
+
+
+def test_conv_mx6_multi_launch_split_k_and_refusals():
+    from omgsr_amd import ops
+    C, Cout = 128, 128
+    w = torch.randn(Cout, C, 3, 3, generator=_g(9)) * (9 * C) ** -0.5
+    pw = ops.pack_conv_weight(w, None, device=DEV, split=4)
+    # the tile-shape groups of a tiled-VAE level in one launch (FLAT plan for the whole group), then a spatial group
+    for shapes in ([(3, 40, 40), (1, 40, 32), (1, 32, 40), (1, 32, 32)], [(2, 96, 96), (1, 96, 64), (1, 64, 96)]):
+        xs = [torch.randn(n, h, wd, C, generator=_g(20 + i)) for i, (n, h, wd) in enumerate(shapes)]
+        ys = ops.conv2d_multi([ops.to_operand(x.to(DEV), 4) for x in xs], pw, pad=1)
+        for x, y in zip(xs, ys):
+            ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+            assert _rel(y, ref) < 3e-5
+    # one image per call: the chunk ranges of the contraction as one launch group (halo split-K), fp6 chunks included
+    for (N, H, W, Ci, Co) in [(1, 64, 64, 512, 512), (1, 32, 32, 640, 640), (1, 8, 64, 64, 128)]:
+        x = torch.randn(N, H, W, Ci, generator=_g(41))
+        wk = torch.randn(Co, Ci, 3, 3, generator=_g(42)) * (9 * Ci) ** -0.5
+        r = torch.randn(N, H, W, Co, generator=_g(44))
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wk.double(), padding=1).permute(0, 2, 3, 1) + r.double()
+        y = ops.conv2d(ops.to_operand(x.to(DEV), 4), ops.pack_conv_weight(wk, None, device=DEV, split=4), pad=1, residual=r.to(DEV))
+        assert _rel(y, ref) < 3e-5
+    # no GEMM epilogue writes the form, no 1x1 / phase-form weight is packed in it, and an operand of the other form is refused by shape of the call
+    with pytest.raises(ValueError):
+        ops.conv2d(ops.to_operand(xs[0].to(DEV), 4), pw, pad=1, out_dtype=ops.OUT_BF16, out_split=4)
+    with pytest.raises(ValueError):
+        ops.pack_conv_weight(torch.randn(128, 128, 1, 1), None, device=DEV, split=4)
+    with pytest.raises(ValueError):
+        ops.pack_conv_weight(w, None, device=DEV, split=4, upsample_phases=True)
