@@ -362,7 +362,11 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
                 for (int i = 0; i < FM; ++i) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
-                        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
+                        // s_nop 3: at this register pressure hipcc assembles some 6-register fragments with v_mov copies placed right in front of
+                        // the MFMA that reads them, and it pads no hazards around inline asm - without the wait states the matrix pipe read stale
+                        // registers now and then (found by the bit-repeatability assertions of test_conv_mx6 / the loader test; the FLAT forms
+                        // showed it first). Four cycles in front of an instruction that occupies the pipe for 32: hidden behind its predecessor.
+                        asm volatile("s_nop 3\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
                                      : "+v"(acc[i][j]) : "v"(b6[j]), "v"(a6[i]), "v"(sb6[j]), "v"(sa6[i]));   // transposed tile
                     if constexpr (LATE) {
                         if (i == FM / 2 - 1) {

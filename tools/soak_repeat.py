@@ -8,9 +8,11 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 dev = "cuda"
 g = torch.Generator().manual_seed(7)
 def soak(name, fn, n):
-    ref = fn(); bad = 0
+    # (operand tensors in the MX forms are raw bytes behind a 16-bit dtype - some are NaN patterns: compare bit patterns, not values)
+    bits = lambda t: t.view(torch.int16) if t.dtype in (torch.float16, torch.bfloat16) else t       # noqa: E731
+    ref = bits(fn()); bad = 0
     for _ in range(n):
-        bad += int(not torch.equal(fn(), ref))
+        bad += int(not torch.equal(bits(fn()), ref))
     print(f"{name:48s} {n} repeats, {bad} differ", flush=True)
     return bad
 total = 0
@@ -49,6 +51,15 @@ for N_, C, Co, H_, W_ in [(1, 512, 512, 64, 64), (1, 640, 640, 32, 32), (1, 320,
     pc = ops.pack_conv_weight(torch.randn(Co, C, 3, 3, generator=g) * (9 * C) ** -0.5, torch.zeros(Co), device=dev, split=3)
     rr = torch.randn(N_, H_, W_, Co, generator=g).to(dev)
     total += soak(f"[accurate] MX halo conv, split-K {N_}x{H_}x{W_} {C}->{Co}", lambda: ops.conv2d(xc, pc, pad=1, residual=rr), reps)
+# ... the fp6 correction chunks (OMGSR_EL_MX6): spatial, FLAT (22- and 27-piece patch) and split-K forms, and the quad-cooperative producers
+for N_, C, Co, H_, W_ in [(4, 128, 128, 256, 256), (4, 256, 512, 75, 75), (8, 512, 512, 40, 40), (4, 256, 256, 38, 38), (1, 512, 512, 64, 64), (36, 320, 320, 64, 64)]:
+    xf = (torch.randn(N_, H_, W_, C, generator=g) * 0.5).to(dev)
+    pc = ops.pack_conv_weight(torch.randn(Co, C, 3, 3, generator=g) * (9 * C) ** -0.5, torch.zeros(Co), device=dev, split=4)
+    xc = ops.to_operand(xf, 4)
+    total += soak(f"[accurate] fp6 halo conv {N_}x{H_}x{W_} {C}->{Co}", lambda: ops.conv2d(xc, pc, pad=1), reps)
+    total += soak(f"[accurate] fp6 cast {N_}x{H_}x{W_}x{C}", lambda: ops.to_operand(xf, 4), reps // 4)
+    mean, rstd, _ = ops.group_norm_stats(xf, 32, 1e-6)
+    total += soak(f"[accurate] fp6 GroupNorm apply {N_}x{H_}x{W_}x{C}", lambda: ops.group_norm_apply(xf, mean, rstd, None, None, 32, ops.ACT_SILU, split=4), reps // 4)
 # ... and GroupNorm apply + SiLU as the conv's patch producer (fast tiers: a wave normalises its own LDS-DMA'd pieces in place)
 for tier in (torch.bfloat16, torch.float16):
     ops.set_compute_dtype(tier)
