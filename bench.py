@@ -47,7 +47,9 @@ WORKLOADS = {
 }
 DTYPES = {"fp32": "float32", "fp16": "float16", "bf16": "bfloat16"}
 IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel", 6: "igemm_halo_kernel<TAPS=4>", 7: "igemm_halo_multi_kernel", 8: "igemm_halo_multi_kernel<TAPS=4>", 9: "igemm_gmx_kernel",
-                  10: "igemm_halo_kernel<GN>", 11: "igemm_halo_multi_kernel<GN>", 12: "igemm_halo_multi_kernel(split-K)+splitk_reduce_kernel"}
+                  10: "igemm_halo_kernel<GN>", 11: "igemm_halo_multi_kernel<GN>", 12: "igemm_halo_multi_kernel(split-K)+splitk_reduce_kernel",
+                  13: "igemm_halo_kernel<fp6>", 14: "igemm_halo_multi_kernel<fp6>", 15: "igemm_halo_multi_kernel<fp6>(split-K)+splitk_reduce_kernel"}
+FP6_VARIANTS = (13, 14, 15)       # correction chunks as fp6: 8 MFMA passes per 64 channels where fp8 takes 16 - 3/4 of the fp8 form's matrix-pipe time
 
 
 def parse(argv=None):
@@ -162,7 +164,7 @@ def collect_timing(lib_mod):
         # upsampling convs 4 of their 9 taps. `flops` (omgsr_timing: work_of) is the work HANDED to the kernel: logical channels, 9 taps.
         issued = e.flops
         if e.kind == 1 and e.m > 0 and e.n > 0 and e.k > 0:
-            issued = 2.0 * e.m * e.n * e.k * (4.0 / 9.0 if int(e.variant) in (6, 8) else 1.0)
+            issued = 2.0 * e.m * e.n * e.k * (4.0 / 9.0 if int(e.variant) in (6, 8) else 0.75 if int(e.variant) in FP6_VARIANTS else 1.0)
         k = kinds.setdefault(int(e.kind), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, issued=0.0))
         k["launches"] += 1; k["ms"] += e.ms; k["flops"] += e.flops; k["bytes"] += e.bytes; k["issued"] += issued
         sg = stages.setdefault(int(e.stage), dict(launches=0, ms=0.0, mfma_ms=0.0, mfma_flops=0.0))
@@ -405,8 +407,11 @@ def attach_traffic(roofline, per_kernel, fam, krows):
         expect["igemm_dma_kernel"] = expect.get("igemm_dma_kernel", 0) + sk
     if hsk:
         expect["igemm_halo_multi_kernel"] = expect.get("igemm_halo_multi_kernel", 0) + hsk
-    if sk or hsk:
-        expect["splitk_reduce_kernel"] = sk + hsk
+    hsk6 = mine.get("igemm_halo_multi_kernel<fp6>(split-K)+splitk_reduce_kernel", 0)
+    if hsk6:
+        expect["igemm_halo_multi_kernel<fp6>"] = expect.get("igemm_halo_multi_kernel<fp6>", 0) + hsk6
+    if sk or hsk or hsk6:
+        expect["splitk_reduce_kernel"] = sk + hsk + hsk6
     ok_all, total_meas, total_n = True, 0.0, 0
     for name, n in expect.items():
         row = krows.get(name)
@@ -422,7 +427,7 @@ def attach_traffic(roofline, per_kernel, fam, krows):
         if tgt is not None:
             tgt["traffic_bytes_per_launch"] = round(row["hbm_bytes_per_launch"]) if ok else None
             tgt["traffic_launches_seen"] = seen
-            if ok and tgt["bytes_per_launch"] > 0 and "(split-K)" not in name and not (name == "igemm_dma_kernel" and sk) and not (name == "igemm_halo_multi_kernel" and hsk):
+            if ok and tgt["bytes_per_launch"] > 0 and "(split-K)" not in name and not (name == "igemm_dma_kernel" and sk) and not (name == "igemm_halo_multi_kernel" and hsk) and not (name == "igemm_halo_multi_kernel<fp6>" and hsk6):
                 tgt["traffic_over_algorithmic"] = round(row["hbm_bytes_per_launch"] / tgt["bytes_per_launch"], 3)
     n_igemm = sum(n for k, n in expect.items() if k.startswith(("igemm", "splitk")))
     if ok_all and total_n == n_igemm and roofline["launches"] > 0:

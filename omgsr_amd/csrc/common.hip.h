@@ -187,8 +187,9 @@ OMGSR_DEVINL void e2m3_pack8(const float (&v)[8], const float inv_scale, unsigne
     w1 = (c[5] >> 2) | (c[6] << 4) | (c[7] << 10);
 }
 // 8 channels c .. c + 7 of a row. COOPERATIVE: lanes 4k .. 4k + 3 of the wave must hold the four octets (c & 31) = 0, 8, 16, 24 of ONE block of ONE
-// row, all of them active (the thread-per-octet kernels - cast, GroupNorm apply - map consecutive lanes to consecutive octets and C % 64 == 0).
-template <typename T> OMGSR_DEVINL void store8_mx6(void* base, const int64_t row_byte0, const int C, const int c, const float (&f)[8]) {
+// row and all of them must CALL this (the thread-per-octet kernels - cast, GroupNorm apply, split-K reduce - and the GEMM epilogues map
+// consecutive lanes to consecutive octets and C % 64 == 0). `store` false (a row outside the image, the same for the whole quad): nothing is written.
+template <typename T> OMGSR_DEVINL void store8_mx6(void* base, const int64_t row_byte0, const int C, const int c, const float (&f)[8], const bool store = true) {
     unsigned char* row = reinterpret_cast<unsigned char*>(base) + row_byte0;
     u32x4_t hi;
     float ah[8], al[8], mh = 0.0f, ml = 0.0f;
@@ -201,7 +202,7 @@ template <typename T> OMGSR_DEVINL void store8_mx6(void* base, const int64_t row
         mh = fmaxf(mh, fmaxf(fabsf(ah[2 * q]), fabsf(ah[2 * q + 1])));
         ml = fmaxf(ml, fmaxf(fabsf(al[2 * q]), fabsf(al[2 * q + 1])));
     }
-    *reinterpret_cast<u32x4_t*>(row + 2 * c) = hi;
+    if (store) *reinterpret_cast<u32x4_t*>(row + 2 * c) = hi;
     const unsigned sl = mx6_scale_byte(quad_max(ml)), sh = mx6_scale_byte(quad_max(mh));
     const int oct = (c >> 3) & 3;
     unsigned char* grp = row + 2 * C + (c >> 6) * 64 + ((c >> 5) & 1) * 16;        // the block's first 16 bytes in the a_lo' third; + C: a_hi'
@@ -213,6 +214,7 @@ template <typename T> OMGSR_DEVINL void store8_mx6(void* base, const int64_t row
         const unsigned o0 = quad_perm<0xB1>(w0), o1 = quad_perm<0xB1>(w1);       // the odd octet's bits reach its even partner
         const unsigned d0 = w0, d1 = w1 | (o0 << 16), d2 = (o0 >> 16) | (o1 << 16);
         unsigned char* g = grp + seg * C;
+        if (!store) continue;
         if (oct == 0) {
             *reinterpret_cast<u32x2_t*>(g) = u32x2_t{d0, d1};
             *reinterpret_cast<unsigned*>(g + 8) = d2;

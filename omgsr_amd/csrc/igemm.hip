@@ -263,9 +263,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
                 v[e] = x;
                 amax = fmaxf(amax, fabsf(x));
             }
-            store8_mx<T>(p.out, (int64_t)m * 4 * p.Cout, p.Cout, n, v);
+            if (p.out_mx == 6) store8_mx6<T>(p.out, (int64_t)m * 4 * p.Cout, p.Cout, n, v);        // (thread per octet, whole rows: lane quads = blocks)
+            else store8_mx<T>(p.out, (int64_t)m * 4 * p.Cout, p.Cout, n, v);
             if (p.overflow_flag && amax > 65504.0f) atomicOr(p.overflow_flag, 1u);
-            if (p.overflow_flag && amax > 448.0f) atomicOr(p.overflow_flag, 2u);
+            if (p.overflow_flag && p.out_mx == 1 && amax > 448.0f) atomicOr(p.overflow_flag, 2u);
             return;
         }
     }
@@ -529,7 +530,8 @@ int validate_args(omgsr_igemm_args& a) {
     // an MX operand is understood by the halo-tile kernel (3x3 convs, mx_geometry_ok) and by the MX GEMM kernel (1x1: igemm_gmx.hip)
     if (a.mx_chunks16 < 0 || (a.mx_chunks16 > 0 && !mx_geometry_ok(a) && !omgsr::igemm_gmx_ok(a))) return OMGSR_E_SHAPE;
     // ... the fp6 form (OMGSR_EL_MX6) by the halo-tile kernel's nine-tap forms only
-    if (a.mx_chunks16 > 0 && a.mx_fmt != 0 && a.mx_fmt != 8 && (a.mx_fmt != 6 || a.upsample || !mx_geometry_ok(a))) return OMGSR_E_SHAPE;
+    if (a.mx_chunks16 > 0 && a.mx_fmt != 0 && a.mx_fmt != 8 && (a.mx_fmt != 6 || !mx_geometry_ok(a))) return OMGSR_E_SHAPE;
+    if (a.out_mx != 0 && a.out_mx != 1 && a.out_mx != 6) return OMGSR_E_BADARG;
     if (a.out_mx && (a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cout & 63) || a.out_lo_off || a.out_ld || a.gn_partial ||
                      omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
     if (a.gn_scale_shift && (a.gn_nimg <= 0 || a.gn_act != OMGSR_ACT_SILU || !gn_fusable(a))) return OMGSR_E_SHAPE;      // (SiLU is the one activation the producer applies)
@@ -603,6 +605,7 @@ extern "C" int omgsr_igemm_multi(const omgsr_igemm_args* args, int32_t count, vo
             omgsr::TimingScope ts(OMGSR_TK_IGEMM, gf, gb, st, gm, logical_cols, (long long)grp[0].R * grp[0].S * grp[0].Cin);
             ts.rec.variant = ng == 1 ? (mode == 1 ? 6 : 3) : (mode == 1 ? 8 : 7);      // 7 / 8: igemm_halo_multi_kernel (gather / phase form)
             if (grp[0].gn_scale_shift) ts.rec.variant = ng == 1 ? 10 : 11;              // 10 / 11: the GroupNorm-fused instantiations
+            if (grp[0].mx_chunks16 > 0 && grp[0].mx_fmt == 6) ts.rec.variant = ng == 1 ? 13 : 14;      // 13 / 14 (/ 15: split-K): fp6 correction chunks
             rc = ng == 1 ? omgsr::igemm_halo_launch(grp[0], geo[0], st, mode == 1) : omgsr::igemm_halo_launch_multi(grp, geo, ng, st, mode == 1);
         }
         ng = 0; gf = gb = 0.0; gm = 0;
@@ -673,7 +676,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
             if (a.gn_partial) return OMGSR_E_BADARG;        // the reduce pass does not emit GroupNorm statistics (omgsr_igemm_gn_slots says so)
             int rc;
             if (use_halo(a)) {                       // chunk ranges of the halo-tile kernel as one launch group
-                ts.rec.variant = 12;
+                ts.rec.variant = a.mx_fmt == 6 ? 15 : 12;
                 rc = omgsr::igemm_halo_launch_splitk(a, g, splits, st);
             } else {
                 g.splits = splits;
@@ -702,7 +705,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
     }
     // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
     if (use_halo_phase(a)) { ts.rec.variant = 6; return omgsr::igemm_halo_launch(a, g, st, true); }
-    if (use_halo(a)) { ts.rec.variant = a.gn_scale_shift ? 10 : 3; return omgsr::igemm_halo_launch(a, g, st); }
+    if (use_halo(a)) { ts.rec.variant = a.gn_scale_shift ? 10 : (a.mx_chunks16 > 0 && a.mx_fmt == 6) ? 13 : 3; return omgsr::igemm_halo_launch(a, g, st); }
     if (a.gn_scale_shift) return OMGSR_E_SHAPE;                  // (validate_args already refused it: never reached)
     {
         static const char* dbg = getenv("OMGSR_DEBUG_DISPATCH");      // one line per conv-shaped problem that did NOT take the halo kernel

@@ -16,9 +16,12 @@ import collections, csv, json, re, sys
 # (bench name, regex over the rocprofv3 Kernel_Name) - first match wins; mangled names: igemm_halo_multi_kernelI<T>Lb<NARROW>ELi<TAPS>ELb<MX>E,
 # igemm_halo_kernelI<T>Li<ABL>ELb<PRIO>ELb<NARROW>ELi<TAPS>ELb<MX>E
 KERNELS = [
-    # round 5: ... ELi<FLAT>ELi<GNF>ELb<SPLITK>E follow; GNF = 1 are the GroupNorm-fused instantiations (bench: `<GN>`)
-    ("igemm_halo_multi_kernel<GN>", re.compile(r"igemm_halo_multi_kernelI\w+?_?Lb[01]ELi9ELb0ELi0ELi1E")),
-    ("igemm_halo_kernel<GN>", re.compile(r"igemm_halo_kernelI\w+?_?Li\dELb[01]ELb[01]ELi9ELb0ELi0ELi1E")),
+    # round 5: ... ELi<FLAT>ELi<GNF>ELb<SPLITK>E follow; GNF = 1 are the GroupNorm-fused instantiations (bench: `<GN>`); MX is an int since the
+    # fp6 form (L[bi]: older traces carry the bool mangling): MX = 6 are the fp6 instantiations (bench: `<fp6>`)
+    ("igemm_halo_multi_kernel<GN>", re.compile(r"igemm_halo_multi_kernelI\w+?_?Lb[01]ELi9EL[bi]0ELi0ELi1E")),
+    ("igemm_halo_kernel<GN>", re.compile(r"igemm_halo_kernelI\w+?_?Li\dELb[01]ELb[01]ELi9EL[bi]0ELi0ELi1E")),
+    ("igemm_halo_multi_kernel<fp6>", re.compile(r"igemm_halo_multi_kernelI\w+?_?Lb[01]ELi9ELi6E")),
+    ("igemm_halo_kernel<fp6>", re.compile(r"igemm_halo_kernelI\w+?_?Li\dELb[01]ELb[01]ELi9ELi6E")),
     ("igemm_halo_multi_kernel<TAPS=4>", re.compile(r"igemm_halo_multi_kernelI\w+?_?Lb[01]ELi4E|igemm_halo_multi_kernel<[^>]*, 4,")),
     ("igemm_halo_multi_kernel", re.compile(r"igemm_halo_multi_kernel")),
     ("igemm_halo_kernel<TAPS=4>", re.compile(r"igemm_halo_kernelI\w+?_?Li\dELb[01]ELb[01]ELi4E|igemm_halo_kernel<[^>]*, 4,")),
