@@ -57,7 +57,7 @@ extern "C" {
  * kernel for 3x3 convs, igemm_gmx_kernel for GEMM-shaped problems) multiplies the first half by fp16 weights in fp16 MFMAs and the fp8 parts by fp8 copies of w_hi / w_lo in block-scaled MFMAs
  * (v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 rate), all into one fp32 accumulator. */
 #define OMGSR_EL_MX 3
-/* OMGSR_EL_MX6 (round 5; outputs of the GroupNorm apply / cast kernels and of omgsr_igemm with out_mx = 6): the same 4C-byte row [a_hi fp16 | a_lo' | a_hi'] whose two
+/* OMGSR_EL_MX6 (round 5; outputs of the GroupNorm apply / cast kernels only): the same 4C-byte row [a_hi fp16 | a_lo' | a_hi'] whose two
  * correction thirds hold fp6 (OCP e2m3) codes with one E8M0 scale per 32-channel block: every 64-byte group of a third covers 64 channels =
  * two blocks; block h (0, 1) owns bytes [16h, 16h + 16) (codes 0 .. 20 and the low 2 bits of 21: channel i at bits [6i, 6i + 6) of the block's
  * little-endian 192-bit string), bytes [32 + 16h, 40 + 16h) (the rest of the string), byte 40 + 16h (the block's scale: a = code 2^(scale - 127))
@@ -169,8 +169,7 @@ typedef struct omgsr_igemm_args {
     int32_t in_el;         /* element kind of `in` when gn_scale_shift is set: OMGSR_EL_16 | OMGSR_EL_F32 */
     int32_t mx_fmt;        /* mx_chunks16 > 0: format of the correction chunks - 0 (or 8): OMGSR_EL_MX (fp8 e4m3, per-tensor scales mx_scale_*);
                               6: OMGSR_EL_MX6 (fp6 e2m3 with one E8M0 scale byte per 32-channel block, in the data; 3x3 convs of the halo-tile
-                              kernel only, nine-tap and phase forms). Operand and weight carry the same format. out_mx = 6 writes the OUTPUT
-                              in that form (any kernel's epilogue and the split-K reduce pass; same conditions as out_mx = 1). */
+                              kernel's nine-tap forms only). Operand and weight carry the same format. */
 } omgsr_igemm_args;
 /* 1 when omgsr_igemm / omgsr_igemm_multi would run these arguments with the GroupNorm apply fused into the conv's patch producer (the
  * fields above may still be unset: the answer depends on geometry, operand / weight form, compute type and `in_el` only; for a problem of a

@@ -263,10 +263,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
                 v[e] = x;
                 amax = fmaxf(amax, fabsf(x));
             }
-            if (p.out_mx == 6) store8_mx6<T>(p.out, (int64_t)m * 4 * p.Cout, p.Cout, n, v);        // (thread per octet, whole rows: lane quads = blocks)
-            else store8_mx<T>(p.out, (int64_t)m * 4 * p.Cout, p.Cout, n, v);
+            store8_mx<T>(p.out, (int64_t)m * 4 * p.Cout, p.Cout, n, v);
             if (p.overflow_flag && amax > 65504.0f) atomicOr(p.overflow_flag, 1u);
-            if (p.overflow_flag && p.out_mx == 1 && amax > 448.0f) atomicOr(p.overflow_flag, 2u);
+            if (p.overflow_flag && amax > 448.0f) atomicOr(p.overflow_flag, 2u);
             return;
         }
     }
@@ -530,8 +529,8 @@ int validate_args(omgsr_igemm_args& a) {
     // an MX operand is understood by the halo-tile kernel (3x3 convs, mx_geometry_ok) and by the MX GEMM kernel (1x1: igemm_gmx.hip)
     if (a.mx_chunks16 < 0 || (a.mx_chunks16 > 0 && !mx_geometry_ok(a) && !omgsr::igemm_gmx_ok(a))) return OMGSR_E_SHAPE;
     // ... the fp6 form (OMGSR_EL_MX6) by the halo-tile kernel's nine-tap forms only
-    if (a.mx_chunks16 > 0 && a.mx_fmt != 0 && a.mx_fmt != 8 && (a.mx_fmt != 6 || !mx_geometry_ok(a))) return OMGSR_E_SHAPE;
-    if (a.out_mx != 0 && a.out_mx != 1 && a.out_mx != 6) return OMGSR_E_BADARG;
+    if (a.mx_chunks16 > 0 && a.mx_fmt != 0 && a.mx_fmt != 8 && (a.mx_fmt != 6 || a.upsample || !mx_geometry_ok(a))) return OMGSR_E_SHAPE;
+    if (a.out_mx != 0 && a.out_mx != 1) return OMGSR_E_BADARG;         // (the fp6 form is written by the cast / GroupNorm apply kernels only: the fused epilogues have no registers to spare for it)
     if (a.out_mx && (a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cout & 63) || a.out_lo_off || a.out_ld || a.gn_partial ||
                      omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
     if (a.gn_scale_shift && (a.gn_nimg <= 0 || a.gn_act != OMGSR_ACT_SILU || !gn_fusable(a))) return OMGSR_E_SHAPE;      // (SiLU is the one activation the producer applies)

@@ -61,7 +61,7 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
             // MX output: the fp8 correction fields use fixed scales and clamp at +-448 (store8_mx), so an element beyond that keeps only its
             // fp16 main term (single-rounding accuracy, nothing becomes NaN). Bit 1 of the same word counts as a DIAGNOSTIC, not an error:
             // ops.mx_saturation_seen() (real SD2.1 feed-forward / attention activations reach the hundreds; seeded weights never do)
-            if (p.overflow_flag && p.out_mx == 1 && __any(amax > 448.0f) && lane == 0) atomicOr(p.overflow_flag, 2u);       // (the fp6 form scales per block: nothing saturates)
+            if (p.overflow_flag && p.out_mx && __any(amax > 448.0f) && lane == 0) atomicOr(p.overflow_flag, 2u);
         }
     };
     const bool vec_ok = (p.Cout & 7) == 0 && (ldo & 7) == 0;
@@ -234,11 +234,6 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
                     }
                     bool sok;
                     const int spix = opix(i, row, sok);
-                    if (p.out_mx == 6) {     // OMGSR_EL_MX6: cooperative over lane quads (consecutive lanes = consecutive octets of one output row; a
-                                             // quad shares sok and col_ok: Cout % 64 == 0), so every lane calls it and only the store is predicated
-                        if (sok && col_ok) note8(v);
-                        store8_mx6<T>(outb, (int64_t)spix * 4 * p.Cout, p.Cout, n_out, v, sok && col_ok);
-                    } else
                     if (sok && col_ok) {
                         const int64_t o = (int64_t)spix * ldo + n_out;
                         if (gn_on) {

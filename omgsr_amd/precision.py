@@ -223,11 +223,12 @@ def set_mx(model: nn.Module, patterns: Iterable[str]) -> int:
             conv1 = m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0)          # GEMM-shaped: igemm_gmx_kernel (round 4)
             if (conv3 or conv1) and m.in_channels % 64 == 0 and m.out_channels >= 96 \
                     and m.out_channels % 8 == 0 and m.op_split == 2 and m.w_split == 2:
-                # fp6 correction segments (OMGSR_EL_MX6, op_split 4; round 5): every 3x3 conv of the halo-tile kernel (ResnetBlock2D conv1 /
-                # conv2: operand from a GroupNorm apply; the up-samplers' conv: operand from the previous layer's epilogue). Half the matrix-pipe
-                # passes of fp8 on the correction chunks (1.5x instead of 2x per layer), the same 3 mantissa bits with a scale per 32-channel
-                # block. The GEMM-shaped MX kernels (1x1 shortcuts, token linears) stay fp8. OMGSR_MX=8 keeps every layer at fp8 (A/B runs).
-                fp6 = conv3 and mx_env != "8"
+                # fp6 correction segments (OMGSR_EL_MX6, op_split 4; round 5): the 3x3 convs whose operand a GroupNorm apply writes - a
+                # ResnetBlock2D's conv1 / conv2. (The up-samplers' 3x3 conv takes its operand from the previous layer's GEMM epilogue, and the
+                # fused epilogues have no registers to spare for the cooperative fp6 store: built, measured - it spilled every MX kernel - and
+                # removed, profiles/r05_experiments.md.) Half the matrix-pipe passes of fp8 on the correction chunks (1.5x instead of 2x per
+                # layer), the same 3 mantissa bits with a scale per 32-channel block. OMGSR_MX=8 keeps every layer at fp8 (A/B runs).
+                fp6 = conv3 and mx_env != "8" and not getattr(m, "phase_upsample", False) and name.rsplit(".", 1)[-1] in ("conv1", "conv2")
                 m.op_split = 4 if fp6 else 3
                 n += 1
     return n

@@ -950,45 +950,10 @@ def test_conv_mx6_multi_launch_split_k_and_refusals():
         ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wk.double(), padding=1).permute(0, 2, 3, 1) + r.double()
         y = ops.conv2d(ops.to_operand(x.to(DEV), 4), ops.pack_conv_weight(wk, None, device=DEV, split=4), pad=1, residual=r.to(DEV))
         assert _rel(y, ref) < 3e-5
-    # no 1x1 weight is packed in the form (the GEMM-shaped MX kernels read fp8 corrections)
+    # no GEMM epilogue writes the form, no 1x1 / phase-form weight is packed in it
+    with pytest.raises(ValueError):
+        ops.conv2d(ops.to_operand(xs[0].to(DEV), 4), pw, pad=1, out_dtype=ops.OUT_BF16, out_split=4)
     with pytest.raises(ValueError):
         ops.pack_conv_weight(torch.randn(128, 128, 1, 1), None, device=DEV, split=4)
-
-
-def test_conv_mx6_upsample_phase_form_and_epilogue_outputs():
-    """The producer / consumer pair of an up-sampler in the fp6 form: GEMM epilogues (every kernel family: register-staged, LDS-DMA, ping-pong,
-    halo-tile) and the split-K reduce pass write the OMGSR_EL_MX6 operand (out_split 4) byte for byte as the cast kernel does, and the
-    phase-decomposed up-sampling conv consumes it (fp16 chunks + fp6 chunks of the phase-summed kernels)."""
-    from omgsr_amd import ops
-    C = 256
-    x = torch.randn(2, 43, 86, C, generator=_g(31))
-    w = torch.randn(C, C, 3, 3, generator=_g(32)) * (9 * C) ** -0.5
-    b = 0.1 * torch.randn(C, generator=_g(33))
-    ref = F.conv2d(F.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
-    pw = ops.pack_conv_weight(w, b, device=DEV, split=4, upsample_phases=True)
-    assert pw.w_ph is not None and pw.mx_fmt == 6
-    y = ops.conv2d(x.to(DEV), pw, pad=1, upsample=True, gn_groups=32)
-    assert _rel(y, ref) < 3e-5
-    bits = lambda t: t.contiguous().view(torch.int16)              # noqa: E731  (raw bytes behind a 16-bit dtype: compare patterns, not values)
-    eye = ops.pack_linear_weight(torch.eye(C), None, device=DEV)
-    for rows in (300, 2 * 43 * 86, 40 * 43 * 86):                  # register-staged / LDS-DMA / 256-row tiles
-        xr = (torch.randn(rows, C, generator=_g(34)) * 3).to(torch.float16).float().to(DEV)
-        via_epilogue = ops.linear(xr.reshape(1, rows, C), eye, out_dtype=ops.OUT_BF16, out_split=4).reshape(rows, 2 * C)
-        assert torch.equal(bits(via_epilogue), bits(ops.to_operand(xr, 4)))
-    # the halo-tile kernel's epilogue (a ResnetBlock's conv2 feeding the up-sampler): 3x3 conv with an identity centre tap
-    wi = torch.zeros(C, C, 3, 3); wi[:, :, 1, 1] = torch.eye(C)
-    xh = (torch.randn(2, 40, 64, C, generator=_g(35)) * 3).to(torch.float16).float().to(DEV)
-    via_halo = ops.conv2d(ops.to_operand(xh, 4), ops.pack_conv_weight(wi, None, device=DEV, split=4), pad=1, out_dtype=ops.OUT_BF16, out_split=4)
-    assert torch.equal(bits(via_halo), bits(ops.to_operand(xh, 4)))
-    # ... and the split-K reduce pass (few rows, long contraction)
-    K = 5120
-    xs = torch.randn(1, 256, K, generator=_g(36))
-    ws = torch.randn(1280, K, generator=_g(37)) * K ** -0.5
-    pws = ops.pack_linear_weight(ws, None, device=DEV, split=2, w_split=2)
-    full = ops.linear(ops.to_operand(xs.to(DEV), 2), pws)                                  # fp32 stream output of the same launch plan
-    got = ops.linear(ops.to_operand(xs.to(DEV), 2), pws, out_dtype=ops.OUT_BF16, out_split=4)
-    assert torch.equal(bits(got), bits(ops.to_operand(full, 4)))
-    xm = ops.linear(x.to(torch.float16).float().to(DEV).reshape(1, -1, C), eye, out_dtype=ops.OUT_BF16, out_split=4).reshape(2, 43, 86, 2 * C)
-    y2 = ops.conv2d(xm, pw, pad=1, upsample=True)
-    ref2 = F.conv2d(F.interpolate(x.to(torch.float16).permute(0, 3, 1, 2).double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
-    assert _rel(y2, ref2) < 3e-5
+    with pytest.raises(ValueError):
+        ops.pack_conv_weight(w, None, device=DEV, split=4, upsample_phases=True)
