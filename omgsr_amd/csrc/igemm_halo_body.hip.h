@@ -337,7 +337,8 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
                 // block (e2m3 codes: 6 registers), byte 24 is the block's E8M0 scale. The 8-pass fp6 form of the instruction (cbsz / blgp = 2) takes
                 // the six registers and, per lane, the scale bytes of both fragments. A template value, not a run-time branch: both forms in one
                 // kernel cost 100+ spilled registers (the allocator loses track of the tied accumulators); 24 data bytes + 1 scale byte per read
-                // instead of the whole 32: two registers less per fragment (24 spilled registers with 8-register fragments).
+                // instead of the whole 32: two registers less per fragment (24 spilled registers with 8-register fragments; ds_read_b128 +
+                // ds_read_b96 - scale in the third dword, one LDS instruction less - spills 15: measured at build time, not shipped).
                 typedef int i32x2_t __attribute__((ext_vector_type(2)));
                 typedef int i32x6_t __attribute__((ext_vector_type(6)));
                 i32x6_t a6[FM], b6[FN];
