@@ -123,6 +123,58 @@ def test_split_weight_packings(accurate_tier):
     assert pgl.geglu and pgl.cout == 128 and pgl.mx is not None and pgl.cin == 128
 
 
+_E2M3_GRID = [0, .125, .25, .375, .5, .625, .75, .875, 1, 1.125, 1.25, 1.375, 1.5, 1.625, 1.75, 1.875, 2, 2.25, 2.5, 2.75, 3, 3.25, 3.5, 3.75, 4, 4.5, 5, 5.5, 6, 6.5, 7, 7.5]
+
+
+def _decode_mx6_third(raw):
+    """One correction third of an OMGSR_EL_MX6 row, straight from the format's definition (include/omgsr_hip.h)."""
+    grid = torch.tensor(_E2M3_GRID, dtype=torch.float64)
+    lead, C = raw.shape[:-1], raw.shape[-1]
+    g = raw.reshape(-1, C // 64, 64).to(torch.int64)
+    out = torch.zeros(g.shape[0], C // 64, 2, 32, dtype=torch.float64)
+    for h in (0, 1):
+        st = torch.cat([g[..., 16 * h:16 * h + 16], g[..., 32 + 16 * h:40 + 16 * h]], -1)
+        sc = 2.0 ** (g[..., 40 + 16 * h].double() - 127)
+        for i in range(32):
+            by, sh = (6 * i) // 8, (6 * i) % 8
+            code = ((st[..., by] | (st[..., min(by + 1, 23)] << 8)) >> sh) & 63
+            out[..., h, i] = torch.where((code & 32) != 0, -1.0, 1.0) * grid[code & 31] * sc
+    return out.reshape(*lead, C)
+
+
+def test_fp6_weight_packing(accurate_tier):
+    """split 4 (OMGSR_EL_MX6): [w_hi fp16 | e2m3 blocks of w_hi | e2m3 blocks of w - w_hi] per tap; every 32-channel block carries its own E8M0
+    scale, codes round to nearest (ties to even) and saturate at 7.5, padding bytes are zero; 3x3 stride-1 nine-tap convs only."""
+    ops = accurate_tier
+    g = torch.Generator().manual_seed(5)
+    C, Cout = 128, 16
+    w = torch.randn(Cout, C, 3, 3, generator=g) * 0.05 * torch.exp(torch.randn(C, 1, 1, generator=g))
+    pw = ops.pack_conv_weight(w, None, device="cpu", split=4)
+    assert pw.split == 4 and pw.mx_fmt == 6 and pw.mx[0] == C // 32 and pw.cin == 2 * C and pw.row_channels == 2 * C and pw.w_ph is None
+    assert pw.w_cm is not None and tuple(pw.w_cm.shape) == (2 * C // 32, 9, pw.cout_pad, 32)
+    by = pw.w[:Cout].view(torch.uint8).reshape(Cout, 9, 4 * C)
+    ref = w.permute(0, 2, 3, 1).reshape(Cout, 9, C)
+    hi = by[..., :2 * C].contiguous().view(torch.float16).float()
+    assert torch.equal(hi, ref.to(torch.float16).float())
+    hi6, lo6 = _decode_mx6_third(by[..., 2 * C:3 * C]), _decode_mx6_third(by[..., 3 * C:])
+    bmax = lambda t: t.reshape(Cout, 9, C // 32, 32).abs().amax(-1, keepdim=True).expand(Cout, 9, C // 32, 32).reshape(Cout, 9, C)      # noqa: E731
+    lo = (ref - hi).double()
+    assert ((hi6 - hi.double()).abs() <= bmax(hi.double()) * (0.25 / 3.75)).all() and ((lo6 - lo).abs() <= bmax(lo) * (0.25 / 3.75)).all()
+    assert ((hi.double() + lo6) - ref.double()).abs().max() < 2.0 ** -14 * ref.abs().max()
+    raw = by[..., 2 * C:].reshape(Cout, 9, 2 * C // 64, 64)
+    assert not raw[..., 41:48].any() and not raw[..., 57:64].any()                 # the 7 + 7 padding bytes of a 64-byte group
+    # exact grid points survive, ties go to even codes, anything beyond 7.5 x the block scale saturates
+    v = torch.zeros(1, 64)
+    v[0, :8] = torch.tensor([4.0, 4.25, 4.75, 7.5, 7.9, -0.0625, 0.1875, -3.0])    # block max 7.9 -> scale 2^0 (top binade [4, 8))
+    d = _decode_mx6_third(ops._e2m3_blocks(v))[0, :8]
+    assert d.tolist() == [4.0, 4.0, 5.0, 7.5, 7.5, -0.0, 0.25, -3.0]
+    assert ops._e2m3_blocks(torch.zeros(2, 64)).sum() == 0                          # an all-zero block: scale byte 0, codes 0
+    with pytest.raises(ValueError, match="3x3"):
+        ops.pack_conv_weight(torch.randn(16, 64, 1, 1), None, device="cpu", split=4)
+    with pytest.raises(ValueError, match="nine-tap"):
+        ops.pack_conv_weight(w, None, device="cpu", split=4, upsample_phases=True)
+
+
 def test_phase_summed_kernels_equal_the_upsampled_conv():
     """conv3x3(nearest_up2(x)) at output pixel (2y + a, 2x + b) == the 2 x 2 convolution of x with the phase-(a, b) summed taps."""
     from omgsr_amd.ops import _phase_kernels
