@@ -57,7 +57,7 @@ extern "C" {
  * kernel for 3x3 convs, igemm_gmx_kernel for GEMM-shaped problems) multiplies the first half by fp16 weights in fp16 MFMAs and the fp8 parts by fp8 copies of w_hi / w_lo in block-scaled MFMAs
  * (v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 rate), all into one fp32 accumulator. */
 #define OMGSR_EL_MX 3
-/* OMGSR_EL_MX6 (round 5; outputs of the GroupNorm apply / cast kernels only): the same 4C-byte row [a_hi fp16 | a_lo' | a_hi'] whose two
+/* OMGSR_EL_MX6 (round 5; outputs of the GroupNorm apply / cast kernels and of omgsr_igemm with out_mx = 6 where omgsr_igemm_out_mx6_ok() allows): the same 4C-byte row [a_hi fp16 | a_lo' | a_hi'] whose two
  * correction thirds hold fp6 (OCP e2m3) codes with one E8M0 scale per 32-channel block: every 64-byte group of a third covers 64 channels =
  * two blocks; block h (0, 1) owns bytes [16h, 16h + 16) (codes 0 .. 20 and the low 2 bits of 21: channel i at bits [6i, 6i + 6) of the block's
  * little-endian 192-bit string), bytes [32 + 16h, 40 + 16h) (the rest of the string), byte 40 + 16h (the block's scale: a = code 2^(scale - 127))
@@ -146,7 +146,7 @@ typedef struct omgsr_igemm_args {
                               always takes the halo-tile kernel; and 1x1 stride 1 (every Linear: `weight` rows are [w_hi fp16 | w_hi' fp8 | w_lo' fp8],
                               K_pad = Cin), which takes igemm_gmx_kernel (ABI v14). Cin = 2 x logical channels (16-bit slots), in_ld = 0. */
     int32_t mx_scale_w1, mx_scale_a1, mx_scale_w2, mx_scale_a2;   /* E8M0 exponents (127 = 2^0): the instruction multiplies each product by 2^(w - 127) 2^(a - 127) */
-    int32_t out_mx;        /* 1: the 16-bit output is written in the OMGSR_EL_MX form (4 Cout bytes per pixel; out_dtype OMGSR_OUT_BF16, NHWC,
+    int32_t out_mx;        /* 6: ... in the OMGSR_EL_MX6 form (same conditions; only where omgsr_igemm_out_mx6_ok()); 1: the 16-bit output is written in the OMGSR_EL_MX form (4 Cout bytes per pixel; out_dtype OMGSR_OUT_BF16, NHWC,
                               Cout % 64 == 0, fp16 compute type, no GroupNorm statistics): the operand of a following mixed-precision conv */
     int32_t group_tiles;   /* written by omgsr_igemm_multi_plan: halo-kernel tiles of the whole launch group this problem belongs to (0 = alone);
                               kernel choice and the GroupNorm-statistics layout use max(own tiles, group_tiles) */
@@ -169,12 +169,17 @@ typedef struct omgsr_igemm_args {
     int32_t in_el;         /* element kind of `in` when gn_scale_shift is set: OMGSR_EL_16 | OMGSR_EL_F32 */
     int32_t mx_fmt;        /* mx_chunks16 > 0: format of the correction chunks - 0 (or 8): OMGSR_EL_MX (fp8 e4m3, per-tensor scales mx_scale_*);
                               6: OMGSR_EL_MX6 (fp6 e2m3 with one E8M0 scale byte per 32-channel block, in the data; 3x3 convs of the halo-tile
-                              kernel's nine-tap forms only). Operand and weight carry the same format. */
+                              kernel only, nine-tap and phase forms). Operand and weight carry the same format. */
 } omgsr_igemm_args;
 /* 1 when omgsr_igemm / omgsr_igemm_multi would run these arguments with the GroupNorm apply fused into the conv's patch producer (the
  * fields above may still be unset: the answer depends on geometry, operand / weight form, compute type and `in_el` only; for a problem of a
  * launch group call omgsr_igemm_multi_plan first). 0: run omgsr_groupnorm_apply and hand the conv its operand as before. */
 int32_t omgsr_igemm_gn_fusable(const omgsr_igemm_args* a);
+/* 1 when this problem may write its output as the fp6 operand form (out_mx = 6; the field may still be unset): a 3x3 stride-1 conv that the
+ * halo-tile kernel runs in its spatial nine-tap form with a plain / two-term-split fp16 or an OMGSR_EL_MX6 operand, Cout % 64 == 0, no fused
+ * statistics (dedicated instantiations: the cooperative fp6 store does not fit next to the other output forms of the shared epilogue). Otherwise
+ * the host lets the problem write a stream tensor and runs omgsr_to_operand(y_el = OMGSR_EL_MX6) behind it. */
+int32_t omgsr_igemm_out_mx6_ok(const omgsr_igemm_args* a);
 /* (scale, shift) table of a GroupNorm for the fused form: out[n][c] = (rstd[n][g] gamma[c], beta[c] - mean[n][g] rstd[n][g] gamma[c]), g = c / (C / G);
  * mean / rstd f32 [nimg][G], gamma / beta f32 [C] | NULL, out f32 [nimg][C][2]. */
 int omgsr_groupnorm_scale_shift(const float* mean, const float* rstd, const float* gamma, const float* beta, float* out, int32_t nimg, int32_t C,

@@ -85,6 +85,7 @@ SIGNATURES = {
     "omgsr_igemm_gn_slots": (C.c_int32, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_entries": (C.c_int32, [C.POINTER(IgemmArgs)]),
     "omgsr_igemm_gn_fusable": (C.c_int32, [C.POINTER(IgemmArgs)]),
+    "omgsr_igemm_out_mx6_ok": (C.c_int32, [C.POINTER(IgemmArgs)]),
     "omgsr_groupnorm_scale_shift": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "omgsr_groupnorm_finalize": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, C.c_double, _F, _P]),
     "omgsr_groupnorm_partial": (C.c_int, [_P, _P, _I, _L, _I, _I, _I, _P]),

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libomgsr_hip.so"
-SOURCES = ["igemm.hip", "igemm_dma.hip", "igemm_p8.hip", "igemm_gmx.hip", "igemm_halo.hip", "igemm_halo_f16.hip", "igemm_halo_multi.hip", "igemm_halo_mx.hip", "igemm_halo_mx6.hip", "igemm_halo_mx6_flat.hip", "igemm_halo_flat.hip", "igemm_halo_gn.hip", "attention.hip", "norm.hip", "elementwise.hip", "colorfix.hip", "preprocess.hip", "mfma_peak.hip"]
+SOURCES = ["igemm.hip", "igemm_dma.hip", "igemm_p8.hip", "igemm_gmx.hip", "igemm_halo.hip", "igemm_halo_f16.hip", "igemm_halo_multi.hip", "igemm_halo_mx.hip", "igemm_halo_mx6.hip", "igemm_halo_mx6_flat.hip", "igemm_halo_out6.hip", "igemm_halo_flat.hip", "igemm_halo_gn.hip", "attention.hip", "norm.hip", "elementwise.hip", "colorfix.hip", "preprocess.hip", "mfma_peak.hip"]
 ARCH = "gfx950"
 
 

@@ -34,6 +34,7 @@ int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 bool igemm_gmx_ok(const omgsr_igemm_args& a);
 int igemm_gmx_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);
 int igemm_halo_tiles(const omgsr_igemm_args& a, bool phase = false);
+bool igemm_halo_out6_ok(const omgsr_igemm_args& a);   // igemm_halo_out6.hip: the instantiations whose epilogue writes OMGSR_EL_MX6 can run this problem
 int igemm_halo_flat(const omgsr_igemm_args& a);      // pitch of the FLAT form the halo kernel would use for this problem (narrow maps), 0 = spatial tiles
 int igemm_halo_tiles_form(const omgsr_igemm_args& a, int flat);
 int igemm_halo_gn_slots(const omgsr_igemm_args& a, bool phase = false);
@@ -263,9 +264,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
                 v[e] = x;
                 amax = fmaxf(amax, fabsf(x));
             }
-            store8_mx<T>(p.out, (int64_t)m * 4 * p.Cout, p.Cout, n, v);
+            if (p.out_mx == 6) store8_mx6<T>(p.out, (int64_t)m * 4 * p.Cout, p.Cout, n, v);        // (thread per octet, whole rows: lane quads = blocks)
+            else store8_mx<T>(p.out, (int64_t)m * 4 * p.Cout, p.Cout, n, v);
             if (p.overflow_flag && amax > 65504.0f) atomicOr(p.overflow_flag, 1u);
-            if (p.overflow_flag && amax > 448.0f) atomicOr(p.overflow_flag, 2u);
+            if (p.overflow_flag && p.out_mx == 1 && amax > 448.0f) atomicOr(p.overflow_flag, 2u);
             return;
         }
     }
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const omgsr_igemm_ar
 
 bool use_halo(const omgsr_igemm_args& a);
 bool use_halo_phase(const omgsr_igemm_args& a);
+bool out_mx6_ok(const omgsr_igemm_args& a);
 int halo_splitk_plan(const omgsr_igemm_args& a);
 
 // Split-K for the halo-tile kernel (round 5: the reference's own operating point is ONE 128 -> 512 image per call, infer/infer_omgsr_s.py:92 - its 3x3
@@ -400,6 +403,13 @@ bool use_halo(const omgsr_igemm_args& a_real) {
     return (tiles > gt ? tiles : gt) >= 192;
 }
 
+// out_mx = 6: the problem must run on one of the halo-tile kernel's OUT6 instantiations (the spatial nine-tap form, plain / split fp16 or fp6 operand);
+// with a workspace and a split-K plan the reduce pass writes the form instead (its partial launches are ordinary fp32 ones)
+bool out_mx6_ok(const omgsr_igemm_args& a) {
+    if (a.upsample || a.act == OMGSR_ACT_GEGLU || a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC) return false;
+    return omgsr::igemm_halo_out6_ok(a) && use_halo(a);
+}
+
 // Nearest-2x upsampling + 3x3 conv as four 2 x 2 convolutions of the low-res map (weight_ph: phase-summed kernels), 4 / 9 of the MFMA work
 bool use_halo_phase(const omgsr_igemm_args& a_real) {
     if (a_real.mx_chunks16 > 0) return a_real.upsample && mx_geometry_ok(a_real);
@@ -477,6 +487,12 @@ bool gn_fusable(const omgsr_igemm_args& a_in) {
 }  // namespace
 
 extern "C" int32_t omgsr_igemm_gn_fusable(const omgsr_igemm_args* ap) { return (ap && gn_fusable(*ap)) ? 1 : 0; }
+extern "C" int32_t omgsr_igemm_out_mx6_ok(const omgsr_igemm_args* ap) {
+    if (!ap) return 0;
+    omgsr_igemm_args a = *ap;
+    a.out_mx = 6;
+    return out_mx6_ok(a) ? 1 : 0;
+}
 
 extern "C" int32_t omgsr_igemm_gn_slots(const omgsr_igemm_args* ap) {
     if (!ap) return 0;
@@ -529,8 +545,11 @@ int validate_args(omgsr_igemm_args& a) {
     // an MX operand is understood by the halo-tile kernel (3x3 convs, mx_geometry_ok) and by the MX GEMM kernel (1x1: igemm_gmx.hip)
     if (a.mx_chunks16 < 0 || (a.mx_chunks16 > 0 && !mx_geometry_ok(a) && !omgsr::igemm_gmx_ok(a))) return OMGSR_E_SHAPE;
     // ... the fp6 form (OMGSR_EL_MX6) by the halo-tile kernel's nine-tap forms only
-    if (a.mx_chunks16 > 0 && a.mx_fmt != 0 && a.mx_fmt != 8 && (a.mx_fmt != 6 || a.upsample || !mx_geometry_ok(a))) return OMGSR_E_SHAPE;
-    if (a.out_mx != 0 && a.out_mx != 1) return OMGSR_E_BADARG;         // (the fp6 form is written by the cast / GroupNorm apply kernels only: the fused epilogues have no registers to spare for it)
+    if (a.mx_chunks16 > 0 && a.mx_fmt != 0 && a.mx_fmt != 8 && (a.mx_fmt != 6 || !mx_geometry_ok(a))) return OMGSR_E_SHAPE;
+    // out_mx = 6 (the fp6 operand form as OUTPUT): the halo-tile kernel's dedicated instantiations (igemm_halo_out6.hip) and the split-K reduce pass -
+    // omgsr_igemm_out_mx6_ok() tells the host beforehand; everything else writes a stream tensor and the cast kernel follows
+    if (a.out_mx != 0 && a.out_mx != 1 && a.out_mx != 6) return OMGSR_E_BADARG;
+    if (a.out_mx == 6 && !out_mx6_ok(a)) return OMGSR_E_SHAPE;
     if (a.out_mx && (a.out_dtype != OMGSR_OUT_BF16 || a.out_layout != OMGSR_LAYOUT_NHWC || (a.Cout & 63) || a.out_lo_off || a.out_ld || a.gn_partial ||
                      omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
     if (a.gn_scale_shift && (a.gn_nimg <= 0 || a.gn_act != OMGSR_ACT_SILU || !gn_fusable(a))) return OMGSR_E_SHAPE;      // (SiLU is the one activation the producer applies)

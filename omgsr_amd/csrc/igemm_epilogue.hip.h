@@ -20,7 +20,7 @@ OMGSR_DEVINL void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "me
 // (pixels) mb[i] .. mb[i] + nvalid[i] - 1; n_base: first PACKED column of the wave tile (GEGLU: packed
 // [32 a | 32 g] per 64). Must be called by every wave of the block.
 // RES32: the residual is an fp32 stream tensor (accurate tier) instead of the 16-bit compute type.
-template <typename T, int WTN, int FM, int FN, bool RES32>
+template <typename T, int WTN, int FM, int FN, bool RES32, bool OUT6 = false>
 OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
                                       const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
                                       float* gn_dst, const int gn_howo, const int pxs, const int flat_base) {
@@ -234,6 +234,13 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
                     }
                     bool sok;
                     const int spix = opix(i, row, sok);
+                    if constexpr (OUT6) {      // OUT6 (a template flag with its own kernel instantiations, igemm_halo_out6.hip: as a run-time branch next to the
+                                               // other output forms the cooperative store spilled every kernel that includes this epilogue): the output is the
+                                               // OMGSR_EL_MX6 operand of an up-sampling conv. Lane quads hold the four octets of a block (consecutive lanes =
+                                               // consecutive octets of one output row, Cout % 64 == 0): every lane calls, only the store is predicated
+                        if (sok && col_ok) note8(v);
+                        store8_mx6<T>(outb, (int64_t)spix * 4 * p.Cout, p.Cout, n_out, v, sok && col_ok);
+                    } else
                     if (sok && col_ok) {
                         const int64_t o = (int64_t)spix * ldo + n_out;
                         if (gn_on) {
@@ -407,12 +414,12 @@ OMGSR_DEVINL void igemm_epilogue_impl(const omgsr_igemm_args& p, f32x16_t (&acc)
     flush_ovf();
 }
 
-template <typename T, int WTN, int FM, int FN>
+template <typename T, int WTN, int FM, int FN, bool OUT6 = false>
 OMGSR_DEVINL void igemm_epilogue(const omgsr_igemm_args& p, f32x16_t (&acc)[FM][FN], float* epi, const int lane,
                                  const int (&mb)[FM], const int (&nvalid)[FM], const int n_base, const int bz,
                                  float* gn_dst = nullptr, const int gn_howo = 0, const int pxs = 1, const int flat_base = 0) {
-    if (p.res_el == OMGSR_EL_F32 && p.residual) igemm_epilogue_impl<T, WTN, FM, FN, true>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo, pxs, flat_base);
-    else igemm_epilogue_impl<T, WTN, FM, FN, false>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo, pxs, flat_base);
+    if (p.res_el == OMGSR_EL_F32 && p.residual) igemm_epilogue_impl<T, WTN, FM, FN, true, OUT6>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo, pxs, flat_base);
+    else igemm_epilogue_impl<T, WTN, FM, FN, false, OUT6>(p, acc, epi, lane, mb, nvalid, n_base, bz, gn_dst, gn_howo, pxs, flat_base);
 }
 
 // linear-M helper for the GEMM-shaped kernels: row block i starts at m_base + 32*i

@@ -42,7 +42,10 @@ int igemm_halo_launch_f16(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st,
 // one problem per grid, bf16 compute type (the fp16 instantiations are a translation unit of their own: hipcc compiles the files in parallel)
 int igemm_halo_gn_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);        // igemm_halo_gn.hip
 
+int igemm_halo_out6_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st);              // igemm_halo_out6.hip
+
 int igemm_halo_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st, const bool phase) {
+    if (a.out_mx == 6) return phase ? OMGSR_E_SHAPE : igemm_halo_out6_launch(a, g, st);
     if (a.gn_scale_shift) return phase ? OMGSR_E_SHAPE : igemm_halo_gn_launch(a, g, st);
     if (a.mx_chunks16 > 0) return igemm_halo_launch_mx(a, g, st);
     const bool narrow = halo_geo(a, g, phase);

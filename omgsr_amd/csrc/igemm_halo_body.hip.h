@@ -88,7 +88,7 @@ OMGSR_DEVINL void glds16(const void* gsrc, unsigned lds_dst) {
 // fp32 chunk is 42 KB: no LDS room): loads held in VGPRs across K-steps next to inline-asm DMA traffic the compiler cannot count - not built.
 // SPLITK (round 5): the workgroup runs the chunk range IgemmGeo.cc0 .. cc1 of the contraction (split-K launch groups). A template flag, not a run-time
 // test: with the two extra loop bounds live the FLAT instantiations - already at 256 registers - went from 3 to 38 spilled VGPRs.
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, int MX = 0, int FLAT = 0, int GNF = 0, bool SPLITK = false>      // MX: 0 plain, 1 fp8 correction chunks, 6 fp6 ones; FLAT: 0 spatial tiles, 1 FLAT form, 2 FLAT form with the 27-piece patch
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, int MX = 0, int FLAT = 0, int GNF = 0, bool SPLITK = false, bool OUT6 = false>      // OUT6: the epilogue writes OMGSR_EL_MX6 and nothing else (igemm_halo_out6.hip); MX: 0 plain, 1 fp8 correction chunks, 6 fp6 ones; FLAT: 0 spatial tiles, 1 FLAT form, 2 FLAT form with the 27-piece patch
 OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const int tile, const int bidy) {      // tile: logical (XCD-remapped) tile index
     static_assert(GNF == 0 || (TAPS == 9 && !MX && FLAT == 0 && ABL == 0 && !PRIO), "GNF: spatial nine-tap form only");
     constexpr int WTN = NARROW ? 32 : 64, FM = NARROW ? 2 : 4, FN = NARROW ? 1 : 2, BNK = NARROW ? 32 : 128;
@@ -505,7 +505,7 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
         // ... phase form: four launches' worth of slots per spatial tile, [N][tiles][2][4 phases][G][2]
         const int64_t slot = PHASE ? ((int64_t)(img * per_img + trem) * 2 + wm) * 4 + bidy : (int64_t)(img * per_img + trem) * 2 + wm;
         float* gn_dst = (p.gn_partial && !NARROW) ? p.gn_partial + slot * p.gn_entries * 2 : nullptr;
-        igemm_epilogue<T, WTN, FM, FN>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0, gn_dst, 0, PHASE ? 2 : (FP ? -FP : 1), FP ? img * p.Ho * p.Wo : 0);
+        igemm_epilogue<T, WTN, FM, FN, OUT6>(p, acc, epi, lane, mb, nv, n0 + wn * WTN, 0, gn_dst, 0, PHASE ? 2 : (FP ? -FP : 1), FP ? img * p.Ho * p.Wo : 0);
     }
 }
 
@@ -534,7 +534,7 @@ OMGSR_DEVINL bool phase_block_map(const int b, const int T, const int n8, const 
     return tile < T;
 }
 
-template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, int MX = 0, int FLAT = 0, int GNF = 0>
+template <typename T, int ABL, bool PRIO, bool NARROW = false, int TAPS = 9, int MX = 0, int FLAT = 0, int GNF = 0, bool OUT6 = false>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_args p, const IgemmGeo g) {
     int tile, phase;
     // Phase form (TAPS = 4). The four phases of a tile read the SAME low-res patch and each its own phase-summed weights. Three block orders:
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const omgsr_igemm_ar
     } else {
         tile = xcd_remap((int)blockIdx.x, g.ntm * g.ntn); phase = (int)blockIdx.y;
     }
-    halo_body<T, ABL, PRIO, NARROW, TAPS, MX, FLAT, GNF>(p, g, tile, phase);
+    halo_body<T, ABL, PRIO, NARROW, TAPS, MX, FLAT, GNF, false, OUT6>(p, g, tile, phase);
 }
 
 // Several problems that share weights and epilogue options in ONE launch (the tiled VAE runs every layer once per tile-shape group:
@@ -563,7 +563,7 @@ struct HaloMulti {
     int start[HALO_MULTI_MAX + 1];
     int count;
 };
-template <typename T, bool NARROW, int TAPS, int MX = 0, int FLAT = 0, int GNF = 0, bool SPLITK = false>
+template <typename T, bool NARROW, int TAPS, int MX = 0, int FLAT = 0, int GNF = 0, bool SPLITK = false, bool OUT6 = false>
 __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMulti m) {
     int s = 0, tile, phase;
     if (TAPS == 4 && m.g[0].interleave) {      // x-only grid of 4 x the 8-aligned ranges; block order inside a problem's range: see igemm_halo_kernel
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_multi_kernel(const HaloMult
         if (bid >= m.g[s].ntm * m.g[s].ntn) return;                                 // filler block of the 8-aligned range
         tile = xcd_remap(bid, m.g[s].ntm * m.g[s].ntn); phase = (int)blockIdx.y;
     }
-    halo_body<T, 0, false, NARROW, TAPS, MX, FLAT, GNF, SPLITK>(m.p[s], m.g[s], tile, phase);
+    halo_body<T, 0, false, NARROW, TAPS, MX, FLAT, GNF, SPLITK, OUT6>(m.p[s], m.g[s], tile, phase);
 }
 
 
@@ -589,6 +589,7 @@ static inline int halo_flat_eligible(const omgsr_igemm_args& a) {
     static const char* off = getenv("OMGSR_HALO_FLAT");
     if (off && off[0] == '0') return 0;
     if (a.gn_scale_shift) return 0;                 // the normalising patch producer exists in the spatial form only (omgsr_igemm_gn_fusable said so)
+    if (a.out_mx == 6) return 0;                    // ... and so do the instantiations whose epilogue writes the fp6 operand form (igemm_halo_out6.hip)
     static const char* mw = getenv("OMGSR_HALO_FLAT_MAXW");        // A/B runs: 45 = only the 22-piece patch
     static const int maxw = mw ? atoi(mw) : 80;                   // 256 + 2 (W + 2) + 2 <= 432 patch rows (27 pieces)
     const int logical_cols = (a.act == OMGSR_ACT_GEGLU) ? 2 * a.Cout : a.Cout;

@@ -22,6 +22,7 @@ static int multi_attrs() {
 
 int igemm_halo_launch_multi_mx(const void* halo_multi, unsigned blocks, hipStream_t st);
 int igemm_halo_gn_launch_multi(const void* halo_multi, unsigned blocks, bool narrow, hipStream_t st);      // igemm_halo_gn.hip
+int igemm_halo_out6_launch_multi(const void* halo_multi, unsigned blocks, hipStream_t st);                 // igemm_halo_out6.hip
 int igemm_halo_flat_launch_multi(const void* halo_multi, unsigned blocks, hipStream_t st);      // igemm_halo_flat.hip       // igemm_halo_mx.hip (HaloMulti has no linkage: same header, opaque pointer)
 
 // `count` problems (<= HALO_MULTI_MAX) in one launch; all of them take the same kernel shape (the caller checks: same weights,
@@ -46,6 +47,7 @@ int igemm_halo_launch_multi(const omgsr_igemm_args* a, const IgemmGeo* g0, const
     if (rc != 0) return rc;
     const dim3 grid = (phase && m.g[0].interleave) ? dim3(4 * at) : dim3(at, phase ? 4 : 1, 1);
     if (m.g[0].cc1 > 0 && (flat || phase || narrow || a[0].mx_chunks16 <= 0 || a[0].gn_scale_shift)) return OMGSR_E_SHAPE;      // split-K: the spatial MX instantiation only (halo_splitk_plan)
+    if (a[0].out_mx == 6) return (phase || flat || narrow || m.g[0].cc1 > 0) ? OMGSR_E_SHAPE : igemm_halo_out6_launch_multi(&m, (unsigned)at, st);
     if (a[0].gn_scale_shift) return (phase || flat) ? OMGSR_E_SHAPE : igemm_halo_gn_launch_multi(&m, (unsigned)at, narrow, st);
     if (flat) return igemm_halo_flat_launch_multi(&m, (unsigned)at, st);
     if (a[0].mx_chunks16 > 0) return igemm_halo_launch_multi_mx(&m, (unsigned)at, st);

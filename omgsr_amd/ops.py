@@ -341,8 +341,8 @@ def _pack_mx(w: torch.Tensor, bias, cout: int, cin: int, R: int, S: int, dev, up
     fp8 MFMAs whose E8M0 scale operands undo s1 / s2 and the operand's 2^11.
     fmt 6 (split 4, OMGSR_EL_MX6; 3x3 convs of the halo-tile kernel only): the two correction thirds hold fp6 (e2m3) codes with a scale byte per
     32-channel block inside the data (_e2m3_blocks) - the MFMA runs them in half the passes of fp8."""
-    if fmt == 6 and ((R, S) != (3, 3) or upsample_phases):
-        raise ValueError("the fp6 form (split 4) serves 3x3 stride-1 convolutions of the halo-tile kernel's nine-tap form")
+    if fmt == 6 and (R, S) != (3, 3):
+        raise ValueError("the fp6 form (split 4) serves the 3x3 stride-1 convolutions of the halo-tile kernel")
     rows = (lambda t: _mx6_rows(t)) if fmt == 6 else (lambda t: _mx_rows(t, s1, s2))
     if (R, S) not in ((3, 3), (1, 1)) or cin % 64 or act_dtype() != torch.float16:
         raise ValueError("the mixed-precision (MX) form serves 3x3 and 1x1 convolutions (linears) with Cin % 64 == 0 in the fp16 compute type")
@@ -363,7 +363,7 @@ def _pack_mx(w: torch.Tensor, bias, cout: int, cin: int, R: int, S: int, dev, up
         w_ph = full.view(4, cout_pad, 4, kslots // 32, 32).permute(0, 3, 2, 1, 4).contiguous()         # [phase][chunk][tap][Cout_pad][32]
     b = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
     if fmt == 6:
-        return PackedWeight(out, b, cout, kslots, R, S, w_cm=w_cm, split=4, w_split=1, in_ld=kslots, w_ph=None, mx=(cin // 32, 127, 127, 127, 127), mx_fmt=6)
+        return PackedWeight(out, b, cout, kslots, R, S, w_cm=w_cm, split=4, w_split=1, in_ld=kslots, w_ph=w_ph, mx=(cin // 32, 127, 127, 127, 127), mx_fmt=6)
     return PackedWeight(out, b, cout, kslots, R, S, w_cm=w_cm, split=3, w_split=1, in_ld=kslots, w_ph=w_ph,
                         mx=(cin // 32, 127 - s1, 127 - MX_LO_SHIFT, 127 - s2, 127))
 
@@ -511,9 +511,7 @@ def _fill_out(a: IgemmArgs, out: torch.Tensor, out_split: int, residual: Optiona
     a.out = out.data_ptr()
     a.out_dtype = OUT_F32 if out.dtype == torch.float32 else OUT_BF16
     a.out_lo_off = cout if out_split == 2 else 0
-    if out_split == 4:
-        raise ValueError("no GEMM epilogue writes the fp6 operand form (OMGSR_EL_MX6): its producers are the GroupNorm apply and cast kernels")
-    a.out_mx = int(out_split == 3)
+    a.out_mx = {3: 1, 4: 6}.get(out_split, 0)
     if residual is not None:
         a.residual = residual.data_ptr()
         a.res_el = _el(residual, "residual")
@@ -633,6 +631,11 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: tuple[int
     if gn is not None and not _gn_candidate(x, pw):
         x, gn = gn.apply(x, pw.split), None
     x, out = _conv_args(a, x, pw, stride, pad, upsample, act, residual, gate, out_dtype, alpha, out, out_split, sample_rows)
+    if out_split == 4 and not _lib.load().omgsr_igemm_out_mx6_ok(C.byref(a)):
+        # the fp6 operand form comes out of the halo-tile kernel's dedicated instantiations only: anything else writes a stream tensor and the
+        # cast kernel makes the operand (one more pass over the tensor; small maps and GEMM-shaped problems)
+        return to_operand(conv2d(x, pw, stride=stride, pad=pad, upsample=upsample, act=act, residual=residual, gate=gate, out_dtype=OUT_STREAM,
+                                 alpha=alpha, sample_rows=sample_rows, gn=gn), 4)
     keep = None
     if gn is not None:
         a.in_el = EL_16
@@ -672,6 +675,9 @@ def conv2d_multi(xs, pw: PackedWeight, *, stride: int = 1, pad: tuple[int, int, 
         if gn is not None:
             arr[i].in_el = EL_16
     check(lib.omgsr_igemm_multi_plan(arr, n), "omgsr_igemm_multi_plan")
+    if out_split == 4 and not all(lib.omgsr_igemm_out_mx6_ok(C.byref(arr[i])) for i in range(n)):
+        ys = conv2d_multi(keep, pw, stride=stride, pad=pad, upsample=upsample, act=act, residuals=residuals, out_dtype=OUT_STREAM, gn=gn)
+        return [to_operand(y, 4) for y in ys]
     if gn is not None:
         # one form per layer: every tile-shape group runs the normalising patch producer, or the apply pass runs for all of them
         if all(_gn_fusable(arr[i], gn) for i in range(n)):

@@ -217,6 +217,7 @@ def set_mx(model: nn.Module, patterns: Iterable[str]) -> int:
     _touch()
     regs = [re.compile(p) for p in patterns]
     n = 0
+    is_vae = hasattr(model, "decoder") and hasattr(model, "encoder")
     for name, m in model.named_modules():
         if isinstance(m, Conv2d) and any(r.search(name) for r in regs):
             conv3 = m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)          # halo-tile kernel
@@ -224,11 +225,13 @@ def set_mx(model: nn.Module, patterns: Iterable[str]) -> int:
             if (conv3 or conv1) and m.in_channels % 64 == 0 and m.out_channels >= 96 \
                     and m.out_channels % 8 == 0 and m.op_split == 2 and m.w_split == 2:
                 # fp6 correction segments (OMGSR_EL_MX6, op_split 4; round 5): the 3x3 convs whose operand a GroupNorm apply writes - a
-                # ResnetBlock2D's conv1 / conv2. (The up-samplers' 3x3 conv takes its operand from the previous layer's GEMM epilogue, and the
-                # fused epilogues have no registers to spare for the cooperative fp6 store: built, measured - it spilled every MX kernel - and
-                # removed, profiles/r05_experiments.md.) Half the matrix-pipe passes of fp8 on the correction chunks (1.5x instead of 2x per
-                # layer), the same 3 mantissa bits with a scale per 32-channel block. OMGSR_MX=8 keeps every layer at fp8 (A/B runs).
-                fp6 = conv3 and mx_env != "8" and not getattr(m, "phase_upsample", False) and name.rsplit(".", 1)[-1] in ("conv1", "conv2")
+                # ResnetBlock2D's conv1 / conv2 - and the VAE's up-sampling convs, whose operand the previous ResnetBlock's conv2 writes from the
+                # halo-tile kernel's OUT6 instantiations (ops.conv2d falls back to a stream tensor + the cast kernel where those cannot run; the
+                # UNet's up-samplers sit behind GEMM-shaped producers and small maps and stay fp8). Half the matrix-pipe passes of fp8 on the
+                # correction chunks (1.5x instead of 2x per layer), the same 3 mantissa bits with a scale per 32-channel block. The GEMM-shaped
+                # MX kernels are not matrix-pipe bound and stay fp8. OMGSR_MX=8 keeps every layer at fp8 (A/B runs).
+                is_up = bool(getattr(m, "phase_upsample", False))
+                fp6 = conv3 and mx_env != "8" and ((is_up and is_vae) or (not is_up and name.rsplit(".", 1)[-1] in ("conv1", "conv2")))
                 m.op_split = 4 if fp6 else 3
                 n += 1
     return n

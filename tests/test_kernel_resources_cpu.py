@@ -60,21 +60,23 @@ def test_the_tight_kernels_are_where_design_says(tables):
         if k.startswith(("igemm_halo", "igemm_dma", "igemm_p8", "igemm_gmx", "attn_kernel")):
             assert b["occupancy"] >= 2, (k, b)
     def targs(k):
-        """{TAPS, MX, FLAT, GNF, SPLITK, PRIO} of a halo instantiation: igemm_halo_kernel<T, ABL, PRIO, NARROW, TAPS, MX, FLAT, GNF>,
-        igemm_halo_multi_kernel<T, NARROW, TAPS, MX, FLAT, GNF, SPLITK>."""
+        """{TAPS, MX, FLAT, GNF, SPLITK, PRIO, OUT6} of a halo instantiation: igemm_halo_kernel<T, ABL, PRIO, NARROW, TAPS, MX, FLAT, GNF, OUT6>,
+        igemm_halo_multi_kernel<T, NARROW, TAPS, MX, FLAT, GNF, SPLITK, OUT6>."""
         a = k[k.index("<") + 1:-1].split(",")
         if k.startswith("igemm_halo_multi_kernel"):
-            return dict(taps=a[2], mx=a[3], flat=a[4], gnf=a[5], splitk=a[6], prio="0", abl="0")
-        return dict(taps=a[4], mx=a[5], flat=a[6], gnf=a[7], splitk="0", prio=a[2], abl=a[1])
+            return dict(taps=a[2], mx=a[3], flat=a[4], gnf=a[5], splitk=a[6], out6=a[7], prio="0", abl="0")
+        return dict(taps=a[4], mx=a[5], flat=a[6], gnf=a[7], out6=a[8], splitk="0", prio=a[2], abl=a[1])
     halo = {k: (b, targs(k)) for k, b in built.items() if k.startswith("igemm_halo")}
-    mx = [b for b, t in halo.values() if t["taps"] == "9" and t["mx"] == "1" and t["splitk"] == "0"]      # nine-tap MX instantiations, spatial and FLAT form
+    mx = [b for b, t in halo.values() if t["taps"] == "9" and t["mx"] == "1" and t["splitk"] == "0" and t["out6"] == "0"]      # nine-tap MX instantiations, spatial and FLAT form
     assert len(mx) == 6 and all(b["spill_vgpr"] <= 16 and b["scratch"] <= 64 for b in mx), mx
     flat = [b for b, t in halo.values() if t["flat"] in ("1", "2")]      # the FLAT form (22- and 27-piece patch): 9 fragment-address registers instead of 36
     assert len(flat) == 16 and all(b["spill_vgpr"] <= 4 for b in flat), flat
     sk = [b for b, t in halo.values() if t["splitk"] == "1"]             # the split-K (chunk range) instantiations: spatial MX forms only, small-M regime
     assert len(sk) == 2 and all(b["spill_vgpr"] <= 24 and b["occupancy"] >= 2 for b in sk), sk
     mx6 = [b for b, t in halo.values() if t["mx"] == "6"]                # fp6 correction chunks (round 5): 24-byte fragments + a scale byte, 3 spilled registers
-    assert len(mx6) == 7 and all(b["spill_vgpr"] <= 4 and b["scratch"] <= 16 and b["occupancy"] >= 2 for b in mx6), mx6
+    assert len(mx6) == 11 and all(b["spill_vgpr"] <= 4 and b["scratch"] <= 16 and b["occupancy"] >= 2 for b in mx6), mx6
+    out6 = [b for b, t in halo.values() if t["out6"] == "1"]             # the epilogue writes the fp6 operand form: a template flag with four instantiations of its own
+    assert len(out6) == 4 and all(b["spill_vgpr"] <= 4 and b["scratch"] <= 16 and b["occupancy"] >= 2 for b in out6), out6
     gn = [b for b, t in halo.values() if t["gnf"] == "1"]                # GroupNorm apply as the patch producer (round 5): no spills, two workgroups per CU
     assert len(gn) == 8 and all(b["spill_vgpr"] == 0 and b["scratch"] == 0 for b in gn), gn
     for k, (b, t) in halo.items():

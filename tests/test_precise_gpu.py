@@ -950,10 +950,58 @@ def test_conv_mx6_multi_launch_split_k_and_refusals():
         ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wk.double(), padding=1).permute(0, 2, 3, 1) + r.double()
         y = ops.conv2d(ops.to_operand(x.to(DEV), 4), ops.pack_conv_weight(wk, None, device=DEV, split=4), pad=1, residual=r.to(DEV))
         assert _rel(y, ref) < 3e-5
-    # no GEMM epilogue writes the form, no 1x1 / phase-form weight is packed in it
-    with pytest.raises(ValueError):
-        ops.conv2d(ops.to_operand(xs[0].to(DEV), 4), pw, pad=1, out_dtype=ops.OUT_BF16, out_split=4)
+    # no 1x1 weight is packed in the form (the GEMM-shaped MX kernels read fp8 corrections)
     with pytest.raises(ValueError):
         ops.pack_conv_weight(torch.randn(128, 128, 1, 1), None, device=DEV, split=4)
-    with pytest.raises(ValueError):
-        ops.pack_conv_weight(w, None, device=DEV, split=4, upsample_phases=True)
+
+
+def test_conv_mx6_upsample_phase_form_and_out6_producers():
+    """The producer / consumer pair of a VAE up-sampler in the fp6 form: the previous 3x3 conv writes the OMGSR_EL_MX6 operand from the halo-tile kernel's
+    OUT6 instantiations (plain fp16 and fp6 operands, single launches and launch groups) byte for byte as the cast kernel would; problems those
+    instantiations cannot run (small maps, GEMM-shaped ones) take a stream tensor + the cast kernel, with the same bytes; the phase-decomposed
+    up-sampling conv consumes the operand (fp16 chunks + fp6 chunks of the phase-summed kernels)."""
+    import ctypes as C_
+    from omgsr_amd import _lib, ops
+    bits = lambda t: t.contiguous().view(torch.int16)              # noqa: E731  (raw bytes behind a 16-bit dtype: compare patterns, not values)
+    C = 128
+    wi = torch.zeros(C, C, 3, 3); wi[:, :, 1, 1] = torch.eye(C)      # identity centre tap: the epilogue sees exactly its input
+    res = torch.randn(4, 96, 128, C, generator=_g(50))
+    xh = (torch.randn(4, 96, 128, C, generator=_g(35)) * 3).to(torch.float16).float()
+    want = ops.to_operand((xh + res).to(DEV), 4)
+    for split in (1, 4):                                            # the decoder's single (plain fp16) layers / the fp6 layers in front of an up-sampler
+        pw = ops.pack_conv_weight(wi, None, device=DEV, split=split)
+        a = _lib.IgemmArgs()
+        xo = ops.to_operand(xh.to(DEV), split)
+        ops._conv_args(a, xo, pw, 1, 1, False, ops.ACT_NONE, res.to(DEV), None, ops.OUT_BF16, 1.0, None, 4, 0)
+        assert _lib.load().omgsr_igemm_out_mx6_ok(C_.byref(a)) == 1, "this shape was meant to take an OUT6 instantiation"
+        got = ops.conv2d(xo, pw, pad=1, residual=res.to(DEV), out_dtype=ops.OUT_BF16, out_split=4)
+        assert torch.equal(bits(got), bits(want))
+        # a launch group (the tile-shape groups of a tiled-VAE level)
+        parts = [(xh[:2], res[:2]), (xh[2:, :64], res[2:, :64]), (xh[2:, 64:, :96], res[2:, 64:, :96])]
+        outs = ops.conv2d_multi([ops.to_operand(p[0].contiguous().to(DEV), split) for p in parts], pw, pad=1, residuals=[p[1].contiguous().to(DEV) for p in parts],
+                                out_dtype=ops.OUT_BF16, out_split=4)
+        for o, p_ in zip(outs, parts):
+            assert torch.equal(bits(o), bits(ops.to_operand((p_[0] + p_[1]).contiguous().to(DEV), 4)))
+    # fall-backs: a small map (not a halo-kernel problem) and a Linear - stream tensor + cast kernel, same bytes
+    xs = (torch.randn(1, 16, 16, C, generator=_g(51)) * 3).to(torch.float16).float().to(DEV)
+    got = ops.conv2d(ops.to_operand(xs, 1), ops.pack_conv_weight(wi, None, device=DEV), pad=1, out_dtype=ops.OUT_BF16, out_split=4)
+    assert torch.equal(bits(got), bits(ops.to_operand(xs, 4)))
+    eye = ops.pack_linear_weight(torch.eye(C), None, device=DEV)
+    xr = (torch.randn(1, 5000, C, generator=_g(52)) * 3).to(torch.float16).float().to(DEV)
+    assert torch.equal(bits(ops.linear(xr, eye, out_dtype=ops.OUT_BF16, out_split=4)), bits(ops.to_operand(xr, 4)))
+    # the consumer: nearest-2x + 3x3 conv in the phase form over the fp6 operand
+    C2 = 256
+    x = torch.randn(2, 43, 86, C2, generator=_g(31))
+    w = torch.randn(C2, C2, 3, 3, generator=_g(32)) * (9 * C2) ** -0.5
+    b = 0.1 * torch.randn(C2, generator=_g(33))
+    ref = F.conv2d(F.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    pw = ops.pack_conv_weight(w, b, device=DEV, split=4, upsample_phases=True)
+    assert pw.w_ph is not None and pw.mx_fmt == 6
+    y = ops.conv2d(x.to(DEV), pw, pad=1, upsample=True, gn_groups=32)
+    e = _rel(y, ref)
+    y8 = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w, b, device=DEV, split=3, upsample_phases=True), pad=1, upsample=True)
+    print(f"phase-form fp6 conv: rel {e:.2e} (fp8 form {_rel(y8, ref):.2e})")
+    assert e < 3e-5 and torch.equal(ops.conv2d(x.to(DEV), pw, pad=1, upsample=True), y)
+    ys = ops.conv2d_multi([ops.to_operand(x.to(DEV), 4), ops.to_operand(x[:1, :, :64].contiguous().to(DEV), 4)], pw, pad=1, upsample=True)
+    ref1 = F.conv2d(F.interpolate(x[:1, :, :64].permute(0, 3, 1, 2).double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert _rel(ys[0], ref) < 3e-5 and _rel(ys[1], ref1) < 3e-5

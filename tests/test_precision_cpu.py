@@ -33,11 +33,13 @@ def test_shipped_policy_assignment_on_sd21_shapes():
     # VAE: 30 resnet convs + 3 upsampling convs + (round 4) the 4 1x1 shortcut convs in the mixed-precision form, the decoder's 18 resnet
     # convs above 64 px single, everything else (samplers, conv_in / out, quant convs and - since the 40 x 2-draw sweep of round 4 - the 8
     # mid-block attention linears) split on both sides
-    # round 5: the resnet convs (operand written by a GroupNorm apply) carry their correction segments as fp6 with per-block scales (op_split 4)
-    assert fv == {(4, 2): 30, (3, 2): 7, (1, 1): 18, (2, 2): 17}
+    # round 5: the 3x3 convs of the halo-tile kernel (resnet convs: operand from a GroupNorm apply; the VAE's up-samplers: operand from the previous
+    # conv's OUT6 epilogue) carry their correction segments as fp6 with per-block scales (op_split 4); the 1x1 shortcuts stay fp8
+    assert fv == {(4, 2): 33, (3, 2): 4, (1, 1): 18, (2, 2): 17}
     assert [n for n, m in v.named_modules() if getattr(m, "qk_split", False)] == ["decoder.mid_block.attentions.0"]     # q / k of the decoder's attention split
     mx = [n for n, m in v.named_modules() if getattr(m, "op_split", 0) in (3, 4)]
-    assert all(n.endswith((".conv1", ".conv2")) and "resnets" in n for n, m in v.named_modules() if getattr(m, "op_split", 0) == 4)
+    assert all(m.kernel_size == (3, 3) for n, m in v.named_modules() if getattr(m, "op_split", 0) == 4)
+    assert all(m.kernel_size == (1, 1) for n, m in v.named_modules() if getattr(m, "op_split", 0) == 3)
     assert all(("resnets" in n or "upsamplers" in n) for n in mx) and not any(("decoder.up_blocks.1.resnets" in n and "shortcut" not in n) for n in mx)
     # UNet convs: the 64 x 64 and 32 x 32 resnet convs + the three upsampling convs + every 1x1 shortcut in the mixed-precision form; 16 x 16 resnets and
     # the 8 x 8 level + mid block single. UNet linears (round 4): the 64 x 64 / 32 x 32 transformer blocks' both-sides splits and every
@@ -171,8 +173,8 @@ def test_fp6_weight_packing(accurate_tier):
     assert ops._e2m3_blocks(torch.zeros(2, 64)).sum() == 0                          # an all-zero block: scale byte 0, codes 0
     with pytest.raises(ValueError, match="3x3"):
         ops.pack_conv_weight(torch.randn(16, 64, 1, 1), None, device="cpu", split=4)
-    with pytest.raises(ValueError, match="nine-tap"):
-        ops.pack_conv_weight(w, None, device="cpu", split=4, upsample_phases=True)
+    pu = ops.pack_conv_weight(w, None, device="cpu", split=4, upsample_phases=True)          # the up-samplers' phase-summed 2 x 2 kernels in the same form
+    assert pu.w_ph is not None and tuple(pu.w_ph.shape) == (4, 2 * C // 32, 4, pu.cout_pad, 32) and pu.mx_fmt == 6
 
 
 def test_phase_summed_kernels_equal_the_upsampled_conv():
