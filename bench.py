@@ -48,8 +48,9 @@ WORKLOADS = {
 DTYPES = {"fp32": "float32", "fp16": "float16", "bf16": "bfloat16"}
 IGEMM_VARIANTS = {1: "igemm_kernel", 2: "igemm_dma_kernel", 3: "igemm_halo_kernel", 4: "igemm_dma_kernel(split-K)+splitk_reduce_kernel", 5: "igemm_p8_kernel", 6: "igemm_halo_kernel<TAPS=4>", 7: "igemm_halo_multi_kernel", 8: "igemm_halo_multi_kernel<TAPS=4>", 9: "igemm_gmx_kernel",
                   10: "igemm_halo_kernel<GN>", 11: "igemm_halo_multi_kernel<GN>", 12: "igemm_halo_multi_kernel(split-K)+splitk_reduce_kernel",
-                  13: "igemm_halo_kernel<fp6>", 14: "igemm_halo_multi_kernel<fp6>", 15: "igemm_halo_multi_kernel<fp6>(split-K)+splitk_reduce_kernel"}
-FP6_VARIANTS = (13, 14, 15)       # correction chunks as fp6: 8 MFMA passes per 64 channels where fp8 takes 16 - 3/4 of the fp8 form's matrix-pipe time
+                  13: "igemm_halo_kernel<fp6>", 14: "igemm_halo_multi_kernel<fp6>", 15: "igemm_halo_multi_kernel<fp6>(split-K)+splitk_reduce_kernel",
+                  16: "igemm_halo_kernel<TAPS=4>", 17: "igemm_halo_multi_kernel<TAPS=4>"}       # 16 / 17: the phase form with fp6 correction chunks (named by its form, like rocprofv3's rows)
+FP6_VARIANTS = (13, 14, 15, 16, 17)       # correction chunks as fp6: 8 MFMA passes per 64 channels where fp8 takes 16 - 3/4 of the fp8 form's matrix-pipe time
 
 
 def parse(argv=None):
@@ -164,7 +165,7 @@ def collect_timing(lib_mod):
         # upsampling convs 4 of their 9 taps. `flops` (omgsr_timing: work_of) is the work HANDED to the kernel: logical channels, 9 taps.
         issued = e.flops
         if e.kind == 1 and e.m > 0 and e.n > 0 and e.k > 0:
-            issued = 2.0 * e.m * e.n * e.k * (4.0 / 9.0 if int(e.variant) in (6, 8) else 0.75 if int(e.variant) in FP6_VARIANTS else 1.0)
+            issued = 2.0 * e.m * e.n * e.k * (4.0 / 9.0 if int(e.variant) in (6, 8, 16, 17) else 1.0) * (0.75 if int(e.variant) in FP6_VARIANTS else 1.0)
         k = kinds.setdefault(int(e.kind), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, issued=0.0))
         k["launches"] += 1; k["ms"] += e.ms; k["flops"] += e.flops; k["bytes"] += e.bytes; k["issued"] += issued
         sg = stages.setdefault(int(e.stage), dict(launches=0, ms=0.0, mfma_ms=0.0, mfma_flops=0.0))

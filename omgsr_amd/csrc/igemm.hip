@@ -623,7 +623,7 @@ extern "C" int omgsr_igemm_multi(const omgsr_igemm_args* args, int32_t count, vo
             omgsr::TimingScope ts(OMGSR_TK_IGEMM, gf, gb, st, gm, logical_cols, (long long)grp[0].R * grp[0].S * grp[0].Cin);
             ts.rec.variant = ng == 1 ? (mode == 1 ? 6 : 3) : (mode == 1 ? 8 : 7);      // 7 / 8: igemm_halo_multi_kernel (gather / phase form)
             if (grp[0].gn_scale_shift) ts.rec.variant = ng == 1 ? 10 : 11;              // 10 / 11: the GroupNorm-fused instantiations
-            if (grp[0].mx_chunks16 > 0 && grp[0].mx_fmt == 6) ts.rec.variant = ng == 1 ? 13 : 14;      // 13 / 14 (/ 15: split-K): fp6 correction chunks
+            if (grp[0].mx_chunks16 > 0 && grp[0].mx_fmt == 6) ts.rec.variant = mode == 1 ? (ng == 1 ? 16 : 17) : (ng == 1 ? 13 : 14);      // 13 / 14 (/ 15: split-K): fp6 correction chunks; 16 / 17: in the phase form
             rc = ng == 1 ? omgsr::igemm_halo_launch(grp[0], geo[0], st, mode == 1) : omgsr::igemm_halo_launch_multi(grp, geo, ng, st, mode == 1);
         }
         ng = 0; gf = gb = 0.0; gm = 0;
@@ -722,7 +722,7 @@ extern "C" int omgsr_igemm(const omgsr_igemm_args* ap, void* stream) {
         return omgsr::igemm_gmx_launch(a, g, st);
     }
     // 3x3 s1 p1 convs with a chunk-major weight copy: halo-tile kernel (input patch reused by all 9 taps)
-    if (use_halo_phase(a)) { ts.rec.variant = 6; return omgsr::igemm_halo_launch(a, g, st, true); }
+    if (use_halo_phase(a)) { ts.rec.variant = (a.mx_chunks16 > 0 && a.mx_fmt == 6) ? 16 : 6; return omgsr::igemm_halo_launch(a, g, st, true); }
     if (use_halo(a)) { ts.rec.variant = a.gn_scale_shift ? 10 : (a.mx_chunks16 > 0 && a.mx_fmt == 6) ? 13 : 3; return omgsr::igemm_halo_launch(a, g, st); }
     if (a.gn_scale_shift) return OMGSR_E_SHAPE;                  // (validate_args already refused it: never reached)
     {
