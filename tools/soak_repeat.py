@@ -60,6 +60,15 @@ for N_, C, Co, H_, W_ in [(4, 128, 128, 256, 256), (4, 256, 512, 75, 75), (8, 51
     total += soak(f"[accurate] fp6 cast {N_}x{H_}x{W_}x{C}", lambda: ops.to_operand(xf, 4), reps // 4)
     mean, rstd, _ = ops.group_norm_stats(xf, 32, 1e-6)
     total += soak(f"[accurate] fp6 GroupNorm apply {N_}x{H_}x{W_}x{C}", lambda: ops.group_norm_apply(xf, mean, rstd, None, None, 32, ops.ACT_SILU, split=4), reps // 4)
+# ... the up-sampler pair in the fp6 form: a conv whose epilogue writes the fp6 operand (OUT6 instantiations, plain and fp6 operand) and the phase-form conv that reads it
+for split in (1, 4):
+    xo = ops.to_operand((torch.randn(4, 96, 128, 128, generator=g) * 0.5).to(dev), split)
+    po = ops.pack_conv_weight(torch.randn(128, 128, 3, 3, generator=g) * (9 * 128) ** -0.5, torch.zeros(128), device=dev, split=split)
+    ro = torch.randn(4, 96, 128, 128, generator=g).to(dev)
+    total += soak(f"[accurate] OUT6 halo conv (operand split {split}) 4x96x128 128->128", lambda: ops.conv2d(xo, po, pad=1, residual=ro, out_dtype=ops.OUT_BF16, out_split=4), reps)
+xu = ops.to_operand((torch.randn(4, 86, 86, 256, generator=g) * 0.5).to(dev), 4)
+pu = ops.pack_conv_weight(torch.randn(256, 256, 3, 3, generator=g) * (9 * 256) ** -0.5, torch.zeros(256), device=dev, split=4, upsample_phases=True)
+total += soak("[accurate] fp6 phase-form up-sampling conv 4x86x86 256->256", lambda: ops.conv2d(xu, pu, pad=1, upsample=True), reps)
 # ... and GroupNorm apply + SiLU as the conv's patch producer (fast tiers: a wave normalises its own LDS-DMA'd pieces in place)
 for tier in (torch.bfloat16, torch.float16):
     ops.set_compute_dtype(tier)
