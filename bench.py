@@ -303,6 +303,8 @@ def main():
                     others[name] = tier_leg(getattr(torch, DTYPES[name]), device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img)
             # the tier a checkpoint with out-of-fp16-range activations would actually run (precision.RangeFallback, forced)
             others["fp32_range_fallback"] = tier_leg(torch.float32, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img, range_fallback=True)
+            # the accurate tier with every correction segment as fp8 (round 4's form, OMGSR_MX=8): the same-box reference for what the fp6 segments buy
+            others["fp32_mx_fp8_corrections"] = tier_leg(torch.float32, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img, mx_env="8")
             extra["other_tiers"] = others
             ops.set_compute_dtype(wdtype)
 
@@ -723,14 +725,24 @@ def latency_b1_record(args, device, _lib):
     return rec
 
 
-def tier_leg(wdtype, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img, range_fallback=False):
+def tier_leg(wdtype, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img, range_fallback=False, mx_env=None):
     """The same workload in another --weight_dtype tier: a short timed run + parity of image 0 against the same oracle output.
     range_fallback (accurate tier only): the mode a checkpoint whose activations leave the fp16 range runs in - forced
     with pipe.range_fallback.enter(): bf16 operands (fp32's exponent range), EVERY operand and weight as a two-term split = three K
     segments on every layer, sticky - instead of waiting for an fp16 operand to clip."""
     import torch
     from omgsr_amd.testing import psnr, rel_l2
-    pipe, _ = build_s(device, 0, 1, wdtype)
+    saved = os.environ.get("OMGSR_MX")
+    if mx_env is not None:
+        os.environ["OMGSR_MX"] = mx_env          # precision.set_mx reads it when the pipeline applies its policy
+    try:
+        pipe, _ = build_s(device, 0, 1, wdtype)
+    finally:
+        if mx_env is not None:
+            if saved is None:
+                os.environ.pop("OMGSR_MX", None)
+            else:
+                os.environ["OMGSR_MX"] = saved
     if range_fallback:
         pipe.range_fallback.enter()
     if tiled_vae:
@@ -750,6 +762,8 @@ def tier_leg(wdtype, device, family, side, B, tile, overlap, tiled_vae, inp, ora
     if oracle_img is not None:
         got = out[:1].float().cpu()
         leg.update(rel_l2=round(rel_l2(got, oracle_img), 6), psnr_db=round(psnr(got, oracle_img), 2))
+    if mx_env is not None:
+        leg["mode"] = f"accurate tier under OMGSR_MX={mx_env}: correction segments as fp8 (e4m3, per-tensor scales) on every mixed-precision layer"
     if range_fallback:
         leg["mode"] = "fp32 stream, bf16 MFMA operands, every operand and weight split (3 K segments everywhere); sticky"
         leg["sticky"] = bool(pipe.range_fallback.sticky)
