@@ -71,7 +71,10 @@ def parse(argv=None):
     ap.add_argument("--no-latency", action="store_true", help="default (s1024, 1 GPU) run only: skip the batch-1 latency record (`workloads.latency_ms_b1`: eager vs hipGraph replay)")
     ap.add_argument("--traffic-file", default="", help="rocprofv3 PMC summary (tools/profile_summary.py) to take `roofline.traffic` from; "
                                                        "default: the newest profiles/r*_traffic.json whose args match this run")
-    ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU oracle (median reported) after one warm-up")
+    ap.add_argument("--cpu-runs", type=int, default=1, help="timed runs of the CPU oracle (median reported) after one warm-up on a 512^2 crop")
+    ap.add_argument("--all-tiers", action="store_true", help="also time the fp16 tier and the accurate tier with fp8 correction segments (detail file only)")
+    ap.add_argument("--detail-file", default=os.environ.get("OMGSR_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")),
+                    help="where the full record goes (per-kernel tables, every tier, f1024 / latency records); the stdout line stays compact")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="exercise the N-rank launch / RCCL-shaped broadcast / reporting path on CPU (gloo, reduced models, no kernels)")
     return ap.parse_args(argv)
@@ -287,49 +290,72 @@ def main():
     images = B * world * args.steps
     value = images / elapsed
 
+    # Everything below is reporting. The timed region above is final; each extra leg runs under `guarded`, which records an error
+    # string instead of losing the line, and the stdout line is COMPACT (compact_line: <= 6 KB) - the full record
+    # (per-kernel tables, every tier, the f1024 / latency records) goes to --detail-file.
+    errors = {}
+
+    def guarded(name, fn, *a, **kw):
+        try:
+            return fn(*a, **kw)
+        except Exception as exc:                       # noqa: BLE001 - a failing extra leg must not take the headline with it
+            errors[name] = f"{type(exc).__name__}: {exc}"[:300]
+            try:
+                ops.set_compute_dtype(wdtype)
+                torch.cuda.empty_cache()
+            except Exception:                           # noqa: BLE001
+                pass
+            return None
+
     roofline, extra = None, {}
     if rank == 0 and not args.no_roofline:
-        roofline, extra = roofline_leg(_lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, wdtype)
+        r = guarded("roofline", roofline_leg, _lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, wdtype)
+        if r is not None:
+            roofline, extra = r
 
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and family == "S":
         oracle_img = None
         if not args.no_cpu_baseline:
-            cpu_baseline, parity, oracle_img = cpu_leg(inp, out[:1], tile, overlap, side, tiled_vae, runs=args.cpu_runs)
+            r = guarded("cpu_baseline", cpu_leg, inp, out[:1], tile, overlap, side, tiled_vae, runs=args.cpu_runs)
+            if r is not None:
+                cpu_baseline, parity, oracle_img = r
         if not args.no_fast_tiers:
             others = {}
-            for name in ("fp32", "fp16", "bf16"):
+            tiers = ("fp32", "fp16", "bf16") if args.all_tiers else ("fp32", "bf16")
+            for name in tiers:
                 if name != args.weight_dtype:
-                    others[name] = tier_leg(getattr(torch, DTYPES[name]), device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img)
+                    others[name] = guarded(f"tier_{name}", tier_leg, getattr(torch, DTYPES[name]), device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img)
             # the tier a checkpoint with out-of-fp16-range activations would actually run (precision.RangeFallback, forced)
-            others["fp32_range_fallback"] = tier_leg(torch.float32, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img, range_fallback=True)
-            # the accurate tier with every correction segment as fp8 (round 4's form, OMGSR_MX=8): the same-box reference for what the fp6 segments buy
-            others["fp32_mx_fp8_corrections"] = tier_leg(torch.float32, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img, mx_env="8")
-            extra["other_tiers"] = others
+            others["fp32_range_fallback"] = guarded("tier_fp32_range_fallback", tier_leg, torch.float32, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img, range_fallback=True)
+            if args.all_tiers:
+                # the accurate tier with every correction segment as fp8 (round 4's form, OMGSR_MX=8): the same-box reference for what the fp6 segments buy
+                others["fp32_mx_fp8_corrections"] = guarded("tier_fp32_mx_fp8", tier_leg, torch.float32, device, family, side, B, tile, overlap, tiled_vae, inp, oracle_img, mx_env="8")
+            extra["other_tiers"] = {k: v for k, v in others.items() if v is not None}
             ops.set_compute_dtype(wdtype)
 
     if rank == 0 and world == 1 and family == "F" and not args.no_cpu_baseline:
-        cpu_baseline, par = cpu_leg_f(device, [args.weight_dtype], side, tile, overlap)
-        parity = par[args.weight_dtype]
+        r = guarded("cpu_baseline", cpu_leg_f, device, [args.weight_dtype], side, tile, overlap)
+        if r is not None:
+            cpu_baseline, parity = r[0], r[1][args.weight_dtype]
 
     workloads = None
-    if rank == 0 and world == 1 and args.workload == "s1024" and not args.no_f1024:
+    if rank == 0 and world == 1 and args.workload == "s1024" and not (args.no_f1024 and args.no_latency):
         del pipe, step, out
         torch.cuda.empty_cache()
-        workloads = {"f1024": f1024_record(args, device, _lib)}
-        ops.set_compute_dtype(wdtype)
-    if rank == 0 and world == 1 and args.workload == "s1024" and not args.no_latency:
-        if workloads is None:
-            del pipe, step, out
-            torch.cuda.empty_cache()
-            workloads = {}
-        workloads["latency_ms_b1"] = latency_b1_record(args, device, _lib)
-        ops.set_compute_dtype(wdtype)
+        workloads = {}
+        if not args.no_f1024:
+            workloads["f1024"] = guarded("f1024", f1024_record, args, device, _lib)
+            ops.set_compute_dtype(wdtype)
+        if not args.no_latency:
+            workloads["latency_ms_b1"] = guarded("latency_b1", latency_b1_record, args, device, _lib)
+            ops.set_compute_dtype(wdtype)
+        workloads = {k: v for k, v in workloads.items() if v is not None}
 
     if rank == 0:
         tier = {"fp32": "accurate tier: fp32 tensors between GEMMs, fp16 MFMA operands (two-term split on the layers of omgsr_amd/precision.py), fp32 accumulation",
                 "fp16": "fast tier fp16", "bf16": "fast tier bf16 (the reference's default --weight_dtype)"}[args.weight_dtype]
-        line = {
+        full = {
             "metric": "SR images/sec", "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if args.weight_dtype == "fp32" else args.weight_dtype, "data": "synthetic",
@@ -345,9 +371,94 @@ def main():
             "setup_s": round(build_secs, 1), **extra,
         }
         if workloads:
-            line["workloads"] = workloads
-        print(json.dumps(line), flush=True)
+            full["workloads"] = workloads
+        if errors:
+            full["errors"] = errors
+        detail_path = None
+        try:
+            with open(args.detail_file, "w") as f:
+                json.dump(full, f, indent=1)
+            detail_path = os.path.relpath(args.detail_file, ROOT)
+        except OSError as exc:
+            errors["detail_file"] = str(exc)[:200]
+        print(json.dumps(compact_line(full, family, side, B, tiled_vae, args.weight_dtype, detail_path, errors)), flush=True)
     D.shutdown()
+
+
+MAX_LINE_BYTES = 6000
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(full, family, side, B, tiled_vae, weight_dtype, detail_path, errors):
+    """The ONE stdout line (<= MAX_LINE_BYTES): the contract's keys, `roofline` = the DOMINANT kernel's row (work handed per launch /
+    its average HIP-event duration) with the igemm family's SURVEY 8(d) figure beside it, `cpu_baseline`, `parity`, the stage split and
+    one number per extra leg. Everything else is in the detail file."""
+    tier = {"fp32": "accurate tier (fp32 stream, fp16 MFMA operands + split corrections)", "fp16": "fast tier fp16", "bf16": "fast tier bf16"}[weight_dtype]
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full["config"]
+    wl = f"OMGSR-{family} {side // 4}->{side}, batch={B}/GPU, {tier}" + (", tiled VAE 256/64" if tiled_vae else "")
+    line["config"] = {"workload": wl[:120], **_pick(cfg, "global_batch", "latent_tile", "tile_overlap", "mid_timestep", "world_size"),
+                      "parallelism": f"dp{cfg['world_size']}", "weights": "seeded random, " + ("SD2.1-base" if family == "S" else "FLUX.1-dev") + " shapes",
+                      "timed_region": "pipe.forward (reference's region)"}
+    rf = full.get("roofline")
+    if rf:
+        kernels = rf.get("kernels") or {}
+        dom = next(iter(kernels), None)
+        row = kernels.get(dom, {})
+        line["roofline"] = {
+            "bound": "mfma", "kernel": dom, "achieved": row.get("achieved_tflops"), "peak": rf["peak"], "unit": "TFLOP/s", "frac": row.get("frac"),
+            "basis": "FLOPs handed to the dominant kernel per launch (logical channels, split segments once) / its mean HIP-event duration",
+            "launches": row.get("launches"), "kernel_ms": row.get("total_ms"), "avg_us": row.get("avg_us"),
+            "issued_mfma_tflops": row.get("issued_tflops"), "peak_measured": rf.get("peak_measured_mfma_microbench"),
+            "traffic": row.get("traffic_bytes_per_launch"), "algorithmic_bytes": row.get("bytes_per_launch"),
+            "traffic_over_algorithmic": row.get("traffic_over_algorithmic"),
+            "traffic_measured_in_this_run": False if rf.get("traffic_source") else None,
+            "traffic_source": (rf.get("traffic_source") or "").split(" ")[0] or None, "traffic_kernels_current": rf.get("traffic_kernels_current"),
+            "family": {"name": "igemm (all MFMA GEMM / conv kernels)", "basis": "SURVEY 8(d) algorithmic FLOPs / summed kernel time",
+                       **_pick(rf, "achieved", "frac", "launches", "kernel_ms", "algorithmic_tflop", "handed_tflop", "issued_mfma_tflop",
+                               "traffic", "traffic_over_algorithmic", "pipeline_frac_of_mfma_peak")},
+        }
+    else:
+        line["roofline"] = None
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = ({**_pick(cb, "value", "unit", "cores", "kind"), "sample": str(cb.get("sample", ""))[:160],
+                             **_pick(cb, "cpu_model", "nproc")} if cb else None)
+    line["parity"] = _pick(full.get("parity"), "rel_l2", "psnr_db", "meets_north_star") or None
+    if full.get("stages"):
+        line["stages"] = _pick(full["stages"], "encode_ms", "denoiser_ms", "decode_ms", "denoiser_frac_of_mfma_peak", "denoiser_mfma_kernels_frac_of_peak")
+    if full.get("kernel_ms_by_family"):
+        line["kernel_ms_by_family"] = full["kernel_ms_by_family"]
+    also = {}
+    for name, leg in (full.get("other_tiers") or {}).items():
+        also[f"{full['args']['workload']}_{name}"] = _pick(leg, "ms_per_step", "images_per_s", "rel_l2")
+    wls = full.get("workloads") or {}
+    f10 = wls.get("f1024") or {}
+    for key in ("fp32", "fp32_range_fallback", "bf16"):
+        leg = f10.get(key)
+        if leg:
+            rec = _pick(leg, "ms_per_step", "images_per_s", "batch")
+            rec.update(_pick(leg.get("stages"), "denoiser_frac_of_mfma_peak"))
+            rec.update(_pick(leg.get("parity"), "rel_l2"))
+            also[f"f1024_{key}"] = rec
+    lat = wls.get("latency_ms_b1") or {}
+    for key in ("fp32", "bf16"):
+        if lat.get(key):
+            also[f"s512_b1_{key}"] = _pick(lat[key], "eager_ms", "graph_ms", "graph_equals_eager_bitwise")
+    if also:
+        line["also"] = also
+    line.update(_pick(full, "per_rank_ms_per_step", "n_ranks_seen", "broadcast_bytes", "setup_s"))
+    if errors:
+        line["errors"] = {k: v[:160] for k, v in errors.items()}
+    line["detail"] = detail_path
+    # the driver keeps an 8 KB tail of stdout: never let the line outgrow it
+    for drop in ("also", "kernel_ms_by_family", "stages"):
+        if len(json.dumps(line)) <= MAX_LINE_BYTES:
+            break
+        line.pop(drop, None)
+    return line
 
 
 def make_inputs(family, side, B, tile, rank, device, wdtype):
@@ -456,17 +567,17 @@ def roofline_leg(_lib, step, args, tflop_per_img, B, world, elapsed, tiled_vae, 
     _lib.check(lib.omgsr_mfma_peak(4096, C.byref(peak_meas), torch.cuda.current_stream().cuda_stream), "omgsr_mfma_peak")
     per_kernel = {}
     for name, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
-        # per kernel: `handed_tflop` = the work it was handed (logical channels, split segments counted once, 9 taps for the phase form);
-        # `issued_mfma_tflop` = the MFMA work it ran for that, in fp16-equivalent matrix-pipe time (what SQ_VALU_MFMA_BUSY_CYCLES
-        # reconciles with); `achieved_tflops` / `frac` / `frac_of_measured_peak` are on the ISSUED work, so none can exceed the
-        # micro-benchmark ratio; `handed_tflops` is the rate on the handed work (above the issued rate only where the kernel does less
-        # work than it was handed: the phase-decomposed upsampling convs)
-        ach = k["issued"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        # per kernel (SURVEY 8(d) / VERDICT r5 item 1): `achieved_tflops` / `frac` are ALGORITHMIC - the FLOPs the launches were handed
+        # (logical channels, a split operand's extra K segments counted once, 9 taps for the phase form, tile overlap included: it is
+        # work of that launch) / their summed HIP-event time / the 2.5 PF peak. `issued_tflops` / `issued_frac` is the MFMA work the
+        # kernel actually ran for that, in fp16-equivalent matrix-pipe time (what SQ_VALU_MFMA_BUSY_CYCLES reconciles with).
+        iss = k["issued"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
         hand = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
         per_kernel[name] = {"launches": k["launches"], "total_ms": round(k["ms"], 3), "avg_us": round(k["ms"] * 1e3 / k["launches"], 2),
                             "handed_tflop": round(k["flops"] / 1e12, 3), "issued_mfma_tflop": round(k["issued"] / 1e12, 3),
-                            "achieved_tflops": round(ach, 1), "handed_tflops": round(hand, 1),
-                            "frac": round(ach / PEAK_DENSE_TFLOPS, 4), "frac_of_measured_peak": round(ach / max(float(peak_meas.value), 1.0), 4),
+                            "achieved_tflops": round(hand, 1), "frac": round(hand / PEAK_DENSE_TFLOPS, 4),
+                            "issued_tflops": round(iss, 1), "issued_frac": round(iss / PEAK_DENSE_TFLOPS, 4),
+                            "issued_frac_of_measured_peak": round(iss / max(float(peak_meas.value), 1.0), 4),
                             "bytes_per_launch": round(k["bytes"] / k["launches"])}
     roofline = None
     ig, at = kinds.get(1), kinds.get(2)

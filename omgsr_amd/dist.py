@@ -7,6 +7,7 @@ checksum all-reduce proving the replicas are bit-identical.
 """
 from __future__ import annotations
 
+import datetime
 import os
 from typing import Iterable, List, Tuple
 
@@ -28,7 +29,9 @@ def init(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        kw = {}
+        # explicit collective timeout, longer than any rank-0-only reporting leg of bench.py (the peers wait in the final barrier while
+        # rank 0 runs its roofline pass): the default 10 min of the NCCL backend is not a contract
+        kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("OMGSR_DIST_TIMEOUT_S", "1800")))}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)

@@ -150,3 +150,21 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     # per-rank step time next to the max over ranks the contract times: a SCALE run shows stragglers
     pr = j["per_rank_ms_per_step"]
     assert pr["min"] <= pr["max"] and abs(pr["max"] - j["ms_per_step"]) < 1e-6
+
+
+def test_bench_dry_run_world8_line_is_compact(tmp_path):
+    """configs[4]'s launch shape (`python bench.py --gpus 8 --workload f1024` on the GPU node) rehearsed on CPU: 8 ranks spawned by bench.py
+    itself, gloo, reduced models; the ONE stdout line must fit the driver's stdout tail and report all 8 ranks."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "0", "--dry-run-cpu", "--batch", "8"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= 6000, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["n_ranks_seen"] == 8 and j["config"]["global_batch"] == 64 and j["config"]["images_rank0"] == [0, 8]
+    assert j["scaling"] == "weak" and j["dry_run"] is True and j["config"]["broadcast_bytes"] > 1 << 20

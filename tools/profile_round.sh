@@ -7,12 +7,12 @@ TAG=${1:-r03}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-tiers --no-f1024 --no-latency $*"
+BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-tiers --no-f1024 --no-latency --detail-file $OUT/bench_detail.json $*"
 OMGSR_KERNEL_TABLE=$OUT/ktable.md rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
 DB=$(find $OUT/trace -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB $OUT/kernel_stats.md > /dev/null
 # three pipeline passes: the first also runs the one-time constant folding; tools/traffic_summary.py keeps the last two (steady state)
-ONE="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-tiers --no-f1024 --no-latency $*"
+ONE="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-tiers --no-f1024 --no-latency --detail-file $OUT/bench_detail_pmc.json $*"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 $ONE > /dev/null 2> $OUT/pmc_$C.log
 done

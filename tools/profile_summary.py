@@ -5,7 +5,9 @@ import json, os, shutil, sys
 src, tag, title = sys.argv[1], sys.argv[2], sys.argv[3]
 ttag = sys.argv[4] if len(sys.argv) > 4 else tag + "_traffic"
 extra = (" " + sys.argv[5]) if len(sys.argv) > 5 else ""
-bench = json.loads(open(os.path.join(src, "bench_under_trace.json")).read().strip().splitlines()[-1])
+# the stdout line is compact since round 6; the full record (per-kernel rows) is the detail file written by the same run
+_detail = os.path.join(src, "bench_detail.json")
+bench = json.load(open(_detail)) if os.path.isfile(_detail) else json.loads(open(os.path.join(src, "bench_under_trace.json")).read().strip().splitlines()[-1])
 traffic = json.load(open(os.path.join(src, "traffic.json")))
 roof = bench["roofline"]
 fam = traffic["families"]
