@@ -48,7 +48,7 @@ OMGSR_DEVINL void glds16_sv(const unsigned voff, const void* sbase, const unsign
 }
 
 template <typename T, int D, bool DMA>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, const int ntiles, const float defer) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, const int ntiles, const float defer, const int qtiles, const int xcd_order) {
     constexpr int KP = DMA ? 2 * D : 2 * D + 16;
     constexpr int VP = DMA ? 128 : 136;
     constexpr int K_BYTES = 64 * KP, V_BYTES = D * VP;
@@ -61,8 +61,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // 1-D grid of qtiles x H x B workgroups. XCD-aware order (round 6): the hardware deals consecutive block ids round-robin over the 8 XCDs, so
+    // with the natural order every XCD's L2 fetched every head's K / V^T (FLUX: 8 x 453 MB per launch = the 4.9x of profiles/r05_traffic_f1024_*);
+    // xcd_remap gives each XCD a contiguous range of (b, h, q-tile) ids: the 36 (FLUX) / 32 (UNet) query tiles of a head share ONE L2.
+    const int tile = xcd_order ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int qt = tile % qtiles, bh = tile / qtiles;
+    const int h = bh % p.H, b = bh / p.H;
+    const int q0 = qt * 128 + wave * 32;
 
     const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_bstride + h * D;
     const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_bstride + h * D;
@@ -381,8 +386,12 @@ int launch_attn(const omgsr_attn_args& a, hipStream_t st) {
         attr_set = true;
     }
     const int ntiles = (a.Lk + 63) / 64;
-    dim3 grid((a.Lq + 127) / 128, a.H, a.B);
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL((attn_kernel<T, D, DMA>), grid, dim3(256), LDS, st, a, ntiles, g_defer_max));
+    const int qtiles = (a.Lq + 127) / 128;
+    const int64_t blocks = (int64_t)qtiles * a.H * a.B;
+    if (blocks > 0x7fffffffll) return OMGSR_E_SHAPE;
+    static const char* xo = getenv("OMGSR_ATTN_XCD");            // A/B runs: "0" = natural block order (every XCD reads every head's K / V^T)
+    const int xcd_order = !(xo && xo[0] == '0');
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL((attn_kernel<T, D, DMA>), dim3((unsigned)blocks), dim3(256), LDS, st, a, ntiles, g_defer_max, qtiles, xcd_order));
     return (int)hipGetLastError();
 }
 

@@ -341,8 +341,10 @@ int igemm_dma_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
         static const char* bms = getenv("OMGSR_DMA_BM");             // A/B runs: "256" | "192" | "128" | "64" (the last two: GEMM-shaped problems only)
         const bool gemm_shaped = a.R == 1 && a.S == 1 && a.stride == 1 && !a.upsample;
         if (!bms) {
-            if (t256b < 64) return launch_dma<2, 2, 0, 64>(a, g, st);
-            if (t256b < 160) return launch_dma<2, 2, 0, 128>(a, g, st);
+            // GEMM-shaped problems only: the 64 / 128-row instantiations are tested on 1x1 shapes; a 3x3 / strided conv forced here
+            // (OMGSR_IGEMM_MODE=dma) keeps the 256 / 192-row tiles whatever its tile count
+            if (gemm_shaped && t256b < 64) return launch_dma<2, 2, 0, 64>(a, g, st);
+            if (gemm_shaped && t256b < 160) return launch_dma<2, 2, 0, 128>(a, g, st);
         } else if (gemm_shaped) {
             static const char* mk = getenv("OMGSR_DMA_BM_MAXK");      // ... with K_pad <= this (default: any)
             static const int maxk = mk ? atoi(mk) : (1 << 30);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void igemm_gmx_kernel(const omgsr_igemm_arg
                 for (int j = 0; j < FN; ++j)
                     // inline asm with the accumulator tied in place: through the builtin the register allocator moves whole accumulators
                     // between the fp16 and the fp8 loop. Dependent MFMAs on one accumulator are 7 instructions of 16 passes apart.
-                    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+                    asm volatile("s_nop 3\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
                                  : "+v"(acc[i][j]) : "v"(b8[j]), "v"(a8[i]), "v"(sw), "v"(sa));   // transposed tile
                 if (i == (FM > 1 ? FM / 2 - 1 : 0)) {               // this step's LDS-DMA pieces behind the first half of its MFMAs (one row block: behind all of them)
                     __builtin_amdgcn_sched_barrier(0);

@@ -397,7 +397,10 @@ OMGSR_DEVINL void halo_body(const omgsr_igemm_args& p, const IgemmGeo& g, const 
                     // inline asm: with the builtin the register allocator moves whole accumulators between the fp16 and the fp8 loop
                     // (800+ spilled VGPRs at this kernel's pressure); tied in place it keeps them where they are. Dependent MFMAs on one
                     // accumulator are 7 instructions of 16 passes apart, far beyond the hazard window the compiler would otherwise pad.
-                    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+                    // s_nop 3 (round 6): hipcc pads no hazards around inline asm, and a v_mov copy of a fragment register placed right in
+                    // front of the MFMA raced the matrix pipe in the fp6 form (above); the fp8 sites carry the same padding instead of depending on
+                    // the current register allocation
+                    asm volatile("s_nop 3\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
                                  : "+v"(acc[i][j]) : "v"(b8[j]), "v"(a8[i]), "v"(sw), "v"(sa));   // transposed tile
                 if constexpr (LATE) {
                     if (i == FM / 2 - 1) {

@@ -77,6 +77,10 @@ int igemm_halo_launch_splitk(const omgsr_igemm_args& a, const IgemmGeo& g0, cons
         q.out_dtype = OMGSR_OUT_F32; q.out_ld = ldw; q.out_lo_off = 0; q.out_mx = 0;
         q.bias = nullptr; q.gate = nullptr; q.residual = nullptr; q.act = OMGSR_ACT_NONE; q.alpha = 1.0f;
         q.gn_partial = nullptr; q.gn_groups = 0; q.gn_entries = 0; q.overflow_flag = nullptr; q.workspace = nullptr;
+        // halo_splitk_plan decided on the REAL arguments that this problem runs the spatial form (an out_mx = 6 problem is never FLAT-eligible, so it
+        // plans a split on maps <= 80 wide too); the stripped view (out_mx = 0) WOULD be FLAT-eligible there and halo_geo() would pick FLAT, for which
+        // no chunk-range instantiation exists: a positive group_tiles pins every part to the spatial form (halo_flat_pitch).
+        q.group_tiles = g0.ntm > 0 && g0.ntn > 0 ? g0.ntm * g0.ntn : 1;
         geos[s] = g0;
         if (mx) {
             const int h = splits / 2, t = s < h ? s : s - h;

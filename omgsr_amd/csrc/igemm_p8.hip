@@ -197,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const omgsr_igemm_args
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int ii = 0; ii < 2; ++ii)
-                        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+                        asm volatile("s_nop 3\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
                                      : "+v"(acc[i0 + ii][j]) : "v"(j ? b18[i] : b08[i]), "v"(a8[ii][i]), "v"(sw[i]), "v"(sa[i]));   // transposed tile
             } else {
 #pragma unroll

@@ -42,6 +42,28 @@ def bump_cache_epoch() -> None:
     _CACHE_EPOCH += 1
 
 
+# Rebuild log (pipelines/graphed.py): while a hipGraph capture is open, every cache that rebuilds registers how to INVALIDATE itself. A value built
+# under capture was never computed (its kernels were recorded, not run); if the capture is then discarded, the slots are emptied so that the eager
+# re-run rebuilds them for real instead of reading uninitialised memory.
+_REBUILD_LOG = None
+
+
+def begin_rebuild_log() -> None:
+    global _REBUILD_LOG
+    _REBUILD_LOG = []
+
+
+def end_rebuild_log() -> list:
+    global _REBUILD_LOG
+    log, _REBUILD_LOG = _REBUILD_LOG or [], None
+    return log
+
+
+def _log_rebuild(invalidate) -> None:
+    if _REBUILD_LOG is not None:
+        _REBUILD_LOG.append(invalidate)
+
+
 class InputCache:
     """One-slot cache keyed on per-call INPUT tensors (prompt embeddings, ids, pooled projections). The caching allocator
     reuses addresses, so an address is not an identity: the slot keeps a strong reference to every keyed tensor and
@@ -56,12 +78,17 @@ class InputCache:
         self._versions = tuple(None if t is None else t._version for t in inputs)
         bump_cache_epoch()
 
+    def invalidate(self) -> None:
+        self._inputs, self._versions, self._wkey, self._value = None, None, None, None
+        bump_cache_epoch()
+
     def get(self, inputs: tuple, wkey: tuple, builder):
         same = (self._inputs is not None and len(self._inputs) == len(inputs) and self._wkey == wkey and
                 all(a is b for a, b in zip(self._inputs, inputs)) and
                 self._versions == tuple(None if t is None else t._version for t in inputs))
         if not same:
             bump_cache_epoch()
+            _log_rebuild(self.invalidate)
             self._value = builder()
             self._inputs, self._wkey = tuple(inputs), wkey
             self._versions = tuple(None if t is None else t._version for t in inputs)
@@ -71,10 +98,15 @@ class InputCache:
 class _Packed:
     """Mixin: lazily packed weights keyed on the parameters' identity/version."""
 
+    def _drop_packed(self) -> None:
+        self._pk, self._pk_key = None, None
+        bump_cache_epoch()
+
     def _packed(self, builder, *tensors):
         k = _key(*tensors)
         if getattr(self, "_pk_key", None) != k:
             bump_cache_epoch()
+            _log_rebuild(self._drop_packed)
             self._pk = builder()
             self._pk_key = k
         return self._pk

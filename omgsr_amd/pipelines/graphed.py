@@ -51,6 +51,8 @@ class GraphCache:
         self._seen: Dict[tuple, int] = {}
         self._graphs: Dict[tuple, tuple] = {}
         self._eager_only: set = set()       # keys whose capture failed: run eagerly from then on instead of retrying the capture per call
+        self._last = None                   # (key, cache epoch) when the previous call returned: a capture needs the one-slot caches WARM for its key
+        self.capture_failures: Dict[str, int] = {}      # reason -> count (a capture that throws is not silent)
         self.replays = 0
         self.captures = 0
         self.stale_drops = 0
@@ -59,6 +61,13 @@ class GraphCache:
         self._graphs.clear()
         self._seen.clear()
         self._eager_only.clear()
+        self._last = None
+
+    def _eager(self, full, fn, dynamic):
+        from .. import nn as onn
+        out = fn(*dynamic)
+        self._last = (full, onn.cache_epoch())
+        return out
 
     @staticmethod
     def _ident(t: Optional[torch.Tensor]):
@@ -73,6 +82,7 @@ class GraphCache:
         captured under, and a graph whose epoch is not the current one is dropped instead of replayed (prompt A -> B -> A: graph A's
         K / V^T were freed when B's replaced them in the slot)."""
         from .. import nn as onn, ops, precision
+        from .._lib import OmgsrError
         if not self.enabled:
             return fn(*dynamic)
         # everything that selects kernels or packed-weight forms without touching a parameter: tier, precision policy, batch-invariant
@@ -91,40 +101,64 @@ class GraphCache:
                 s.copy_(d)
             g.replay()
             self.replays += 1
+            self._last = (full, onn.cache_epoch())
             return static_out.clone()
         if full in self._eager_only:
-            return fn(*dynamic)
+            return self._eager(full, fn, dynamic)
         if len(self._eager_only) > 256:      # (bounded like _seen: a service must not grow a set per failed key forever)
             self._eager_only.clear()
         n = self._seen.get(full, 0)
         if len(self._seen) > 4096:       # keys are cheap (ints / shapes), but a service that sees ever-new prompts must not grow without bound
             self._seen.clear()
-        self._seen[full] = n + 1
-        if n == 0:                       # first sight: eager (warms packed weights, folded constants, kernel attributes, the allocator)
-            return fn(*dynamic)
+        # Capture only over WARM caches: the immediately preceding call had this key and no cache has rebuilt since it returned. A builder that
+        # runs under capture is recorded, not executed - prompt A, B, A as single calls reaches the third call with _seen[A] == 1 while the
+        # cross-attention K / V^T slot holds B's: that call runs eagerly (it re-warms the slot) and counts as a first sighting.
+        warm = n > 0 and self._last == (full, onn.cache_epoch())
+        self._seen[full] = n + 1 if warm else 1
+        if not warm:                     # first sight / cold caches: eager (warms packed weights, folded constants, kernel attributes, the allocator)
+            return self._eager(full, fn, dynamic)
         if len(self._graphs) >= self.max_graphs:
             self._graphs.pop(next(iter(self._graphs)))
         static_in = [d.clone() for d in dynamic]
         torch.cuda.synchronize()
         epoch0 = onn.cache_epoch()
         g = torch.cuda.CUDAGraph()
+        onn.begin_rebuild_log()
         try:
             with torch.cuda.graph(g):
                 static_out = fn(*static_in)
-        except Exception:
-            # a capture that throws (an op that synchronises, an allocation the graph pool refuses) must not be retried on every call
+        except RuntimeError as exc:
+            # a capture that throws (an op that synchronises, an allocation the graph pool refuses: both surface as RuntimeError) must not be
+            # retried on every call; anything else (a kernel wrapper's OmgsrError, a TypeError) is a real error and propagates. Values built under
+            # the aborted capture never ran: empty those slots before the eager run.
+            for invalidate in onn.end_rebuild_log():
+                invalidate()
+            if isinstance(exc, OmgsrError):
+                raise
             self._eager_only.add(full)
+            reason = f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}"[:200]
+            self.capture_failures[reason] = self.capture_failures.get(reason, 0) + 1
             torch.cuda.synchronize()
-            return fn(*dynamic)
+            return self._eager(full, fn, dynamic)
+        except BaseException:
+            for invalidate in onn.end_rebuild_log():
+                invalidate()
+            raise
+        rebuilt = onn.end_rebuild_log()
         if onn.cache_epoch() != epoch0:
-            # a cache rebuilt DURING the capture: its value lives in the graph's private pool and the slot now points into it - do not
-            # keep such a graph (the eager warm-up call exists so that this never happens; if it does, stay eager for this key)
+            # a cache rebuilt DURING the capture: its value lives in the graph's private pool, was never computed (the graph is not replayed)
+            # and the slot now points at it - drop the graph, EMPTY every such slot, and run eagerly (which rebuilds them for real). The warm
+            # check above exists so that this never happens; if it does, stay eager for this key.
+            for invalidate in rebuilt:
+                invalidate()
             self._eager_only.add(full)
+            self.capture_failures["cache rebuilt during capture"] = self.capture_failures.get("cache rebuilt during capture", 0) + 1
             del g
             torch.cuda.synchronize()
-            return fn(*dynamic)
+            return self._eager(full, fn, dynamic)
         self._graphs[full] = (g, static_in, static_out, tuple(fixed), epoch0)      # `fixed` kept alive: their addresses are baked into the graph
         self.captures += 1
         g.replay()
         self.replays += 1
+        self._last = (full, onn.cache_epoch())
         return static_out.clone()

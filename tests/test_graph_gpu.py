@@ -99,6 +99,38 @@ def test_graph_prompt_a_b_a_drops_the_stale_graph():
         ops.set_compute_dtype(torch.bfloat16)
 
 
+def test_graph_single_calls_a_b_a_never_capture_over_a_cold_cache():
+    """prompt A, B, A as SINGLE calls. The third call has seen A once, so round 5 captured it - while the one-slot cross-attention
+    K / V^T cache held B's: the builder ran under capture (recorded, never executed), the graph was discarded for the epoch change, and the eager
+    re-run read the never-computed K / V^T. A capture now needs the preceding call to have had the same key with no rebuild since; every result of
+    an alternating A / B service equals the eager result of its prompt, and consecutive calls still capture and replay."""
+    from omgsr_amd import ops
+    from omgsr_amd.testing import synthetic_lq
+    wd = torch.bfloat16
+    try:
+        pipe = _s_pipe(wd)
+        g = torch.Generator().manual_seed(11)
+        pa = torch.randn(1, 77, 128, generator=g).to(device=DEV, dtype=wd)
+        pb = torch.randn(1, 77, 128, generator=g).to(device=DEV, dtype=wd)
+        pipe.vae.posterior_noise = torch.randn(1, 4, 24, 24, generator=g).to(DEV)
+        x = synthetic_lq(1, 192, 192, seed=5).to(device=DEV, dtype=wd)
+        with torch.no_grad():
+            ref_a, ref_b = pipe(x, pa, 32, 8)[0], pipe(x, pb, 32, 8)[0]
+            assert not torch.equal(ref_a, ref_b)
+            pipe.enable_graphs(True)
+            for i, (p, ref) in enumerate([(pa, ref_a), (pb, ref_b), (pa, ref_a), (pb, ref_b), (pa, ref_a), (pb, ref_b)]):
+                junk = torch.full((1 << 22,), float("nan"), device=DEV, dtype=wd)       # poison what the allocator hands out next
+                del junk
+                assert torch.equal(pipe(x, p, 32, 8)[0], ref), f"alternating call {i}"
+            assert pipe.graphs.captures == 0 and not pipe.graphs.capture_failures and not pipe.graphs._eager_only
+            # the same pipe still graphs a prompt that stays: eager (re-warm), capture, replay
+            for _ in range(3):
+                assert torch.equal(pipe(x, pa, 32, 8)[0], ref_a)
+            assert pipe.graphs.captures == 1 and pipe.graphs.replays >= 2
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
+
+
 def test_omgsr_f_graph_batch_1_2_1():
     """The FLUX pipeline's cached timestep / guidance tensors are rebuilt per batch size: B = 1 -> 2 -> 1 under graphs equals eager."""
     from omgsr_amd import ops

@@ -955,6 +955,36 @@ def test_conv_mx6_multi_launch_split_k_and_refusals():
         ops.pack_conv_weight(torch.randn(128, 128, 1, 1), None, device=DEV, split=4)
 
 
+@pytest.mark.parametrize("H,W", [(48, 48), (40, 40), (72, 72), (64, 64)])
+def test_conv_mx6_split_k_with_fp6_output_on_narrow_maps(H, W):
+    """ONE image per call through a ResnetBlock conv2 that feeds an up-sampler in the accurate tier - fp6 operand in, fp6 operand
+    out (out_split = 4), 512 -> 512 on a latent that is not 64 wide. The real arguments plan a spatial split-K (an out_mx = 6 problem is never FLAT);
+    the stripped chunk-range parts used to re-plan themselves onto the FLAT form (W <= 80) and the launch refused with OMGSR_E_SHAPE. The result
+    is the same operand the cast kernel makes of the one-pass conv's stream output: fp16 third equal up to summation order, corrections decoding to it."""
+    import ctypes as C_
+    from omgsr_amd import _lib, ops
+    Ci = Co = 512
+    x = torch.randn(1, H, W, Ci, generator=_g(61))
+    wk = torch.randn(Co, Ci, 3, 3, generator=_g(62)) * (9 * Ci) ** -0.5
+    r = torch.randn(1, H, W, Co, generator=_g(63))
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wk.double(), padding=1).permute(0, 2, 3, 1) + r.double()
+    pw = ops.pack_conv_weight(wk, None, device=DEV, split=4)
+    xo = ops.to_operand(x.to(DEV), 4)
+    a = _lib.IgemmArgs()
+    ops._conv_args(a, xo, pw, 1, 1, False, ops.ACT_NONE, r.to(DEV), None, ops.OUT_BF16, 1.0, None, 4, 0)
+    cols = -(-Co // 128) * 128
+    splits = _lib.load().omgsr_igemm_workspace_bytes(C_.byref(a)) // (4 * H * W * cols)
+    assert a.out_mx == 6 and splits >= 2, "this shape was meant to plan a halo split-K with an fp6 output"
+    got = ops.conv2d(xo, pw, pad=1, residual=r.to(DEV), out_dtype=ops.OUT_BF16, out_split=4)
+    raw = got.cpu().view(torch.uint8).reshape(1, H, W, 4 * Co)
+    hi = raw[..., :2 * Co].contiguous().view(torch.float16).double()
+    lo = _mx6_third(raw[..., 2 * Co:3 * Co])
+    hi6 = _mx6_third(raw[..., 3 * Co:])
+    assert _rel(hi + lo, ref) < 3e-5 and _rel(hi6, ref) < 5e-2
+    again = ops.conv2d(xo, pw, pad=1, residual=r.to(DEV), out_dtype=ops.OUT_BF16, out_split=4)
+    assert torch.equal(again.view(torch.int16), got.view(torch.int16))       # raw bytes (fp6 codes read as fp16 may be NaN patterns)
+
+
 def test_conv_mx6_upsample_phase_form_and_out6_producers():
     """The producer / consumer pair of a VAE up-sampler in the fp6 form: the previous 3x3 conv writes the OMGSR_EL_MX6 operand from the halo-tile kernel's
     OUT6 instantiations (plain fp16 and fp6 operands, single launches and launch groups) byte for byte as the cast kernel would; problems those
