@@ -286,7 +286,13 @@ typedef struct omgsr_attn_args {
     int32_t o_mx;          /* 1: o is written in the mixed-precision operand form OMGSR_EL_MX (the output projection is an MX GEMM,
                               omgsr_igemm with mx_chunks16 > 0): a row of C = H*D channels is 4C bytes [hi fp16 | lo' fp8 | hi' fp8];
                               o_ld = 2C (16-bit slots), o_lo_off = 0, C % 64 == 0, fp16 compute type (ABI v14) */
-    int32_t reserved0;
+    int32_t q_lo_off;      /* ABI v17, with k_lo_off (both > 0 or both 0; D = 64): q and k are TWO-TERM SPLITS - the low halves of a row sit q_lo_off /
+                              k_lo_off elements after q / k (a fused [q | k] projection written with out_lo_off: [q_hi | k_hi | q_lo | k_lo]); the
+                              scores are K_hi Q_hi^T + K_lo Q_hi^T + K_hi Q_lo^T in one fp32 accumulator. The range-fallback tier's bf16 operands
+                              (8-bit mantissas) need it to hold the north-star tolerance on the UNet (replaces nothing in torch: F.sdpa in fp32) */
+    int32_t k_lo_off;
+    int32_t p_split;       /* 1 (with the q / k split): the probabilities enter O^T = V^T P^T as p_hi + p_lo (both 16-bit, from the fp32 value in
+                              registers): one more pass of the PV MFMAs, no memory traffic */
 } omgsr_attn_args;
 /* Process-wide (default 0): the online softmax moves its running maximum only when a row's maximum grows by more than 2^t in
  * the scaled base-2 domain (probabilities then reach 2^t instead of 1; the result is the same quotient). 0 = exact running

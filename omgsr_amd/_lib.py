@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 from .build import lib_path
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class OmgsrError(RuntimeError):
@@ -58,7 +58,7 @@ class AttnArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
         ("q_ld", C.c_int64), ("k_ld", C.c_int64), ("vt_ld", C.c_int64), ("o_ld", C.c_int64),
         ("q_bstride", C.c_int64), ("k_bstride", C.c_int64), ("vt_bstride", C.c_int64), ("o_bstride", C.c_int64),
-        ("scale", C.c_float), ("o_lo_off", C.c_int32), ("o_mx", C.c_int32), ("reserved0", C.c_int32),
+        ("scale", C.c_float), ("o_lo_off", C.c_int32), ("o_mx", C.c_int32), ("q_lo_off", C.c_int32), ("k_lo_off", C.c_int32), ("p_split", C.c_int32),
     ]
 
 

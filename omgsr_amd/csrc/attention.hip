@@ -47,12 +47,17 @@ OMGSR_DEVINL void glds16_sv(const unsigned voff, const void* sbase, const unsign
         : "memory");
 }
 
-template <typename T, int D, bool DMA>
+// SPLIT (round 6, D = 64; omgsr_attn_args.q_lo_off / k_lo_off / p_split): q, k and the probabilities as two-term splits of 16-bit values - the
+// range-fallback tier's bf16 operands carry 8-bit mantissas, and the UNet's 32 attention calls per tile with single bf16 q / k / P cost that tier
+// the north-star tolerance (q 28, k 29, P 26 of its 132 units of squared error). S^T = K_hi Q_hi^T + K_lo Q_hi^T + K_hi Q_lo^T (the
+// K_lo tile rides through LDS behind K_hi: same pieces, same swizzle, same fragment offsets), O^T += V^T P_hi^T + V^T P_lo^T.
+template <typename T, int D, bool DMA, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, const int ntiles, const float defer, const int qtiles, const int xcd_order) {
     constexpr int KP = DMA ? 2 * D : 2 * D + 16;
     constexpr int VP = DMA ? 128 : 136;
     constexpr int K_BYTES = 64 * KP, V_BYTES = D * VP;
-    constexpr int STAGE = K_BYTES + V_BYTES;
+    constexpr int KT_BYTES = SPLIT ? 2 * K_BYTES : K_BYTES;          // [K_hi | K_lo] of a tile
+    constexpr int STAGE = KT_BYTES + V_BYTES;
     constexpr int CPR = D / 8;               // 16-byte chunks per K row
     constexpr int NKC = 64 * CPR / 256;      // K chunks per thread
     constexpr int NVC = D * 8 / 256;         // V^T chunks per thread
@@ -74,12 +79,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     const T* __restrict__ vp = (const T*)p.vt + (int64_t)b * p.vt_bstride + (int64_t)h * D * p.vt_ld;
 
     // Q^T operand fragments live in registers for the whole sweep
-    x8_t<T> qf[NKS];
+    x8_t<T> qf[NKS], qfl[SPLIT ? NKS : 1];
     {
         int qrow = q0 + l31; if (qrow > p.Lq - 1) qrow = p.Lq - 1;
         const T* qr = qp + (int64_t)qrow * p.q_ld + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const x8_t<T>*>(qr + 16 * ks);
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) qfl[ks] = *reinterpret_cast<const x8_t<T>*>(qr + p.q_lo_off + 16 * ks);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qfl[ks]));
+        }
         // retire the loads HERE: hipcc otherwise places their counted vmcnt waits at the first use inside the key loop, where
         // they also wait for the LDS-DMA of the next tile (vmcnt(7) ... vmcnt(0) across the first eight MFMAs: no prefetch left)
 #pragma unroll
@@ -99,24 +110,25 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     }
     typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
     const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;
-    // piece i of the wave's 2 * NPW per tile: even = K piece i / 2, odd = V^T piece i / 2
+    // piece i of the wave's NT * NPW per tile (NT = 2, or 3 with the K_lo tile): type i % NT = K (hi) / V^T / K_lo, index i / NT
+    constexpr int NT = SPLIT ? 3 : 2;
     auto issue_piece = [&](const int kt, const int buf, const int i) {
-        const int j = i >> 1;
+        const int j = i / NT, ty = i % NT;
         const unsigned dst = lds_base + buf * STAGE + wave * 1024 + j * 4096;
-        if ((i & 1) == 0) {
-            const unsigned char* kb = reinterpret_cast<const unsigned char*>(kp + (int64_t)kt * 64 * p.k_ld);
-            glds16_sv(kvoff, kb + (int64_t)j * (4 * RPPK) * p.k_ld * 2, __builtin_amdgcn_readfirstlane(dst));
-        } else {
+        if (ty == 1) {
             const unsigned char* vb = reinterpret_cast<const unsigned char*>(vp + (int64_t)kt * 64);
-            glds16_sv(vvoff, vb + (int64_t)j * 32 * p.vt_ld * 2, __builtin_amdgcn_readfirstlane(dst + K_BYTES));
+            glds16_sv(vvoff, vb + (int64_t)j * 32 * p.vt_ld * 2, __builtin_amdgcn_readfirstlane(dst + KT_BYTES));
+        } else {
+            const unsigned char* kb = reinterpret_cast<const unsigned char*>(kp + (ty == 2 ? p.k_lo_off : 0) + (int64_t)kt * 64 * p.k_ld);
+            glds16_sv(kvoff, kb + (int64_t)j * (4 * RPPK) * p.k_ld * 2, __builtin_amdgcn_readfirstlane(dst + (ty == 2 ? K_BYTES : 0)));
         }
     };
     auto issue_tile = [&](const int kt, const int buf) {
 #pragma unroll
-        for (int i = 0; i < 2 * NPW; ++i) issue_piece(kt, buf, i);
+        for (int i = 0; i < NT * NPW; ++i) issue_piece(kt, buf, i);
     };
 
-    u32x4_t kreg[DMA ? 1 : NKC], vreg[DMA ? 1 : NVC];
+    u32x4_t kreg[DMA ? 1 : NKC], vreg[DMA ? 1 : NVC], kreg_lo[(!DMA && SPLIT) ? NKC : 1];
     auto load_tile = [&](int kt) {
         const int key_base = kt * 64;
 #pragma unroll
@@ -127,6 +139,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (key < p.Lk) v = *reinterpret_cast<const u32x4_t*>(kp + (int64_t)key * p.k_ld + kc * 8);
             kreg[i] = v;
+            if constexpr (SPLIT) {
+                u32x4_t vl = {0u, 0u, 0u, 0u};
+                if (key < p.Lk) vl = *reinterpret_cast<const u32x4_t*>(kp + p.k_lo_off + (int64_t)key * p.k_ld + kc * 8);
+                kreg_lo[i] = vl;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NVC; ++i) {
@@ -150,11 +167,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     };
     auto write_tile = [&](int buf) {
         unsigned char* Ks = lds + buf * STAGE;
-        unsigned char* Vs = Ks + K_BYTES;
+        unsigned char* Vs = Ks + KT_BYTES;
 #pragma unroll
         for (int i = 0; i < NKC; ++i) {
             const int c = t + 256 * i;
             *reinterpret_cast<u32x4_t*>(Ks + (c / CPR) * KP + (c % CPR) * 16) = kreg[i];
+            if constexpr (SPLIT) *reinterpret_cast<u32x4_t*>(Ks + K_BYTES + (c / CPR) * KP + (c % CPR) * 16) = kreg_lo[i];
         }
 #pragma unroll
         for (int i = 0; i < NVC; ++i) {
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
             if (kt + 1 < ntiles) load_tile(kt + 1);
         }
         const unsigned char* Ks = lds + buf * STAGE;
-        const unsigned char* Vs = Ks + K_BYTES;
+        const unsigned char* Vs = Ks + KT_BYTES;
 
         // S^T = K Q^T : two 32-key blocks
         f32x16_t s[2];
@@ -214,17 +232,33 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
         if constexpr (DMA) {
             // every K fragment of the tile is requested before the first MFMA (left to itself hipcc reuses ONE fragment
             // register: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, 32 exposed LDS latencies per tile); sched_barriers pin the phases
-            x8_t<T> kf[2][NKS];
+            x8_t<T> kf[2][NKS], kfl[SPLIT ? 2 : 1][SPLIT ? NKS : 1];
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) kf[sb][ks] = *reinterpret_cast<const x8_t<T>*>(Ks + 32 * sb * KP + koff[ks]);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) kfl[sb][ks] = *reinterpret_cast<const x8_t<T>*>(Ks + K_BYTES + 32 * sb * KP + koff[ks]);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[sb][r] = 0.0f;
             __builtin_amdgcn_s_setprio(1);
+            if constexpr (SPLIT) {          // the two correction products first (small terms into the empty accumulator), then the main product
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) s[sb] = mfma32(kfl[sb][ks], qf[ks], s[sb]);
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) s[sb] = mfma32(kf[sb][ks], qfl[ks], s[sb]);
+            }
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
@@ -242,6 +276,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[sb][r] = 0.0f;
                 const unsigned char* kr = Ks + (32 * sb + l31) * KP + half * 16;
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        const x8_t<T> kl = *reinterpret_cast<const x8_t<T>*>(kr + K_BYTES + ks * 32);
+                        s[sb] = mfma32(kl, qf[ks], s[sb]);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        const x8_t<T> kf = *reinterpret_cast<const x8_t<T>*>(kr + ks * 32);
+                        s[sb] = mfma32(kf, qfl[ks], s[sb]);
+                    }
+                }
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
                     const x8_t<T> kf = *reinterpret_cast<const x8_t<T>*>(kr + ks * 32);
@@ -292,18 +338,37 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
         l_run += rs;
 
         // P^T operand: score registers converted in place (key permutation, see header)
-        x8_t<T> pf[2][2];
+        x8_t<T> pf[2][2], pfl[SPLIT ? 2 : 1][SPLIT ? 2 : 1];
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[sb][u][j] = (T)s[sb][8 * u + j];
+        const bool psplit = SPLIT && p.p_split;
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pfl[sb][u][j] = (T)(s[sb][8 * u + j] - (float)pf[sb][u][j]);
+        }
 
         // O^T += V^T P^T
         if constexpr (DMA) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+            if constexpr (SPLIT) {
+                if (psplit) {
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) o[db] = mfma32(vf[db][2 * sb + u], pfl[sb][u], o[db]);
+                }
+            }
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -323,6 +388,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
                         const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(a);
                         const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(a + 16);
                         const u32x4_t both = {lo[0], lo[1], hi[0], hi[1]};
+                        if constexpr (SPLIT) {
+                            if (psplit) o[db] = mfma32(*reinterpret_cast<const x8_t<T>*>(&both), pfl[sb][u], o[db]);
+                        }
                         o[db] = mfma32(*reinterpret_cast<const x8_t<T>*>(&both), pf[sb][u], o[db]);
                     }
             }
@@ -373,14 +441,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
 
 float g_defer_max = 0.0f;
 
-template <int D, bool DMA>
+template <int D, bool DMA, bool SPLIT = false>
 int launch_attn(const omgsr_attn_args& a, hipStream_t st) {
-    constexpr int LDS = DMA ? 2 * (64 * 2 * D + D * 128) : 2 * (64 * (2 * D + 16) + D * 136);
+    constexpr int KT = SPLIT ? 2 : 1;
+    constexpr int LDS = DMA ? 2 * (KT * 64 * 2 * D + D * 128) : 2 * (KT * 64 * (2 * D + 16) + D * 136);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<bf16_t, D, DMA>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<bf16_t, D, DMA, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<f16_t, D, DMA>),
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<f16_t, D, DMA, SPLIT>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -391,7 +460,7 @@ int launch_attn(const omgsr_attn_args& a, hipStream_t st) {
     if (blocks > 0x7fffffffll) return OMGSR_E_SHAPE;
     static const char* xo = getenv("OMGSR_ATTN_XCD");            // A/B runs: "0" = natural block order (every XCD reads every head's K / V^T)
     const int xcd_order = !(xo && xo[0] == '0');
-    OMGSR_DISPATCH_T(hipLaunchKernelGGL((attn_kernel<T, D, DMA>), dim3((unsigned)blocks), dim3(256), LDS, st, a, ntiles, g_defer_max, qtiles, xcd_order));
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL((attn_kernel<T, D, DMA, SPLIT>), dim3((unsigned)blocks), dim3(256), LDS, st, a, ntiles, g_defer_max, qtiles, xcd_order));
     return (int)hipGetLastError();
 }
 
@@ -411,13 +480,18 @@ extern "C" int omgsr_attention(const omgsr_attn_args* ap, void* stream) {
     if (a.o_lo_off < 0 || (a.o_lo_off && ((a.o_lo_off & 3) || a.o_lo_off < a.H * a.D || a.o_ld < (int64_t)a.o_lo_off + a.H * a.D))) return OMGSR_E_SHAPE;
     // MX output: the whole row belongs to this call (heads at column 0, o_ld = 2 H D slots), fp16 compute type
     if (a.o_mx && (a.o_lo_off || a.o_ld != 2ll * a.H * a.D || ((a.H * a.D) & 63) || omgsr::compute_dtype() != 1)) return OMGSR_E_SHAPE;
+    // two-term split q / k (ABI v17): both or neither, 16-byte aligned low halves, head_dim 64 (the UNet's; FLUX's RMS-normalised q / k do not need it)
+    const bool split = a.q_lo_off != 0 || a.k_lo_off != 0;
+    if (split && (a.q_lo_off <= 0 || a.k_lo_off <= 0 || (a.q_lo_off & 7) || (a.k_lo_off & 7) || a.D != 64)) return OMGSR_E_SHAPE;
+    if (a.p_split && !split) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const double flops = 4.0 * (double)a.B * a.H * (double)a.Lq * a.Lk * a.D;
-    const double bytes = 2.0 * (double)a.B * a.H * a.D * (2.0 * a.Lq + 2.0 * a.Lk);
+    const double flops = 4.0 * (double)a.B * a.H * (double)a.Lq * a.Lk * a.D;         // (work handed: the split form's extra passes are overhead)
+    const double bytes = 2.0 * (double)a.B * a.H * a.D * ((split ? 3.0 : 2.0) * a.Lq + (split ? 3.0 : 2.0) * a.Lk);
     omgsr::TimingScope ts(OMGSR_TK_ATTN, flops, bytes, st, (long long)a.B * a.H * a.Lq, a.Lk, a.D);
     // LDS-DMA staging needs whole 64-key tiles (a DMA piece cannot be masked) and 32-bit source offsets
     static const char* var = getenv("OMGSR_ATTN_VARIANT");      // A/B runs: "0" = register-staged K / V^T tiles everywhere
     const bool dma = (a.Lk & 63) == 0 && a.k_ld < (1 << 22) && a.vt_ld < (1 << 22) && !(var && var[0] == '0');
+    if (split) return dma ? launch_attn<64, true, true>(a, st) : launch_attn<64, false, true>(a, st);
     if (a.D == 64) return dma ? launch_attn<64, true>(a, st) : launch_attn<64, false>(a, st);
     if (a.D == 128) return dma ? launch_attn<128, true>(a, st) : launch_attn<128, false>(a, st);
     return OMGSR_E_SHAPE;

@@ -197,7 +197,7 @@ inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)((tot
 
 }  // namespace
 
-extern "C" int omgsr_abi_version(void) { return 16; }
+extern "C" int omgsr_abi_version(void) { return 17; }
 
 extern "C" int omgsr_set_compute_dtype(int dtype) {
     if (dtype != OMGSR_DT_BF16 && dtype != OMGSR_DT_F16) return OMGSR_E_BADARG;

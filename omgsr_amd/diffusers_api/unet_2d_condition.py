@@ -94,29 +94,36 @@ class Attention(nn.Module):
     def self_nhwc(self, xn: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         """xn: LayerNorm'd operand tokens [B, L, C*split]; returns residual + to_out(attn) on the stream."""
         B, L, _ = xn.shape
-        qk = ops.linear(xn, self._qk_packed(), out_dtype=ops.OUT_BF16)  # [B, L, 2*inner]
+        sp = ops.attn_split() and self.dim_head == 64
+        # [B, L, 2*inner]; range-fallback tier: [q_hi | k_hi | q_lo | k_lo] (two-term split from the projection's epilogue, ops.attn_split)
+        qk = ops.linear(xn, self._qk_packed(), out_dtype=ops.OUT_BF16, out_split=2 if sp else 1)
         vt = ops.linear_t(xn, self.to_v.packed(), L)                    # [B, inner, L8]
         o = ops.attention(qk, qk, vt, self.heads, self.dim_head, self.scale, q_col=0, k_col=self.inner, Lk=L,
-                          out_split=self.to_out[0].in_split())
+                          out_split=self.to_out[0].in_split(), q_lo_col=2 * self.inner if sp else None, k_lo_col=3 * self.inner if sp else None)
         return self.to_out[0].nhwc(o, residual=residual)
 
     def context(self, ehs: torch.Tensor):
         """K and V^T of a fixed prompt: computed once per prompt TENSOR (the cache holds a reference to it and compares
         identity + version; an address is not an identity, the allocator reuses addresses)."""
+        sp = ops.attn_split() and self.dim_head == 64
+
         def build():
             e = ehs.float().contiguous() if ops.precise() else ehs.to(ops.act_dtype()).contiguous()
-            kk = ops.linear(e, self.to_k.packed(), out_dtype=ops.OUT_BF16)      # [Bc, 77, inner]
+            kk = ops.linear(e, self.to_k.packed(), out_dtype=ops.OUT_BF16, out_split=2 if sp else 1)      # [Bc, 77, inner] ([k_hi | k_lo] when split)
             vt = ops.linear_t(e, self.to_v.packed(), e.shape[1])                # [Bc, inner, 80]
             return kk, vt, e.shape[1]
         return self._ctx_cache.get((ehs,), self._ctx_key(), build)
 
     def _ctx_key(self) -> tuple:
-        return _key(self.to_k.weight, self.to_v.weight, self.to_k.in_split(), self.to_k.in_wsplit(), self.to_v.in_wsplit())
+        return _key(self.to_k.weight, self.to_v.weight, self.to_k.in_split(), self.to_k.in_wsplit(), self.to_v.in_wsplit(),
+                    bool(ops.attn_split() and self.dim_head == 64))
 
     def cross_nhwc(self, xn: torch.Tensor, ehs: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
         kk, vt, Lk = self.context(ehs)
-        q = self.to_q.nhwc(xn, out_dtype=ops.OUT_BF16)
-        o = ops.attention(q, kk, vt, self.heads, self.dim_head, self.scale, Lk=Lk, out_split=self.to_out[0].in_split())
+        sp = kk.shape[-1] == 2 * self.inner
+        q = self.to_q.nhwc(xn, out_dtype=ops.OUT_BF16, out_split=2 if sp else 1)
+        o = ops.attention(q, kk, vt, self.heads, self.dim_head, self.scale, Lk=Lk, out_split=self.to_out[0].in_split(),
+                          q_lo_col=self.inner if sp else None, k_lo_col=self.inner if sp else None)
         return self.to_out[0].nhwc(o, residual=residual)
 
 

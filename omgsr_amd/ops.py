@@ -15,6 +15,7 @@ Every function dispatches on the dtype of the tensors it is handed.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -52,6 +53,16 @@ def stream_dtype() -> torch.dtype:
 
 def precise() -> bool:
     return _PRECISE
+
+
+def attn_split() -> bool:
+    """The UNet's attention takes q, k (from their projections' epilogues) and P (in registers) as two-term splits: in the range-fallback tier
+    (fp32 stream, bf16 operands: 8-bit mantissas), where single q / k / P cost the north-star tolerance on OMGSR-S 256->1024 (1.15e-3).
+    OMGSR_ATTN_SPLIT=0 | 1 forces it off / on in the accurate tiers (A/B runs)."""
+    env = os.environ.get("OMGSR_ATTN_SPLIT")
+    if env is not None and _PRECISE:
+        return env != "0"
+    return bool(_PRECISE and _ACT == torch.bfloat16)
 
 
 def mode_key() -> tuple:
@@ -417,8 +428,16 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
         raise ValueError("split / w_split must be 1 or 2")
     if w_split == 2 and bool(torch.equal(w.to(act_dtype()).float(), w)):
         # every value is exact in the compute type (an fp16 / bf16 checkpoint's layers that no LoRA merge touched): w_lo == 0, and a
-        # segment of zeros adds exactly 0 to the accumulator - drop it (same bits, one K segment less)
-        w_split = 1
+        # segment of zeros adds exactly 0 to the accumulator - drop it (same bits, one K segment less). The phase form of an up-sampling conv
+        # carries SUMS of 2 - 4 taps (_phase_kernels), which are not representable just because the taps are (round 6: with bf16-representable
+        # weights the range-fallback tier rounded those sums to 8 bits and measured 3.4e-3 where full-mantissa weights measure 1.1e-3): the
+        # segment goes only if the summed kernels are exact too - one w_split serves both packings, their K layouts must agree
+        ph_exact = True
+        if upsample_phases and R == 3 and S == 3:
+            ph0 = _phase_kernels(w)
+            ph_exact = bool(torch.equal(ph0.to(act_dtype()).float(), ph0))
+        if ph_exact:
+            w_split = 1
     in_ld = cin8 * split
     w_raw = w
     w = _segments(w, split, w_split)
@@ -1064,8 +1083,11 @@ def layer_norm(x: torch.Tensor, a: Optional[torch.Tensor], b: Optional[torch.Ten
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, head_dim: int, scale: float,
               *, q_col: int = 0, k_col: int = 0, Lk: Optional[int] = None, out: Optional[torch.Tensor] = None,
-              o_col: int = 0, out_split: int = 1, o_lo_col: Optional[int] = None) -> torch.Tensor:
+              o_col: int = 0, out_split: int = 1, o_lo_col: Optional[int] = None, q_lo_col: Optional[int] = None,
+              k_lo_col: Optional[int] = None, p_split: bool = True) -> torch.Tensor:
     """q [B, Lq, *] (heads at columns q_col + h*D), k [Bk, Lk, *], vt [Bk, heads*D, ld] -> o [B, Lq, heads*D]
+    q_lo_col / k_lo_col (both or neither, head_dim 64): q and k are two-term splits whose low halves start at those columns of the same rows
+    (a projection written with out_split = 2); the scores then run three MFMA passes and, with p_split, the probabilities two (attn_split()).
     (an operand for the output projection; out_split 2: [B, Lq, 2*heads*D] as the two-term split; 3: the same bytes per row in the
     mixed-precision form OMGSR_EL_MX, for an output projection that runs as an MX GEMM).
     Bk == 1 broadcasts one K/V over the batch (constant cross-attention context)."""
@@ -1091,6 +1113,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, he
     a.scale = scale
     a.o_lo_off = 0 if out_split != 2 else ((o_lo_col - o_col) if o_lo_col is not None else inner)
     a.o_mx = int(out_split == 3)
+    if (q_lo_col is None) != (k_lo_col is None):
+        raise ValueError("attention: q_lo_col and k_lo_col come together")
+    a.q_lo_off = 0 if q_lo_col is None else q_lo_col - q_col
+    a.k_lo_off = 0 if k_lo_col is None else k_lo_col - k_col
+    a.p_split = int(q_lo_col is not None and p_split)
     if out_split == 3 and o_col != 0:
         raise ValueError("attention: an MX output owns its whole row (o_col must be 0)")
     check(_lib.load().omgsr_attention(C.byref(a), _stream()), "omgsr_attention")

@@ -388,6 +388,8 @@ class RangeFallback:
         # accurate pipeline B would otherwise run its fp16-only policy (MX layers, q / k splits) under bf16 operands and fail every call
         self.weight_dtype = weight_dtype
         self.mx_saturation_count = 0    # calls in which a mixed-precision operand carried a value beyond +-448 (its fp8 correction fields saturated)
+        self.mx_demoted = False         # round 6: after such a call the fixed-scale fp8 layers run fp16 correction segments (demote_mx), sticky
+        self._mx_saved = None
         self.count = 0
         self.sticky = False
         self._saved = None
@@ -404,6 +406,27 @@ class RangeFallback:
         self.sticky = True
         if self.on_mode_change:
             self.on_mode_change()
+
+    def demote_mx(self) -> int:
+        """the fp8 correction fields of the mixed-precision form (op_split 3: UNET_MX_LIN, the GEMM-shaped MX convs, the UNet's
+        up-samplers) use FIXED scales and clamp at +-448, and the layers that carry them read un-normalised activations (GEGLU hidden states,
+        attention outputs, raw residual streams) that a trained checkpoint drives into the hundreds or thousands. When the saturation bit fires,
+        those layers fall back to fp16 correction segments (op_split 2 with the weight split kept: three K segments, no range limit below fp16's
+        own, which the range guard covers) - per layer FORM, for the whole pipeline, sticky like the range fallback. The fp6 layers (op_split 4)
+        carry a scale per 32-channel block and never saturate. Returns how many layers moved."""
+        moved = []
+        for model in self.models:
+            for m in model.modules():
+                if isinstance(m, (Conv2d, Linear)) and m.op_split == 3:
+                    m.op_split = 2
+                    moved.append(m)
+        if moved:
+            self._mx_saved = (self._mx_saved or []) + moved
+            self.mx_demoted = True
+            _touch()
+            if self.on_mode_change:
+                self.on_mode_change()
+        return len(moved)
 
     def reassert(self) -> None:
         """Called at the top of every forward(): another pipeline may have switched the process-wide tier in between."""
@@ -426,6 +449,11 @@ class RangeFallback:
                     m.op_split, m.w_split, m.out_inner16 = a, w, i16
             self._saved = None
             _touch()
+        if self._mx_saved is not None:           # (after the rows above: a range fallback entered AFTER a demotion saved the demoted marks)
+            for m in self._mx_saved:
+                m.op_split = 3
+            _touch()
+        self._mx_saved, self.mx_demoted = None, False
         if self.sticky:
             ops.set_compute_dtype(torch.float32)
         self.sticky = False
@@ -440,15 +468,25 @@ class RangeFallback:
         out = run()
         torch.cuda.synchronize()
         overflowed = (not self.sticky) and ops.precise() and ops.overflow_seen()          # (reads the guard word: also latches the MX diagnostic bit)
-        if ops.precise() and ops.mx_saturation_seen():
+        saturated = ops.precise() and ops.mx_saturation_seen()
+        if saturated:
             # not an error - the fp16 main term of that element is exact, its two correction terms were clamped, so it carried
             # single-rounding accuracy. Seeded weights never get here; a checkpoint whose feed-forward / attention outputs reach the hundreds
-            # does, and then the accuracy evidence of this tier (all from O(1) activations) does not cover it: say so once.
+            # does, and then the accuracy evidence of this tier (all from O(1) activations) does not cover it: say so once - and (round 6)
+            # stop using the fixed-scale form: demote_mx() + one recompute, sticky (OMGSR_MX_SAT_FALLBACK=0: warn only, round 5's behaviour)
             self.mx_saturation_count += 1
+            fallback = _os.environ.get("OMGSR_MX_SAT_FALLBACK", "1") != "0" and not overflowed and not self.sticky
             if self.mx_saturation_count == 1:
                 warnings.warn(f"{what} accurate tier: a mixed-precision (fp16 + fp8 correction) operand held values beyond +-448; their correction "
-                              f"terms saturated (single-rounding accuracy for those elements). OMGSR_MX_LINEAR=0 / OMGSR_MX=0 run those layers "
-                              f"with fp16 correction segments instead")
+                              f"terms saturated (single-rounding accuracy for those elements). " +
+                              ("This call is recomputed with fp16 correction segments on those layers and the pipeline stays in that form "
+                               "(pipe.range_fallback.reset() returns to the fp8 form)" if fallback else
+                               "OMGSR_MX_LINEAR=0 / OMGSR_MX=0 run those layers with fp16 correction segments instead"))
+            if fallback and self.demote_mx():
+                out = run()
+                torch.cuda.synchronize()
+                overflowed = ops.overflow_seen()
+                ops.mx_saturation_seen()                 # (the fp6 layers never set it; the demoted ones cannot)
         if overflowed:
             self.count += 1
             warnings.warn(f"{what} accurate tier: an fp16 MFMA operand exceeded 65504; this call is recomputed with bf16 operands and "

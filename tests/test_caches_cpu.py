@@ -1,5 +1,6 @@
 """Host-side caches that must not go stale: the Flux modulation-table dependency list and the pipeline's cached
 timestep / guidance tensors. CPU only: no kernel is called."""
+import pytest
 import torch
 
 
@@ -104,3 +105,47 @@ def test_graph_cache_drops_entries_captured_under_an_older_cache_epoch():
     p0 = precision.policy_epoch()
     precision.set_operand_split(torch.nn.Sequential(onn.Conv2d(32, 32, 3)), [r"."])
     assert precision.policy_epoch() > p0
+
+
+def test_mx_saturation_demotes_the_fixed_scale_layers_and_reset_restores_them(monkeypatch):
+    """when the MX saturation bit fires, the layers in the fixed-scale fp8 form (op_split 3) fall back to fp16 correction
+    segments (op_split 2, weight split kept), the call is recomputed once, the pipeline stays in that form; fp6 layers (op_split 4: a scale per
+    block) are untouched; reset() returns to the fp8 form - also when a range fallback was entered after the demotion."""
+    from omgsr_amd import nn as onn, ops, precision
+    from omgsr_amd.nn import Conv2d, Linear
+    state = dict(act=torch.float16, precise=True)
+    monkeypatch.setattr(ops, "set_compute_dtype", lambda dt, operand_dtype=None: state.update(
+        act=torch.bfloat16 if dt == torch.bfloat16 else (operand_dtype or torch.float16), precise=dt == torch.float32))
+    monkeypatch.setattr(ops, "precise", lambda: state["precise"])
+    monkeypatch.setattr(ops, "act_dtype", lambda: state["act"])
+    monkeypatch.setattr(ops, "overflow_seen", lambda reset=True: False)
+    sat = [True, False, False]
+    monkeypatch.setattr(ops, "mx_saturation_seen", lambda reset=True: sat.pop(0) if sat else False)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    net = torch.nn.Sequential(Linear(64, 64), Conv2d(64, 128, 3, padding=1), Conv2d(64, 128, 1), Linear(64, 64))
+    for m, sp in zip(net, (3, 4, 3, 1)):
+        m.op_split, m.w_split = sp, (2 if sp > 1 else 1)
+    rf = precision.RangeFallback(net, weight_dtype=torch.float32)
+    dropped = []
+    rf.on_mode_change = lambda: dropped.append(1)
+    p0, calls = precision.policy_epoch(), []
+    with pytest.warns(UserWarning, match="recomputed with fp16 correction segments"):
+        rf.run(lambda: calls.append([m.op_split for m in net]), "T")
+    assert calls == [[3, 4, 3, 1], [2, 4, 2, 1]]                     # one recompute, in the demoted form
+    assert rf.mx_demoted and rf.mx_saturation_count == 1 and not rf.sticky and rf.count == 0
+    assert precision.policy_epoch() > p0 and dropped                  # packed weights / captured graphs of the fp8 form are not reused
+    assert [m.w_split for m in net] == [2, 2, 2, 1]
+    rf.run(lambda: calls.append([m.op_split for m in net]), "T")     # sticky: no second recompute
+    assert len(calls) == 3 and calls[-1] == [2, 4, 2, 1]
+    rf.enter()                                                        # a later fp16 overflow: every layer split, bf16 operands
+    assert [m.op_split for m in net] == [2, 2, 2, 2] and rf.sticky
+    rf.reset()
+    assert [m.op_split for m in net] == [3, 4, 3, 1] and not rf.sticky and not rf.mx_demoted
+    # OMGSR_MX_SAT_FALLBACK=0: round 5's behaviour (diagnostic only)
+    monkeypatch.setenv("OMGSR_MX_SAT_FALLBACK", "0")
+    sat[:] = [True]
+    rf2 = precision.RangeFallback(net, weight_dtype=torch.float32)
+    n = []
+    with pytest.warns(UserWarning, match="OMGSR_MX_LINEAR=0"):
+        rf2.run(lambda: n.append(1), "T")
+    assert len(n) == 1 and not rf2.mx_demoted and [m.op_split for m in net] == [3, 4, 3, 1]

@@ -499,6 +499,45 @@ def test_attention_split_output():
     assert e2 < e1 and e2 < 3e-4        # P is a 16-bit operand either way; the split removes the output rounding
 
 
+@pytest.mark.parametrize("Lq,Lk,dt", [(1024, 1024, torch.bfloat16), (300, 77, torch.bfloat16), (1000, 1024, torch.float16), (128, 200, torch.bfloat16)],
+                         ids=["self-bf16-dma", "cross-bf16-ragged", "self-fp16-dma", "ragged-keys-bf16"])
+def test_attention_two_term_split_q_k_p(Lq, Lk, dt):
+    """omgsr_attn_args.q_lo_off / k_lo_off / p_split (ABI v17): q, k and the probabilities as two-term splits inside the flash
+    kernel - S^T = K_hi Q_hi^T + K_lo Q_hi^T + K_hi Q_lo^T, O^T += V^T (P_hi + P_lo)^T. Against the fp64 attention of the UNsplit q, k (V rounded
+    once: it stays a single operand) the split form is limited by V and the fp32 accumulators only; the single form by the 8-bit (bf16) / 11-bit
+    (fp16) mantissas of q, k and P. LDS-DMA path (Lk % 64 == 0) and the register-staged path (ragged Lk: cross-attention)."""
+    from omgsr_amd import ops
+    B, H, D = 2, 5, 64
+    inner = H * D
+    ops.set_compute_dtype(torch.float32, operand_dtype=dt)
+    q = torch.randn(B, Lq, inner, generator=_g(90)) * 1.5
+    k = torch.randn(B, Lk, inner, generator=_g(91)) * 1.5
+    v = torch.randn(B, Lk, inner, generator=_g(92)).to(dt)
+    L8 = -(-Lk // 8) * 8
+    vt = torch.zeros(B, inner, L8, dtype=dt)
+    vt[:, :, :Lk] = v.transpose(1, 2)
+    sp = lambda t: torch.cat([t.to(dt), (t - t.to(dt).float()).to(dt)], -1)        # noqa: E731  [hi | lo]
+    qq, kk = sp(q).to(DEV), sp(k).to(DEV)
+    qh, kh, vh = (t.double().reshape(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * D ** -0.5, -1) @ vh).transpose(1, 2).reshape(B, Lq, inner)
+    both = lambda o: o[..., :inner].float() + o[..., inner:].float()                # noqa: E731
+    single = ops.attention(qq[..., :inner].contiguous(), kk[..., :inner].contiguous(), vt.to(DEV), H, D, D ** -0.5, Lk=Lk, out_split=2)
+    split = ops.attention(qq, kk, vt.to(DEV), H, D, D ** -0.5, Lk=Lk, out_split=2, q_lo_col=inner, k_lo_col=inner)
+    qk_only = ops.attention(qq, kk, vt.to(DEV), H, D, D ** -0.5, Lk=Lk, out_split=2, q_lo_col=inner, k_lo_col=inner, p_split=False)
+    e1, e2, e3 = _rel(both(single), ref), _rel(both(split), ref), _rel(both(qk_only), ref)
+    print(f"attention {Lq} x {Lk} {dt}: single {e1:.2e}  q/k split {e3:.2e}  q/k/P split {e2:.2e}")
+    bound = 3e-5 if dt == torch.bfloat16 else 3e-6
+    assert e2 < bound and e2 < e3 < e1 and e1 > 20 * e2
+    assert torch.equal(ops.attention(qq, kk, vt.to(DEV), H, D, D ** -0.5, Lk=Lk, out_split=2, q_lo_col=inner, k_lo_col=inner), split)
+    # a fused [q | k] projection buffer: [q_hi | k_hi | q_lo | k_lo] (the UNet's self-attention in the range-fallback tier)
+    if Lq == Lk:
+        fused = torch.cat([qq[..., :inner], kk[..., :inner], qq[..., inner:], kk[..., inner:]], -1).contiguous()
+        got = ops.attention(fused, fused, vt.to(DEV), H, D, D ** -0.5, q_col=0, k_col=inner, Lk=Lk, out_split=2, q_lo_col=2 * inner, k_lo_col=3 * inner)
+        assert torch.equal(got, split)
+    with pytest.raises(Exception):
+        ops.attention(qq, kk, vt.to(DEV), H, D, D ** -0.5, Lk=Lk, q_lo_col=inner)            # one low half without the other
+
+
 def test_stream_plumbing_fp32():
     from omgsr_amd import ops
     x = torch.randn(2, 5, 20, 24, generator=_g(17))
