@@ -266,6 +266,10 @@ int omgsr_layernorm(const void* x, void* y, const float* a, const float* b, int6
  * (OMGSR_EL_SPLIT); x f32 [rows][C], C % 8 == 0. (Inputs of convs that no norm precedes: up / down-sampling convs,
  * 1x1 shortcuts, conv_in, proj_out, post_quant_conv.) */
 int omgsr_to_operand(const float* x, void* y, int64_t rows, int32_t C, int32_t y_el, uint32_t* overflow_flag, void* stream);
+/* ABI v17: V of an attention as the TRANSPOSED two-term split (omgsr_attn_args.vt_lo_off): x f32 [B][L][C] (a projection's stream output) ->
+ * y 16-bit [B][2C][ld], y[b][c][l] = round(x[b][l][c]), y[b][C + c][l] = round(x - hi); ld >= L, ld % 8 == 0, columns >= L are left untouched
+ * (the caller zero-fills). Replaces v.transpose(1, 2) in fp32 under F.scaled_dot_product_attention for the range-fallback tier. */
+int omgsr_transpose_split(const float* x, void* y, int32_t B, int32_t L, int32_t C, int64_t ld, void* stream);
 
 /*
  * K7/K8 — fused softmax(Q K^T * scale) V on MFMA (replaces F.scaled_dot_product_attention).
@@ -293,6 +297,10 @@ typedef struct omgsr_attn_args {
     int32_t k_lo_off;
     int32_t p_split;       /* 1 (with the q / k split): the probabilities enter O^T = V^T P^T as p_hi + p_lo (both 16-bit, from the fp32 value in
                               registers): one more pass of the PV MFMAs, no memory traffic */
+    int32_t reserved1;
+    int64_t vt_lo_off;     /* > 0 (with the q / k split): V^T is a two-term split too - the low halves of [H*D][vt_ld] start vt_lo_off ELEMENTS after
+                              vt (omgsr_transpose_split writes [B][2 H D][ld]: vt_lo_off = H * D * vt_ld, vt_bstride = 2 H D vt_ld); O^T gains the
+                              V_lo^T P_hi^T pass */
 } omgsr_attn_args;
 /* Process-wide (default 0): the online softmax moves its running maximum only when a row's maximum grows by more than 2^t in
  * the scaled base-2 domain (probabilities then reach 2^t instead of 1; the result is the same quotient). 0 = exact running

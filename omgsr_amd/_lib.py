@@ -59,6 +59,7 @@ class AttnArgs(C.Structure):
         ("q_ld", C.c_int64), ("k_ld", C.c_int64), ("vt_ld", C.c_int64), ("o_ld", C.c_int64),
         ("q_bstride", C.c_int64), ("k_bstride", C.c_int64), ("vt_bstride", C.c_int64), ("o_bstride", C.c_int64),
         ("scale", C.c_float), ("o_lo_off", C.c_int32), ("o_mx", C.c_int32), ("q_lo_off", C.c_int32), ("k_lo_off", C.c_int32), ("p_split", C.c_int32),
+        ("reserved1", C.c_int32), ("vt_lo_off", C.c_int64),
     ]
 
 
@@ -98,6 +99,7 @@ SIGNATURES = {
     "omgsr_groupnorm_stats": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P]),
     "omgsr_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "omgsr_layernorm": (C.c_int, [_P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
+    "omgsr_transpose_split": (C.c_int, [_P, _P, _I, _I, _I, _L, _P]),
     "omgsr_to_operand": (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
     "omgsr_attention": (C.c_int, [C.POINTER(AttnArgs), _P]),
     "omgsr_softmax_rows": (C.c_int, [_P, _P, _L, _I, _I, _P]),

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     constexpr int VP = DMA ? 128 : 136;
     constexpr int K_BYTES = 64 * KP, V_BYTES = D * VP;
     constexpr int KT_BYTES = SPLIT ? 2 * K_BYTES : K_BYTES;          // [K_hi | K_lo] of a tile
-    constexpr int STAGE = KT_BYTES + V_BYTES;
+    constexpr int VT_BYTES = SPLIT ? 2 * V_BYTES : V_BYTES;          // [V^T_hi | V^T_lo] (the lo tile is only filled / read when p.vt_lo_off > 0)
+    constexpr int STAGE = KT_BYTES + VT_BYTES;
     constexpr int CPR = D / 8;               // 16-byte chunks per K row
     constexpr int NKC = 64 * CPR / 256;      // K chunks per thread
     constexpr int NVC = D * 8 / 256;         // V^T chunks per thread
@@ -110,14 +111,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
     }
     typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
     const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)lds;
-    // piece i of the wave's NT * NPW per tile (NT = 2, or 3 with the K_lo tile): type i % NT = K (hi) / V^T / K_lo, index i / NT
-    constexpr int NT = SPLIT ? 3 : 2;
+    // piece i of the wave's NT * NPW per tile (NT = 2, or 4 with the K_lo and V^T_lo tiles): type i % NT = K (hi) / V^T / K_lo / V^T_lo, index i / NT
+    constexpr int NT = SPLIT ? 4 : 2;
+    const bool vsplit = SPLIT && p.vt_lo_off > 0;                    // (wave-uniform: a kernel argument)
     auto issue_piece = [&](const int kt, const int buf, const int i) {
         const int j = i / NT, ty = i % NT;
         const unsigned dst = lds_base + buf * STAGE + wave * 1024 + j * 4096;
-        if (ty == 1) {
-            const unsigned char* vb = reinterpret_cast<const unsigned char*>(vp + (int64_t)kt * 64);
-            glds16_sv(vvoff, vb + (int64_t)j * 32 * p.vt_ld * 2, __builtin_amdgcn_readfirstlane(dst + KT_BYTES));
+        if (ty == 1 || ty == 3) {
+            if (ty == 3 && !vsplit) return;
+            const unsigned char* vb = reinterpret_cast<const unsigned char*>(vp + (ty == 3 ? p.vt_lo_off : 0) + (int64_t)kt * 64);
+            glds16_sv(vvoff, vb + (int64_t)j * 32 * p.vt_ld * 2, __builtin_amdgcn_readfirstlane(dst + KT_BYTES + (ty == 3 ? V_BYTES : 0)));
         } else {
             const unsigned char* kb = reinterpret_cast<const unsigned char*>(kp + (ty == 2 ? p.k_lo_off : 0) + (int64_t)kt * 64 * p.k_ld);
             glds16_sv(kvoff, kb + (int64_t)j * (4 * RPPK) * p.k_ld * 2, __builtin_amdgcn_readfirstlane(dst + (ty == 2 ? K_BYTES : 0)));
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
         for (int i = 0; i < NT * NPW; ++i) issue_piece(kt, buf, i);
     };
 
-    u32x4_t kreg[DMA ? 1 : NKC], vreg[DMA ? 1 : NVC], kreg_lo[(!DMA && SPLIT) ? NKC : 1];
+    u32x4_t kreg[DMA ? 1 : NKC], vreg[DMA ? 1 : NVC], kreg_lo[(!DMA && SPLIT) ? NKC : 1], vreg_lo[(!DMA && SPLIT) ? NVC : 1];
     auto load_tile = [&](int kt) {
         const int key_base = kt * 64;
 #pragma unroll
@@ -151,18 +154,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
             const int drow = c >> 3, kc = c & 7;
             const int key0 = key_base + kc * 8;
             const int nvalid = p.Lk - key0;
-            u32x4_t v = {0u, 0u, 0u, 0u};
+            u32x4_t v = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
             if (nvalid > 0) {
                 v = *reinterpret_cast<const u32x4_t*>(vp + (int64_t)drow * p.vt_ld + key0);
+                if constexpr (SPLIT) {
+                    if (vsplit) vl = *reinterpret_cast<const u32x4_t*>(vp + p.vt_lo_off + (int64_t)drow * p.vt_ld + key0);
+                }
                 if (nvalid < 8) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        if (2 * w >= nvalid) v[w] = 0u;
-                        else if (2 * w + 1 >= nvalid) v[w] &= 0xffffu;
+                        if (2 * w >= nvalid) { v[w] = 0u; vl[w] = 0u; }
+                        else if (2 * w + 1 >= nvalid) { v[w] &= 0xffffu; vl[w] &= 0xffffu; }
                     }
                 }
             }
             vreg[i] = v;
+            if constexpr (SPLIT) vreg_lo[i] = vl;
         }
     };
     auto write_tile = [&](int buf) {
@@ -180,6 +187,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
             unsigned char* d = Vs + (c >> 3) * VP + (c & 7) * 16;     // 8-byte aligned only
             *reinterpret_cast<u32x2_t*>(d) = (u32x2_t){vreg[i][0], vreg[i][1]};
             *reinterpret_cast<u32x2_t*>(d + 8) = (u32x2_t){vreg[i][2], vreg[i][3]};
+            if constexpr (SPLIT) {
+                *reinterpret_cast<u32x2_t*>(d + V_BYTES) = (u32x2_t){vreg_lo[i][0], vreg_lo[i][1]};
+                *reinterpret_cast<u32x2_t*>(d + V_BYTES + 8) = (u32x2_t){vreg_lo[i][2], vreg_lo[i][3]};
+            }
         }
     };
 
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
 
         // S^T = K Q^T : two 32-key blocks
         f32x16_t s[2];
-        x8_t<T> vf[DMA ? NDB : 1][4];
+        x8_t<T> vf[DMA ? NDB : 1][4], vfl[(DMA && SPLIT) ? NDB : 1][(DMA && SPLIT) ? 4 : 1];
         if constexpr (DMA) {
             // every K fragment of the tile is requested before the first MFMA (left to itself hipcc reuses ONE fragment
             // register: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, 32 exposed LDS latencies per tile); sched_barriers pin the phases
@@ -269,6 +280,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) vf[db][c] = *reinterpret_cast<const x8_t<T>*>(Vs + 32 * db * VP + voff[c]);
+            if constexpr (SPLIT) {
+                if (vsplit) {
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) vfl[db][c] = *reinterpret_cast<const x8_t<T>*>(Vs + V_BYTES + 32 * db * VP + voff[c]);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         } else {
 #pragma unroll
@@ -368,6 +387,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
 #pragma unroll
                             for (int u = 0; u < 2; ++u) o[db] = mfma32(vf[db][2 * sb + u], pfl[sb][u], o[db]);
                 }
+                if (vsplit) {
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) o[db] = mfma32(vfl[db][2 * sb + u], pf[sb][u], o[db]);
+                }
             }
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
@@ -390,6 +417,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const omgsr_attn_args p, c
                         const u32x4_t both = {lo[0], lo[1], hi[0], hi[1]};
                         if constexpr (SPLIT) {
                             if (psplit) o[db] = mfma32(*reinterpret_cast<const x8_t<T>*>(&both), pfl[sb][u], o[db]);
+                            if (vsplit) {
+                                const u32x2_t llo = *reinterpret_cast<const u32x2_t*>(a + V_BYTES);
+                                const u32x2_t lhi = *reinterpret_cast<const u32x2_t*>(a + V_BYTES + 16);
+                                const u32x4_t bl = {llo[0], llo[1], lhi[0], lhi[1]};
+                                o[db] = mfma32(*reinterpret_cast<const x8_t<T>*>(&bl), pf[sb][u], o[db]);
+                            }
                         }
                         o[db] = mfma32(*reinterpret_cast<const x8_t<T>*>(&both), pf[sb][u], o[db]);
                     }
@@ -444,7 +477,7 @@ float g_defer_max = 0.0f;
 template <int D, bool DMA, bool SPLIT = false>
 int launch_attn(const omgsr_attn_args& a, hipStream_t st) {
     constexpr int KT = SPLIT ? 2 : 1;
-    constexpr int LDS = DMA ? 2 * (KT * 64 * 2 * D + D * 128) : 2 * (KT * 64 * (2 * D + 16) + D * 136);
+    constexpr int LDS = DMA ? 2 * KT * (64 * 2 * D + D * 128) : 2 * KT * (64 * (2 * D + 16) + D * 136);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<bf16_t, D, DMA, SPLIT>),
@@ -483,7 +516,8 @@ extern "C" int omgsr_attention(const omgsr_attn_args* ap, void* stream) {
     // two-term split q / k (ABI v17): both or neither, 16-byte aligned low halves, head_dim 64 (the UNet's; FLUX's RMS-normalised q / k do not need it)
     const bool split = a.q_lo_off != 0 || a.k_lo_off != 0;
     if (split && (a.q_lo_off <= 0 || a.k_lo_off <= 0 || (a.q_lo_off & 7) || (a.k_lo_off & 7) || a.D != 64)) return OMGSR_E_SHAPE;
-    if (a.p_split && !split) return OMGSR_E_SHAPE;
+    if ((a.p_split || a.vt_lo_off) && !split) return OMGSR_E_SHAPE;
+    if (a.vt_lo_off < 0 || (a.vt_lo_off & 7)) return OMGSR_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const double flops = 4.0 * (double)a.B * a.H * (double)a.Lq * a.Lk * a.D;         // (work handed: the split form's extra passes are overhead)
     const double bytes = 2.0 * (double)a.B * a.H * a.D * ((split ? 3.0 : 2.0) * a.Lq + (split ? 3.0 : 2.0) * a.Lk);

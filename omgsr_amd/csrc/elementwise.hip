@@ -87,6 +87,41 @@ __global__ void to_operand_kernel(const float* __restrict__ x, void* __restrict_
     }
 }
 
+// x f32 [B][L][C] -> y [B][2C][ld]: y[b][c][l] = hi, y[b][C + c][l] = lo of the two-term split, transposed through a 64 x 64 LDS tile
+// (reads coalesced along c, 16-byte stores along l). The attention's V^T operand in the range-fallback tier (omgsr_attn_args.vt_lo_off).
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ x, T* __restrict__ y, int L, int C, int64_t ld) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, l0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const float* xb = x + (int64_t)b * L * C;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int l = i >> 6, c = i & 63;
+        tile[l][c] = (l0 + l < L && c0 + c < C) ? xb[(int64_t)(l0 + l) * C + c0 + c] : 0.0f;
+    }
+    __syncthreads();
+    T* yb = y + (int64_t)b * 2 * C * ld;
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {          // 64 channels x 8 groups of 8 consecutive l
+        const int c = i >> 3, g = (i & 7) * 8;
+        if (c0 + c >= C || l0 + g >= L) continue;
+        float hi[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = tile[g + e][c];
+            const T h = (T)v;
+            hi[e] = (float)h;
+            lo[e] = v - hi[e];
+        }
+        T* dh = yb + (int64_t)(c0 + c) * ld + l0 + g;
+        T* dl = dh + (int64_t)C * ld;
+        if (l0 + g + 8 <= L) {
+            *reinterpret_cast<u32x4_t*>(dh) = pack8<T>(hi);
+            *reinterpret_cast<u32x4_t*>(dl) = pack8<T>(lo);
+        } else {
+            for (int e = 0; e < 8 && l0 + g + e < L; ++e) { dh[e] = (T)hi[e]; dl[e] = (T)lo[e]; }
+        }
+    }
+}
+
 // z = ((mu + exp(0.5*clamp(logvar,-30,20)) * eps) - shift) * scale, fp32 math, one rounding.
 template <typename T>      // T: compute type or float (moments and z share it)
 __global__ void vae_sample_kernel(const T* __restrict__ mom, const float* __restrict__ eps, T* __restrict__ z, int64_t rows,
@@ -276,6 +311,16 @@ extern "C" int omgsr_to_operand(const float* x, void* y, int64_t rows, int32_t C
         else hipLaunchKernelGGL((to_operand_kernel<f16_t, 3>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C, overflow_flag);
     } else if (y_el == OMGSR_EL_SPLIT) OMGSR_DISPATCH_T(hipLaunchKernelGGL((to_operand_kernel<T, 2>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C, overflow_flag));
     else OMGSR_DISPATCH_T(hipLaunchKernelGGL((to_operand_kernel<T, 0>), grid1d(rows * (C >> 3)), dim3(256), 0, st, x, y, rows, C, overflow_flag));
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_transpose_split(const float* x, void* y, int32_t B, int32_t L, int32_t C, int64_t ld, void* stream) {
+    if (!x || !y || B <= 0 || L <= 0 || C <= 0) return OMGSR_E_BADARG;
+    if (ld < L || (ld & 7)) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 8.0 * (double)B * L * C, st);
+    const dim3 grid((unsigned)((L + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
+    OMGSR_DISPATCH_T(hipLaunchKernelGGL(transpose_split_kernel<T>, grid, dim3(256), 0, st, x, (T*)y, L, C, ld));
     return (int)hipGetLastError();
 }
 

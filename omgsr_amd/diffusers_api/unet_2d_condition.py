@@ -97,7 +97,8 @@ class Attention(nn.Module):
         sp = ops.attn_split() and self.dim_head == 64
         # [B, L, 2*inner]; range-fallback tier: [q_hi | k_hi | q_lo | k_lo] (two-term split from the projection's epilogue, ops.attn_split)
         qk = ops.linear(xn, self._qk_packed(), out_dtype=ops.OUT_BF16, out_split=2 if sp else 1)
-        vt = ops.linear_t(xn, self.to_v.packed(), L)                    # [B, inner, L8]
+        # [B, inner, L8]; split: [B, 2 * inner, L8] = V^T hi rows, then lo rows (fp32 projection output transposed by transpose_split)
+        vt = ops.transpose_split(ops.linear(xn, self.to_v.packed(), out_dtype=ops.OUT_F32)) if sp else ops.linear_t(xn, self.to_v.packed(), L)
         o = ops.attention(qk, qk, vt, self.heads, self.dim_head, self.scale, q_col=0, k_col=self.inner, Lk=L,
                           out_split=self.to_out[0].in_split(), q_lo_col=2 * self.inner if sp else None, k_lo_col=3 * self.inner if sp else None)
         return self.to_out[0].nhwc(o, residual=residual)
@@ -110,7 +111,8 @@ class Attention(nn.Module):
         def build():
             e = ehs.float().contiguous() if ops.precise() else ehs.to(ops.act_dtype()).contiguous()
             kk = ops.linear(e, self.to_k.packed(), out_dtype=ops.OUT_BF16, out_split=2 if sp else 1)      # [Bc, 77, inner] ([k_hi | k_lo] when split)
-            vt = ops.linear_t(e, self.to_v.packed(), e.shape[1])                # [Bc, inner, 80]
+            vt = (ops.transpose_split(ops.linear(e, self.to_v.packed(), out_dtype=ops.OUT_F32)) if sp else
+                  ops.linear_t(e, self.to_v.packed(), e.shape[1]))              # [Bc, inner, 80] ([Bc, 2 * inner, 80] when split)
             return kk, vt, e.shape[1]
         return self._ctx_cache.get((ehs,), self._ctx_key(), build)
 

@@ -871,6 +871,17 @@ def linear_t(x: torch.Tensor, pw: PackedWeight, rows_per_batch: int, ld: Optiona
     return out
 
 
+def transpose_split(x: torch.Tensor, ld: Optional[int] = None) -> torch.Tensor:
+    """x fp32 [B, L, C] (a projection's stream output) -> [B, 2C, ld] in the operand type: rows [0, C) = round(x)^T, rows [C, 2C) = the low halves.
+    The attention's V^T operand as a two-term split (range-fallback tier, ops.attn_split). Columns >= L are zero."""
+    _req(x, torch.float32, "x")
+    B, L, Cc = x.shape
+    ld = ld or _round_up(L, 8)
+    out = (torch.zeros if ld != L else torch.empty)((B, 2 * Cc, ld), device=x.device, dtype=act_dtype())
+    check(_lib.load().omgsr_transpose_split(x.data_ptr(), out.data_ptr(), B, L, Cc, ld, _stream()), "omgsr_transpose_split")
+    return out
+
+
 def bmm_nt(a_mat: torch.Tensor, b_mat: torch.Tensor, *, alpha: float = 1.0, out_dtype: int = OUT_BF16, out_split: int = 1,
            both_split: bool = False) -> torch.Tensor:
     """out[b] = alpha * a[b] @ b[b]^T ; a [B, M, K], b [B, Npad, K] operands with Npad % 128 == 0, K % 32 == 0.
@@ -1118,6 +1129,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, he
     a.q_lo_off = 0 if q_lo_col is None else q_lo_col - q_col
     a.k_lo_off = 0 if k_lo_col is None else k_lo_col - k_col
     a.p_split = int(q_lo_col is not None and p_split)
+    if vt.shape[1] == 2 * inner:                      # [Bk, 2 * inner, ld]: V^T as the transposed two-term split (transpose_split)
+        if q_lo_col is None:
+            raise ValueError("attention: a split V^T comes with split q / k")
+        a.vt_lo_off = inner * vt.shape[-1]
+    elif vt.shape[1] != inner:
+        raise ValueError(f"attention: vt has {vt.shape[1]} rows, expected {inner} (or {2 * inner} as a two-term split)")
     if out_split == 3 and o_col != 0:
         raise ValueError("attention: an MX output owns its whole row (o_col must be 0)")
     check(_lib.load().omgsr_attention(C.byref(a), _stream()), "omgsr_attention")

@@ -525,9 +525,20 @@ def test_attention_two_term_split_q_k_p(Lq, Lk, dt):
     split = ops.attention(qq, kk, vt.to(DEV), H, D, D ** -0.5, Lk=Lk, out_split=2, q_lo_col=inner, k_lo_col=inner)
     qk_only = ops.attention(qq, kk, vt.to(DEV), H, D, D ** -0.5, Lk=Lk, out_split=2, q_lo_col=inner, k_lo_col=inner, p_split=False)
     e1, e2, e3 = _rel(both(single), ref), _rel(both(split), ref), _rel(both(qk_only), ref)
-    print(f"attention {Lq} x {Lk} {dt}: single {e1:.2e}  q/k split {e3:.2e}  q/k/P split {e2:.2e}")
+    # V as a two-term split too (omgsr_transpose_split from the fp32 values): against the fp64 attention of the UNROUNDED v
+    v32 = torch.randn(B, Lk, inner, generator=_g(92))
+    vts = ops.transpose_split(v32.to(DEV), L8)
+    assert tuple(vts.shape) == (B, 2 * inner, L8)
+    assert torch.equal(vts[:, :inner, :Lk].cpu(), v32.to(dt).transpose(1, 2)) and torch.equal(
+        vts[:, inner:, :Lk].cpu(), (v32 - v32.to(dt).float()).to(dt).transpose(1, 2)) and bool((vts[..., Lk:] == 0).all())
+    ref_v = (torch.softmax(qh @ kh.transpose(-1, -2) * D ** -0.5, -1) @ v32.double().reshape(B, -1, H, D).transpose(1, 2)).transpose(1, 2).reshape(B, Lq, inner)
+    allsp = ops.attention(qq, kk, vts, H, D, D ** -0.5, Lk=Lk, out_split=2, q_lo_col=inner, k_lo_col=inner)
+    e4, e5 = _rel(both(allsp), ref_v), _rel(both(split), ref_v)
+    print(f"attention {Lq} x {Lk} {dt}: single {e1:.2e}  q/k split {e3:.2e}  q/k/P split {e2:.2e}; vs unrounded V: q/k/P split {e5:.2e}, q/k/P/V split {e4:.2e}")
     bound = 3e-5 if dt == torch.bfloat16 else 3e-6
     assert e2 < bound and e2 < e3 < e1 and e1 > 20 * e2
+    assert e4 < bound and e5 > 20 * e4
+    assert torch.equal(ops.attention(qq, kk, vts, H, D, D ** -0.5, Lk=Lk, out_split=2, q_lo_col=inner, k_lo_col=inner), allsp)
     assert torch.equal(ops.attention(qq, kk, vt.to(DEV), H, D, D ** -0.5, Lk=Lk, out_split=2, q_lo_col=inner, k_lo_col=inner), split)
     # a fused [q | k] projection buffer: [q_hi | k_hi | q_lo | k_lo] (the UNet's self-attention in the range-fallback tier)
     if Lq == Lk:
