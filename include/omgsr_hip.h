@@ -367,6 +367,11 @@ int omgsr_crop_nhwc(const void* src, void* dst, int32_t N, int32_t H, int32_t W,
 int omgsr_paste_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t sH, int32_t sW, int32_t sy0,
                      int32_t sx0, int32_t dH, int32_t dW, int32_t dy0, int32_t dx0, int32_t th, int32_t tw,
                      int32_t el, void* stream);
+/* ABI v17: F.interpolate(x, scale_factor = s, mode = "nearest-exact") on an NHWC tensor (the fast tiled-VAE mode's down-sampled copy,
+ * infer/vaehook.py:714-735): dst[n][y][x] = src[n][min(floorf((y + .5) scale_y), H - 1)][min(floorf((x + .5) scale_x), W - 1)] with
+ * scale_* = (float)(1 / s) (ATen's nearest_exact_idx); Ho = floor(H s), Wo = floor(W s) are the caller's. C % 8 == 0 (% 4 for OMGSR_EL_F32). */
+int omgsr_resize_nearest_exact_nhwc(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                                    float scale_y, float scale_x, int32_t el, void* stream);
 /* Flux 2x2 pack / unpack between NHWC [N,H,W,C(ld)] and tokens [N,(H/2)(W/2),4C] with channel
  * order c*4 + dy*2 + dx (infer/omgsr_f_infer_model.py:21-41). dir 0 = pack, 1 = unpack. */
 int omgsr_flux_pack(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ld,

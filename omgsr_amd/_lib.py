@@ -99,6 +99,7 @@ SIGNATURES = {
     "omgsr_groupnorm_stats": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P]),
     "omgsr_groupnorm_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "omgsr_layernorm": (C.c_int, [_P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
+    "omgsr_resize_nearest_exact_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
     "omgsr_transpose_split": (C.c_int, [_P, _P, _I, _I, _I, _L, _P]),
     "omgsr_to_operand": (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
     "omgsr_attention": (C.c_int, [C.POINTER(AttnArgs), _P]),

@@ -201,6 +201,24 @@ __global__ void crop_kernel(const u32x4_t* __restrict__ src, u32x4_t* __restrict
     dst[i] = src[(((int64_t)n * H + y0 + y) * W + x0 + x) * ng + g];
 }
 
+// F.interpolate(mode = "nearest-exact") on an NHWC tensor, 16-byte chunks: src index = min(floorf((dst + 0.5) * scale), in - 1) with
+// scale = (float)(1 / scale_factor), the product in double and rounded to float before the floor - ATen's CPU formula (nearest_exact_idx),
+// which is what the reference's fast tiled-VAE mode runs (infer/vaehook.py:714-735).
+__global__ void resize_nearest_exact_kernel(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, int N, int H, int W, int ng, int Ho, int Wo,
+                                            float sy, float sx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * Ho * Wo * ng) return;
+    const int g = (int)(i % ng);
+    int64_t r = i / ng;
+    const int x = (int)(r % Wo); r /= Wo;
+    const int y = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    int iy = (int)floorf((float)(((double)y + 0.5) * (double)sy)), ix = (int)floorf((float)(((double)x + 0.5) * (double)sx));
+    iy = iy < H - 1 ? iy : H - 1;
+    ix = ix < W - 1 ? ix : W - 1;
+    dst[i] = src[(((int64_t)n * H + iy) * W + ix) * ng + g];
+}
+
 __global__ void paste_kernel(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, int N, int ng, int sH, int sW, int sy0, int sx0,
                              int dH, int dW, int dy0, int dx0, int th, int tw) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -408,6 +426,18 @@ extern "C" int omgsr_crop_nhwc(const void* src, void* dst, int32_t N, int32_t H,
     const int64_t total = (int64_t)N * th * tw * ng;
     omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 32.0 * total, st);
     hipLaunchKernelGGL(crop_kernel, grid1d(total), dim3(256), 0, st, (const u32x4_t*)src, (u32x4_t*)dst, N, H, W, ng, y0, x0, th, tw);
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_resize_nearest_exact_nhwc(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                                               float scale_y, float scale_x, int32_t el, void* stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return OMGSR_E_BADARG;
+    if ((el == OMGSR_EL_F32 ? (C & 3) : (C & 7)) || !(scale_y > 0.0f) || !(scale_x > 0.0f)) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int ng = el == OMGSR_EL_F32 ? C >> 2 : C >> 3;
+    const int64_t total = (int64_t)N * Ho * Wo * ng;
+    omgsr::TimingScope ts(OMGSR_TK_ELT, 0.0, 32.0 * total, st);
+    hipLaunchKernelGGL(resize_nearest_exact_kernel, grid1d(total), dim3(256), 0, st, (const u32x4_t*)src, (u32x4_t*)dst, N, H, W, ng, Ho, Wo, scale_y, scale_x);
     return (int)hipGetLastError();
 }
 

@@ -1290,6 +1290,20 @@ def crop_nhwc(x: torch.Tensor, y0: int, x0: int, th: int, tw: int) -> torch.Tens
     return out
 
 
+def resize_nearest_exact(x: torch.Tensor, scale_factor: float) -> torch.Tensor:
+    """F.interpolate(x_nchw, scale_factor=s, mode="nearest-exact") on an NHWC tensor [N, H, W, C] (any element kind): output
+    [N, floor(H s), floor(W s), C], source index min(floorf((dst + .5) * (float)(1 / s)), in - 1) - ATen's formula (omgsr_resize_nearest_exact_nhwc)."""
+    import math
+    el = _el(x, "x")
+    N, H, W, Cc = x.shape
+    Ho, Wo = int(math.floor(float(H) * scale_factor)), int(math.floor(float(W) * scale_factor))
+    out = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=x.dtype)
+    inv = float(torch.tensor(1.0 / scale_factor, dtype=torch.float32))            # (float)(1 / s), as compute_scales_value<float> makes it
+    check(_lib.load().omgsr_resize_nearest_exact_nhwc(x.data_ptr(), out.data_ptr(), N, H, W, Cc, Ho, Wo, inv, inv, el, _stream()),
+          "omgsr_resize_nearest_exact_nhwc")
+    return out
+
+
 def paste_nhwc(src: torch.Tensor, dst: torch.Tensor, sy0: int, sx0: int, dy0: int, dx0: int, th: int, tw: int) -> None:
     """dst[:, dy0:dy0+th, dx0:dx0+tw, :] = src[:, sy0:sy0+th, sx0:sx0+tw, :] (NHWC, same N, C and element kind)."""
     el = _el(src, "src")

@@ -21,7 +21,6 @@ import math
 from typing import Dict, List, Tuple
 
 import torch
-import torch.nn.functional as F
 
 from .. import ops
 
@@ -217,13 +216,15 @@ class VAEHook:
         re-standardisation act on one small tensor and use torch (plumbing); the network pass uses the HIP kernels."""
         N, H, W, Cp = x.shape
         scale = self.tile_size / max(H, W)
-        xc = x.permute(0, 3, 1, 2).float()
-        small = F.interpolate(xc, scale_factor=scale, mode="nearest-exact")
-        std_o, mean_o = torch.std_mean(xc, dim=[0, 2, 3], keepdim=True)
-        std_n, mean_n = torch.std_mean(small, dim=[0, 2, 3], keepdim=True)
+        # the down-sampled copy comes from the library's own gather kernel (F.interpolate's nearest-exact index formula, ops.resize_nearest_exact);
+        # the per-channel moments of the two tensors are reductions over one small tensor (torch, plumbing - like the reference's own)
+        xc = x.float()
+        small = ops.resize_nearest_exact(x, scale).float()
+        std_o, mean_o = torch.std_mean(xc, dim=[0, 1, 2], keepdim=True)
+        std_n, mean_n = torch.std_mean(small, dim=[0, 1, 2], keepdim=True)
         std_n = torch.where(std_n == 0, torch.ones_like(std_n), std_n)      # zero-padded channels
         small = ((small - mean_n) / std_n * std_o + mean_o).clamp_(min=float(xc.min()), max=float(xc.max()))
-        small = small.permute(0, 2, 3, 1).to(ops.stream_dtype()).contiguous()
+        small = small.to(ops.stream_dtype()).contiguous()
         record: list = []
         self._run(seq, {(small.shape[1], small.shape[2]): small}, {(small.shape[1], small.shape[2]): 1}, N, record=record)
         return record
