@@ -311,6 +311,9 @@ int omgsr_attention(const omgsr_attn_args* a, void* stream);
 /* Row softmax for the unfused d=512 VAE attention: p = softmax(s[:, :Lvalid]); s f32 [rows][L],
  * p bf16 [rows][L]; columns >= Lvalid (zero-padded keys) come out as exactly 0. */
 int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t L, int32_t Lvalid, void* stream);
+/* ABI v17: the same with the probabilities as a two-term split, p [rows][2 L] = [p_hi | p_lo] (range-fallback tier: the first factor of the
+ * PV product, omgsr_igemm with in_ld = L and a [v_hi | v_hi | v_lo] second factor). */
+int omgsr_softmax_rows_split(const float* s, void* p, int64_t rows, int32_t L, int32_t Lvalid, void* stream);
 
 /*
  * K11 — RMSNorm(q,k over head_dim) * w then interleaved-pair RoPE, in place

@@ -104,6 +104,7 @@ SIGNATURES = {
     "omgsr_to_operand": (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
     "omgsr_attention": (C.c_int, [C.POINTER(AttnArgs), _P]),
     "omgsr_softmax_rows": (C.c_int, [_P, _P, _L, _I, _I, _P]),
+    "omgsr_softmax_rows_split": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "omgsr_rmsnorm_rope": (C.c_int, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _I, _F, _P]),
     "omgsr_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "omgsr_nhwc_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P]),

@@ -428,12 +428,14 @@ __global__ __launch_bounds__(256) void layernorm_block_kernel(const void* __rest
 
 // ---------------------------------------------------------------------------------------------
 // Row softmax fp32 -> bf16, one 256-thread block per row, L <= 256*4*MAXV.
-template <typename T, int MAXV>
+// SPLIT (round 6): the probabilities as the two-term split [p_hi (L) | p_lo (L)] per row (range-fallback tier: the PV product of the VAE's
+// one-head attention runs p_hi v_hi + p_lo v_hi + p_hi v_lo, bmm_nt(both_split)).
+template <typename T, int MAXV, bool SPLIT = false>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, T* __restrict__ p, int L, int Lvalid) {
     __shared__ float red[8];
     const int t = threadIdx.x;
     const float* sr = s + (int64_t)blockIdx.x * L;
-    T* pr = p + (int64_t)blockIdx.x * L;
+    T* pr = p + (int64_t)blockIdx.x * (SPLIT ? 2 * L : L);
     const int nv = L >> 2;
     f32x4_t v[MAXV];
     float mx = -3.0e38f;
@@ -472,6 +474,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
             o[0] = pack2<T>(v[i][0] * inv, v[i][1] * inv);
             o[1] = pack2<T>(v[i][2] * inv, v[i][3] * inv);
             *reinterpret_cast<u32x2_t*>(pr + 4 * j) = o;
+            if constexpr (SPLIT) {
+                const T* hp = reinterpret_cast<const T*>(&o);
+                u32x2_t l;
+                l[0] = pack2<T>(v[i][0] * inv - (float)hp[0], v[i][1] * inv - (float)hp[1]);
+                l[1] = pack2<T>(v[i][2] * inv - (float)hp[2], v[i][3] * inv - (float)hp[3]);
+                *reinterpret_cast<u32x2_t*>(pr + L + 4 * j) = l;
+            }
         }
     }
 }
@@ -746,6 +755,18 @@ extern "C" int omgsr_softmax_rows(const float* s, void* p, int64_t rows, int32_t
     if (nv <= 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((softmax_rows_kernel<T, 1>), dim3((unsigned)rows), dim3(256), 0, st, s, (T*)p, L, Lvalid));
     else if (nv <= 4) OMGSR_DISPATCH_T(hipLaunchKernelGGL((softmax_rows_kernel<T, 4>), dim3((unsigned)rows), dim3(256), 0, st, s, (T*)p, L, Lvalid));
     else OMGSR_DISPATCH_T(hipLaunchKernelGGL((softmax_rows_kernel<T, 16>), dim3((unsigned)rows), dim3(256), 0, st, s, (T*)p, L, Lvalid));
+    return (int)hipGetLastError();
+}
+
+extern "C" int omgsr_softmax_rows_split(const float* s, void* p, int64_t rows, int32_t L, int32_t Lvalid, void* stream) {
+    if (!s || !p || rows <= 0 || L <= 0 || Lvalid <= 0 || Lvalid > L) return OMGSR_E_BADARG;
+    if ((L & 3) || L > 256 * 4 * 16 || rows >= (1ll << 31)) return OMGSR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    omgsr::TimingScope ts(OMGSR_TK_SOFTMAX, 0.0, 8.0 * (double)rows * L, st);
+    const int nv = (L / 4 + 255) / 256;
+    if (nv <= 1) OMGSR_DISPATCH_T(hipLaunchKernelGGL((softmax_rows_kernel<T, 1, true>), dim3((unsigned)rows), dim3(256), 0, st, s, (T*)p, L, Lvalid));
+    else if (nv <= 4) OMGSR_DISPATCH_T(hipLaunchKernelGGL((softmax_rows_kernel<T, 4, true>), dim3((unsigned)rows), dim3(256), 0, st, s, (T*)p, L, Lvalid));
+    else OMGSR_DISPATCH_T(hipLaunchKernelGGL((softmax_rows_kernel<T, 16, true>), dim3((unsigned)rows), dim3(256), 0, st, s, (T*)p, L, Lvalid));
     return (int)hipGetLastError();
 }
 

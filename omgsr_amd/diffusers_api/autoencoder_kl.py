@@ -137,7 +137,11 @@ class VaeAttention(nn.Module):
         # qk_split (accurate tier, omgsr_amd/precision.py VAE_QK_SPLIT): q and k leave their projections as two-term splits and the
         # score GEMM runs q_hi k_hi + q_lo k_hi + q_hi k_lo - the logits of a 4096-key softmax over ONE 512-wide head are where this
         # block's rounding is amplified (13 of the 44 units of the worst of 80 draws; tests/emulate_numerics.py --attn-exact dec:qk)
-        qk2 = ops.precise() and getattr(self, "qk_split", False)
+        # Range-fallback tier (ops.attn_split: bf16 operands, 8-bit mantissas): q and k split in BOTH attentions, and the probabilities and V as
+        # two-term splits too, so the PV product runs p_hi v_hi + p_lo v_hi + p_hi v_lo (round 6: the sentinel draw 16 measured 2.8e-3 in that
+        # tier with single bf16 P / V here after the UNet's flash kernel had been fixed)
+        full = ops.attn_split()
+        qk2 = ops.precise() and (getattr(self, "qk_split", False) or full)
         q = self.to_q.nhwc(g, out_dtype=ops.OUT_BF16, out_split=2 if qk2 else 1)
         k = self.to_k.nhwc(g, out_dtype=ops.OUT_BF16, out_split=2 if qk2 else 1)
         if qk2:
@@ -146,11 +150,18 @@ class VaeAttention(nn.Module):
             kp = torch.zeros((N, Lp, Cc), device=x.device, dtype=ops.act_dtype())
             kp[:, :L] = k
             k = kp
-        vt = ops.linear_t(g, self.to_v.packed(), L, ld=Lp)                    # [N, C, Lp], zero padded keys
         s = ops.bmm_nt(q, k, alpha=self.scale, out_dtype=ops.OUT_F32, both_split=qk2)         # [N, L, Lp] fp32 scores
-        p = ops.softmax_rows(s, valid=L)
-        del s
-        o = ops.bmm_nt(p, vt, out_split=self.to_out[0].in_split())            # [N, L, C] operand of the output projection
+        if full:
+            vts = ops.transpose_split(self.to_v.nhwc(g, out_dtype=ops.OUT_F32), Lp)           # [N, 2C, Lp]: V^T hi rows, then lo rows
+            vt = torch.cat([vts[:, :Cc], vts[:, :Cc], vts[:, Cc:]], dim=-1)                   # [N, C, 3 Lp] rows [v_hi | v_hi | v_lo] (plain device copies)
+            p = ops.softmax_rows(s, valid=L, split=True)                                      # [N, L, 2 Lp] rows [p_hi | p_lo]
+            del s, vts
+            o = ops.bmm_nt(p, vt, out_split=self.to_out[0].in_split(), both_split=True)
+        else:
+            vt = ops.linear_t(g, self.to_v.packed(), L, ld=Lp)                    # [N, C, Lp], zero padded keys
+            p = ops.softmax_rows(s, valid=L)
+            del s
+            o = ops.bmm_nt(p, vt, out_split=self.to_out[0].in_split())            # [N, L, C] operand of the output projection
         out = self.to_out[0].nhwc(o, residual=x.reshape(N, L, Cc), gn_groups=self.group_norm.num_groups)   # -> mid resnet norm1
         return ops.carry_gn(out, out.reshape(N, H, W, Cc))
 

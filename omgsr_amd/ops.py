@@ -1141,13 +1141,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, he
     return out
 
 
-def softmax_rows(s: torch.Tensor, valid: Optional[int] = None) -> torch.Tensor:
-    """softmax over the first `valid` columns of each row (the rest come out 0)."""
+def softmax_rows(s: torch.Tensor, valid: Optional[int] = None, split: bool = False) -> torch.Tensor:
+    """softmax over the first `valid` columns of each row (the rest come out 0). split: [..., 2 L] rows [p_hi | p_lo] (the first factor of
+    bmm_nt(both_split=True): the range-fallback tier's PV product)."""
     _req(s, torch.float32, "s")
     L = s.shape[-1]
     rows = s.numel() // L
-    p = torch.empty(s.shape, device=s.device, dtype=act_dtype())
-    check(_lib.load().omgsr_softmax_rows(s.data_ptr(), p.data_ptr(), rows, L, valid or L, _stream()), "omgsr_softmax_rows")
+    p = torch.empty(s.shape[:-1] + ((2 * L) if split else L,), device=s.device, dtype=act_dtype())
+    fn = _lib.load().omgsr_softmax_rows_split if split else _lib.load().omgsr_softmax_rows
+    check(fn(s.data_ptr(), p.data_ptr(), rows, L, valid or L, _stream()), "omgsr_softmax_rows")
     return p
 
 
