@@ -549,6 +549,34 @@ def test_attention_two_term_split_q_k_p(Lq, Lk, dt):
         ops.attention(qq, kk, vt.to(DEV), H, D, D ** -0.5, Lk=Lk, q_lo_col=inner)            # one low half without the other
 
 
+@pytest.mark.parametrize("L,valid,dt", [(4096, 4096, torch.bfloat16), (1152, 1089, torch.bfloat16), (16384, 16384, torch.float16), (128, 100, torch.bfloat16)])
+def test_softmax_rows_split_and_vae_attention_pv_split(L, valid, dt):
+    """omgsr_softmax_rows_split: p = [p_hi | p_lo] per row, hi bit-equal to the single form, hi + lo = the fp32 softmax to 2^-16; padded keys are
+    exact zeros in both halves. Then the range-fallback tier's PV product p_hi v_hi + p_lo v_hi + p_hi v_lo through bmm_nt(both_split) with V^T
+    from omgsr_transpose_split, against fp64."""
+    from omgsr_amd import ops
+    ops.set_compute_dtype(torch.float32, operand_dtype=dt)
+    rows, Cc = 256, 128
+    s = (torch.randn(1, rows, L, generator=_g(95)) * 3).to(DEV)
+    p1 = ops.softmax_rows(s, valid=valid)
+    p2 = ops.softmax_rows(s, valid=valid, split=True)
+    assert tuple(p2.shape) == (1, rows, 2 * L) and torch.equal(p2[..., :L], p1)
+    ref = torch.softmax(s[..., :valid].double().cpu(), -1)
+    got = p2[..., :L].double().cpu() + p2[..., L:].double().cpu()
+    # (fp16 at 16384 keys: probabilities ~6e-5 sit at fp16's smallest normal, their low halves are subnormal - the tier that uses the split is bf16)
+    assert bool((got[..., valid:] == 0).all()) and _rel(got[..., :valid], ref) < (2e-5 if (dt == torch.bfloat16 or L > 8192) else 2e-6)
+    assert _rel(p1[..., :valid], ref) > 20 * _rel(got[..., :valid], ref)
+    v = torch.randn(1, valid, Cc, generator=_g(96))
+    vts = ops.transpose_split(v.to(DEV), L)
+    vt3 = torch.cat([vts[:, :Cc], vts[:, :Cc], vts[:, Cc:]], -1)
+    o = ops.bmm_nt(p2, vt3, out_split=2, both_split=True)
+    o1 = ops.bmm_nt(p1, vts[:, :Cc].contiguous(), out_split=2)
+    oref = ref @ v.double()
+    e2, e1 = _rel(o[..., :Cc].float() + o[..., Cc:].float(), oref), _rel(o1[..., :Cc].float() + o1[..., Cc:].float(), oref)
+    print(f"PV {L} keys {dt}: single {e1:.2e}  split {e2:.2e}")
+    assert e2 < (3e-5 if (dt == torch.bfloat16 or L > 8192) else 3e-6) and e1 > 10 * e2
+
+
 def test_stream_plumbing_fp32():
     from omgsr_amd import ops
     x = torch.randn(2, 5, 20, 24, generator=_g(17))
