@@ -328,7 +328,12 @@ bool igemm_p8_wanted(const omgsr_igemm_args& a, const IgemmGeo& g) {
     // (bf16 130.1 -> 129.1 ms: 52 launches move, dma -5.6 ms, p8 +5.0 ms), K >= 1280 is in between. OMGSR_P8_MIN_K for A/B.
     static const char* mk = getenv("OMGSR_P8_MIN_K");
     const int min_k = mk ? atoi(mk) : 10 * BK;
-    return t256 >= min_tiles && cols256 * 16 <= cols128 * 17 && a.Cin >= min_k;
+    // padded columns allowed, in 16ths of the 128-wide grid's: 20 since round 6 (N = 640 -> 768 columns of 256-wide tiles: three passes of the operand
+    // through the LDS-DMA path instead of five outweigh 20 % more MFMA work on these stream-bound problems: 44 launches of the S-1024 step move,
+    // gmx -5.4 ms, dma -1.1 ms, p8 +5.8 ms; one-box A/B 190.30 -> 189.52 ms accurate, 120.04 -> 119.92 bf16). OMGSR_P8_PAD_NUM=17 = round 5.
+    static const char* pp = getenv("OMGSR_P8_PAD_NUM");
+    const int pad_num = pp ? atoi(pp) : 20;
+    return t256 >= min_tiles && cols256 * 16 <= cols128 * pad_num && a.Cin >= min_k;
 }
 
 int igemm_p8_launch(const omgsr_igemm_args& a, IgemmGeo g, hipStream_t st) {
