@@ -79,6 +79,16 @@ for tier in (torch.bfloat16, torch.float16):
         spec = ops.GnSpec(torch.randn(N_, 32, generator=g).to(dev) * 0.1, (1.0 + 0.1 * torch.randn(N_, 32, generator=g)).abs().to(dev),
                           (1.0 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev), 32, ops.ACT_SILU)
         total += soak(f"[{dt}] GN-fused halo conv {N_}x{H_}x{W_} {C}->{Co}", lambda: ops.conv2d(xs, pc, pad=1, gn=spec), reps)
+# round 6: the flash kernel with q / k / P / V as two-term splits (K_lo and V^T_lo tiles ride through LDS behind the hi tiles: more LDS-DMA pieces per
+# tile under the same vmcnt(0) wait) - the range-fallback tier's UNet attention, LDS-DMA and register-staged paths; and the XCD-ordered 1-D grid
+ops.set_compute_dtype(torch.float32, operand_dtype=torch.bfloat16)
+for B, H, D, Lq, Lk in [(8, 5, 64, 4096, 4096), (36, 5, 64, 4096, 77), (4, 10, 64, 1024, 1024)]:
+    inner = H * D
+    sp = lambda t: torch.cat([t.to(torch.bfloat16), (t - t.to(torch.bfloat16).float()).to(torch.bfloat16)], -1)       # noqa: E731
+    qq = sp(torch.randn(B, Lq, inner, generator=g)).to(dev)
+    kk = sp(torch.randn(1 if Lk == 77 else B, Lk, inner, generator=g)).to(dev)
+    vts = ops.transpose_split((torch.randn(1 if Lk == 77 else B, Lk, inner, generator=g)).to(dev), (Lk + 7) // 8 * 8)
+    total += soak(f"[fallback] split attention {B}x{H}x{D} Lq {Lq} Lk {Lk}", lambda: ops.attention(qq, kk, vts, H, D, D ** -0.5, Lk=Lk, out_split=2, q_lo_col=inner, k_lo_col=inner), reps)
 ops.set_compute_dtype(torch.bfloat16)
 print("TOTAL differing:", total)
 sys.exit(1 if total else 0)
