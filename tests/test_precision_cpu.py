@@ -189,3 +189,48 @@ def test_phase_summed_kernels_equal_the_upsampled_conv():
         for b in (0, 1):
             out[:, :, a::2, b::2] = F.conv2d(F.pad(x, (1 - b, b, 1 - a, a)), ph[2 * a + b].permute(0, 3, 1, 2))
     assert (out - ref).abs().max() < 1e-5
+
+
+def test_w_lo_segment_of_a_phase_form_conv_is_kept_when_the_phase_sums_are_not_exact():
+    """Round 6: pack_conv_weight drops the [w_lo] K segment when every weight is exact in the compute type. An up-sampling conv also carries its four
+    phase-summed 2 x 2 kernels (sums of 2 - 4 taps): bf16-representable TAPS do not make their SUMS bf16-representable, so in the range-fallback tier
+    (bf16 operands) the sums were rounded to 8 bits with no w_lo to carry the rest - 3.4e-3 against the oracle where full-mantissa weights measure
+    1.1e-3. The segment now goes only if the phase sums are exact too; both packings of one layer keep the same K layout."""
+    from omgsr_amd import ops
+    ops.set_compute_dtype(torch.float32, operand_dtype=torch.bfloat16)       # the range-fallback tier's operand type (host-side switch)
+    try:
+        g = torch.Generator().manual_seed(3)
+        w = (torch.randn(64, 32, 3, 3, generator=g) * 0.05).to(torch.bfloat16).float()          # exact in bf16
+        plain = ops.pack_conv_weight(w, None, device="cpu", split=2, w_split=2)
+        assert plain.w_split == 1                                              # nothing to carry: the segment is dropped (same bits, less work)
+        up = ops.pack_conv_weight(w, None, device="cpu", split=2, w_split=2, upsample_phases=True)
+        ph = ops._phase_kernels(w.permute(0, 2, 3, 1))
+        assert not torch.equal(ph.to(torch.bfloat16).float(), ph)              # the sums really are inexact in bf16
+        assert up.w_split == 2 and up.w_ph is not None
+        # [4][Cin/32][4 taps][Cout_pad][32] with Cin = 32 * 3 segments: hi | hi | lo of the phase sums reproduce them to 2^-16
+        seg = up.w_ph.float().reshape(4, 3, 4, up.w_ph.shape[3], 32)[:, :, :, :64]                # [phase][segment][tap][cout][32]
+        want = ph.reshape(4, 64, 4, 32).permute(0, 2, 1, 3)                                       # [phase][tap][cout][c]
+        assert torch.equal(seg[:, 0], seg[:, 1])
+        assert ((seg[:, 0] + seg[:, 2]).permute(0, 1, 2, 3) - want).abs().max() <= want.abs().max() * 2.0 ** -15
+        # exact sums (a 1-tap-per-phase kernel): dropped again
+        w1 = torch.zeros(64, 32, 3, 3); w1[:, :, 1, 1] = w[:, :, 1, 1]
+        assert ops.pack_conv_weight(w1, None, device="cpu", split=2, w_split=2, upsample_phases=True).w_split == 1
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
+
+
+def test_attn_split_follows_the_tier(monkeypatch):
+    """ops.attn_split(): the two-term split q / k / P / V inside the attention kernels belongs to the range-fallback tier (fp32 stream, bf16 operands);
+    OMGSR_ATTN_SPLIT forces it off / on in the accurate tiers only (A/B runs), never in the fast tiers."""
+    from omgsr_amd import ops
+    try:
+        monkeypatch.delenv("OMGSR_ATTN_SPLIT", raising=False)
+        ops.set_compute_dtype(torch.bfloat16); assert not ops.attn_split()
+        ops.set_compute_dtype(torch.float32); assert not ops.attn_split()
+        ops.set_compute_dtype(torch.float32, operand_dtype=torch.bfloat16); assert ops.attn_split()
+        monkeypatch.setenv("OMGSR_ATTN_SPLIT", "0"); assert not ops.attn_split()
+        monkeypatch.setenv("OMGSR_ATTN_SPLIT", "1")
+        ops.set_compute_dtype(torch.float32); assert ops.attn_split()
+        ops.set_compute_dtype(torch.bfloat16); assert not ops.attn_split()
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
