@@ -86,7 +86,9 @@ def set_compute_dtype(dtype: torch.dtype, operand_dtype: Optional[torch.dtype] =
     act = torch.bfloat16 if dtype == torch.bfloat16 else (operand_dtype or torch.float16)
     check(_lib.load().omgsr_set_compute_dtype(0 if act == torch.bfloat16 else 1), "set_compute_dtype")
     # fast tiers: deferred softmax maximum (+5 % attention); accurate tier: exact running maximum
-    check(_lib.load().omgsr_set_attention_defer_max(0.0 if dtype == torch.float32 else 8.0), "set_attention_defer_max")
+    # (OMGSR_ATTN_DEFER_ACCURATE=<log2 threshold>: A/B runs of a deferred maximum in the accurate tier)
+    acc_defer = float(os.environ.get("OMGSR_ATTN_DEFER_ACCURATE", "0"))
+    check(_lib.load().omgsr_set_attention_defer_max(acc_defer if dtype == torch.float32 else 8.0), "set_attention_defer_max")
     _ACT, _PRECISE = act, dtype == torch.float32
 
 
